@@ -1,0 +1,170 @@
+"""ORACLE (test infrastructure): ctypes binding of oracle/c/libnc_ref.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "c", "libnc_ref.so")
+_lib = None
+
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+
+
+def build(force: bool = False) -> str:
+    src = [os.path.join(_HERE, "c", f) for f in ("nc_ref.c", "ref_math.h")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+class RefDacConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_int), ("encoder_dim", C.c_int), ("n_enc_rates", C.c_int), ("enc_rates", C.c_int * 8),
+                ("decoder_dim", C.c_int), ("n_dec_rates", C.c_int), ("dec_rates", C.c_int * 8), ("latent_dim", C.c_int),
+                ("n_codebooks", C.c_int), ("codebook_size", C.c_int), ("codebook_dim", C.c_int)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.ref_dac_create.restype = C.c_void_p
+        L.ref_dac_create.argtypes = [C.POINTER(RefDacConfig), C.c_char_p, C.c_int64]
+        L.ref_dac_destroy.argtypes = [C.c_void_p]
+        L.ref_dac_frames.restype = C.c_int64
+        L.ref_dac_frames.argtypes = [C.c_void_p, C.c_int64]
+        L.ref_dac_encode.argtypes = [C.c_void_p, f32p, C.c_int64, C.c_int64, C.c_int, i64p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_dac_decode.argtypes = [C.c_void_p, f32p, C.c_int64, C.c_int64, f32p]
+        L.ref_dac_from_codes.argtypes = [C.c_void_p, i64p, C.c_int64, C.c_int, C.c_int64, f32p]
+        L.ref_conv1d.argtypes = [f32p, C.c_int64, C.c_int, C.c_int64, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_void_p, f32p, C.c_int64]
+        L.ref_conv_transpose1d.argtypes = [f32p, C.c_int64, C.c_int, C.c_int64, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, f32p, C.c_int64]
+        L.ref_snake.argtypes = [f32p, f32p, C.c_int64, C.c_int64, C.c_int64, f32p]
+        L.ref_tanh.argtypes = [f32p, C.c_int64, f32p]
+        L.ref_fold_wn_dac.argtypes = [f32p, f32p, C.c_int64, C.c_int64, f32p]
+        L.ref_vq_argmin.argtypes = [f32p, C.c_int64, C.c_int, C.c_int64, f32p, C.c_int, i64p, f32p, C.c_void_p]
+        L.ref_num_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _opt(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def conv1d(x, w, bias=None, stride=1, pad=0, dil=1, groups=1, residual=None):
+    x = np.ascontiguousarray(x, np.float32); w = np.ascontiguousarray(w, np.float32)
+    B, Cin, Tin = x.shape
+    Cout, _, K = w.shape
+    Tout = (Tin + 2 * pad - dil * (K - 1) - 1) // stride + 1
+    y = np.empty((B, Cout, Tout), np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    r = None if residual is None else np.ascontiguousarray(residual, np.float32)
+    lib().ref_conv1d(x, B, Cin, Tin, w, _opt(b), Cout, K, stride, pad, dil, groups, _opt(r), y, Tout)
+    return y
+
+
+def conv_transpose1d(x, w, bias=None, stride=1, pad=0, out_pad=0):
+    x = np.ascontiguousarray(x, np.float32); w = np.ascontiguousarray(w, np.float32)
+    B, Cin, Tin = x.shape
+    _, Cout, K = w.shape
+    Tout = (Tin - 1) * stride - 2 * pad + K + out_pad
+    y = np.empty((B, Cout, Tout), np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    lib().ref_conv_transpose1d(x, B, Cin, Tin, w, _opt(b), Cout, K, stride, pad, out_pad, y, Tout)
+    return y
+
+
+def snake(x, alpha):
+    x = np.ascontiguousarray(x, np.float32)
+    a = np.ascontiguousarray(alpha, np.float32).reshape(-1)
+    y = np.empty_like(x)
+    lib().ref_snake(x, a, x.shape[0], x.shape[1], x.shape[2], y)
+    return y
+
+
+def tanh(x):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    lib().ref_tanh(x, x.size, y)
+    return y
+
+
+def fold_wn_dac(v, g):
+    v = np.ascontiguousarray(v, np.float32); g = np.ascontiguousarray(g, np.float32).reshape(-1)
+    w = np.empty_like(v)
+    lib().ref_fold_wn_dac(v, g, v.shape[0], int(np.prod(v.shape[1:])), w)
+    return w
+
+
+def vq_argmin(z_e, codebook):
+    z_e = np.ascontiguousarray(z_e, np.float32); cb = np.ascontiguousarray(codebook, np.float32)
+    B, D, T = z_e.shape
+    idx = np.empty((B, T), np.int64); st = np.empty_like(z_e); bd = np.empty((B, T), np.float32)
+    lib().ref_vq_argmin(z_e, B, D, T, cb, cb.shape[0], idx, st, bd.ctypes.data_as(C.c_void_p))
+    return idx, st, bd
+
+
+class RefDAC:
+    """C-oracle DAC (same call surface as the reference's DAC.Encode / Decode / FromCodes)."""
+
+    def __init__(self, cfg, blob: bytes):
+        rc = RefDacConfig()
+        rc.sample_rate, rc.encoder_dim, rc.decoder_dim = cfg.sample_rate, cfg.encoder_dim, cfg.decoder_dim
+        rc.n_enc_rates, rc.n_dec_rates = len(cfg.encoder_rates), len(cfg.decoder_rates)
+        for i, r in enumerate(cfg.encoder_rates): rc.enc_rates[i] = r
+        for i, r in enumerate(cfg.decoder_rates): rc.dec_rates[i] = r
+        rc.latent_dim, rc.n_codebooks = cfg.resolved_latent_dim, cfg.n_codebooks
+        rc.codebook_size, rc.codebook_dim = cfg.codebook_size, cfg.codebook_dim
+        self.cfg = cfg
+        self._h = lib().ref_dac_create(C.byref(rc), blob, len(blob))
+        if not self._h:
+            raise RuntimeError("ref_dac_create failed (missing tensors?)")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            try:
+                _lib.ref_dac_destroy(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+    def encode(self, pcm, n_quantizers: int = 0):
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        B, _, T = pcm.shape
+        Tz = lib().ref_dac_frames(self._h, T)
+        nq = self.cfg.n_codebooks if n_quantizers <= 0 else min(n_quantizers, self.cfg.n_codebooks)
+        ld, D = self.cfg.resolved_latent_dim, self.cfg.codebook_dim
+        codes = np.empty((B, nq, Tz), np.int64)
+        zq = np.empty((B, ld, Tz), np.float32); lat = np.empty((B, nq * D, Tz), np.float32); ze = np.empty((B, ld, Tz), np.float32)
+        lib().ref_dac_encode(self._h, pcm, B, T, nq, codes, _opt(zq), _opt(lat), _opt(ze))
+        return zq, codes, lat, ze
+
+    def decode(self, z):
+        z = np.ascontiguousarray(z, np.float32)
+        B, _, Tz = z.shape
+        hop = self.cfg.hop_length
+        up = 1
+        L = Tz
+        for s in self.cfg.decoder_rates:
+            L = (L - 1) * s - 2 * ((s + 1) // 2) + 2 * s
+        pcm = np.empty((B, 1, L), np.float32)
+        lib().ref_dac_decode(self._h, z, B, Tz, pcm)
+        return pcm
+
+    def from_codes(self, codes):
+        codes = np.ascontiguousarray(codes, np.int64)
+        B, nq, Tz = codes.shape
+        z = np.empty((B, self.cfg.resolved_latent_dim, Tz), np.float32)
+        lib().ref_dac_from_codes(self._h, codes, B, nq, Tz, z)
+        return z
