@@ -1,0 +1,160 @@
+/* nc_mi355x.h -- C ABI of the MI355X-native neural-audio-codec engine (libnc_mi355x.so).
+ *
+ * This is the drop-in boundary for the reference's Encode/Decode hot path.  The reference
+ * (DillionLowry/NeuralCodecs, C#/.NET 8 on TorchSharp) has no FFI of its own for this path:
+ * every op is a TorchSharp P/Invoke into libtorch.  The functions below are what a C# shim
+ * binds with [DllImport("nc_mi355x")] to keep the managed API surface
+ * (INeuralCodec, DAC.Encode/Decode/FromCodes, SNAC.Encode/Decode, Encodec.Encode/Decode)
+ * while every FLOP runs in hand-written HIP kernels for gfx950.  See INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; tensors are dense row-major float32 [B,C,T] / int64 codes [B,Nq,T'].
+ *   - every function returns nc_status; nc_last_error() gives the thread-local message.
+ *     Mapping to the reference's exceptions: NC_EINVAL -> ArgumentException /
+ *     ArgumentNullException, NC_ENOTFOUND -> FileNotFoundException, NC_ESTATE ->
+ *     InvalidOperationException, NC_EDEVICE / NC_ENOMEM -> NeuralCodecException.
+ *   - one handle = one device + one HIP stream; calls on one handle must be serialised by the
+ *     caller (the reference's modules are not thread-safe either: WNConv1d.cs:150 mutates state
+ *     in forward); distinct handles may run concurrently.
+ *   - "*_dev" variants take DEVICE pointers, enqueue on the handle's stream and return without
+ *     synchronising (zero-copy path used by benchmarks / multi-GPU sharding); the plain variants
+ *     take HOST pointers and are synchronous (the float[] / Tensor overloads of the reference).
+ *   - there is NO CPU fallback: every entry point fails with NC_EDEVICE when no gfx950 device
+ *     is usable.
+ */
+#ifndef NC_MI355X_H
+#define NC_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NC_API __attribute__((visibility("default")))
+
+typedef enum {
+    NC_OK = 0,
+    NC_EINVAL = 1,     /* bad argument (null pointer, wrong sample rate, bad shape) */
+    NC_ENOTFOUND = 2,  /* weight file / tensor not found */
+    NC_ESTATE = 3,     /* call not valid in this state (weights not loaded, ...) */
+    NC_EDEVICE = 4,    /* HIP error / no usable device */
+    NC_ENOMEM = 5,
+    NC_EUNSUPPORTED = 6
+} nc_status;
+
+typedef struct nc_codec nc_codec; /* opaque: replaces the managed DAC / SNAC / Encodec object (INeuralCodec + IDisposable,
+                                     NeuralCodecs.Core/INeuralCodec.cs:8-20) */
+
+NC_API const char* nc_last_error(void);
+NC_API const char* nc_version(void);
+/* number of HIP devices visible (0 when none); never fails */
+NC_API int nc_device_count(void);
+
+/* ------------------------------------------------------------------------------------------ DAC
+ * replaces: new DAC(DACConfig)                    NeuralCodecs.Torch/Models/DAC.cs:51-93
+ *           fields consumed                       NeuralCodecs.Torch/Config/DAC/DACConfig.cs:22-76 */
+typedef struct {
+    int32_t sample_rate;     /* 44100 */
+    int32_t encoder_dim;     /* 64 */
+    int32_t n_encoder_rates; /* 4 */
+    int32_t encoder_rates[8];/* 2,4,8,8 */
+    int32_t decoder_dim;     /* 1536 */
+    int32_t n_decoder_rates; /* 4 */
+    int32_t decoder_rates[8];/* 8,8,4,2 */
+    int32_t latent_dim;      /* 0 => encoder_dim * 2^n_encoder_rates (DAC.cs:64) */
+    int32_t n_codebooks;     /* 9 */
+    int32_t codebook_size;   /* 1024 */
+    int32_t codebook_dim;    /* 8 */
+} nc_dac_config;
+
+NC_API nc_status nc_dac_create(const nc_dac_config* cfg, int device_index, nc_codec** out);
+
+/* replaces: IDisposable.Dispose                   Models/DAC.cs:329-338 */
+NC_API nc_status nc_codec_destroy(nc_codec* h);
+
+/* replaces: INeuralCodec.LoadWeights(path)        Models/DAC.cs:345-389 (FileNotFound / InvalidOperation)
+ * The file is an NCWB0001 weight blob whose tensor names are the reference's TorchSharp
+ * state-dict keys (weight_v / weight_g / bias / alpha / codebook.weight); the
+ * weight-norm fold w = v/(||v||+1e-7)*g (WNConv1d.cs:145-150) happens once here. */
+NC_API nc_status nc_codec_load_weights(nc_codec* h, const char* path);
+NC_API nc_status nc_codec_load_weights_mem(nc_codec* h, const void* blob, size_t nbytes);
+
+/* Run the handle's work on a caller-owned hipStream_t (NULL = the handle's own stream). */
+NC_API nc_status nc_codec_set_stream(nc_codec* h, void* hip_stream);
+NC_API nc_status nc_codec_synchronize(nc_codec* h);
+
+/* Shape helper for DAC.Preprocess (Models/DAC.cs:141-154): padded length and frame count T'. */
+NC_API nc_status nc_dac_query(const nc_codec* h, int64_t T, int64_t* T_padded, int64_t* frames);
+
+/* replaces: DAC.Encode(Tensor audio[B,1,T], int? nQuantizers, int? sampleRate)   Models/DAC.cs:163-181
+ *   pcm        [B,1,T] float32
+ *   sample_rate 0 = model rate; a mismatch returns NC_EINVAL (ArgumentException, DAC.cs:146)
+ *   n_q        0 = all codebooks (the null overload, ResidualVectorQuantizer.cs:54-103)
+ *   codes      [B,n_q,T'] int64            (required)
+ *   z          [B,latent,T'] float32       (nullable; the quantized latents zQ)
+ *   latents    [B,n_q*codebook_dim,T']     (nullable; the projected latents zE)
+ * The two loss outputs of the reference are constant 0 in inference (D5) and are not returned. */
+NC_API nc_status nc_dac_encode(nc_codec* h, const float* pcm, int32_t B, int64_t T, int32_t sample_rate, int32_t n_q,
+                               int64_t* codes, float* z, float* latents);
+NC_API nc_status nc_dac_encode_dev(nc_codec* h, const float* pcm, int32_t B, int64_t T, int32_t sample_rate, int32_t n_q,
+                                   int64_t* codes, float* z, float* latents);
+
+/* replaces: DAC.Decode(Tensor z[B,latent,T'])  -> [B,1,T'*hop]   Models/DAC.cs:231-234 (no trim: D6) */
+NC_API nc_status nc_dac_decode(nc_codec* h, const float* z, int32_t B, int64_t frames, float* pcm);
+NC_API nc_status nc_dac_decode_dev(nc_codec* h, const float* z, int32_t B, int64_t frames, float* pcm);
+
+/* replaces: DAC.FromCodes(Tensor codes[B,n_q,T']) -> z[B,latent,T']   Models/DAC.cs:101-106 */
+NC_API nc_status nc_dac_from_codes(nc_codec* h, const int64_t* codes, int32_t B, int32_t n_q, int64_t frames, float* z);
+NC_API nc_status nc_dac_from_codes_dev(nc_codec* h, const int64_t* codes, int32_t B, int32_t n_q, int64_t frames, float* z);
+
+/* ------------------------------------------------------------------------------------ profiling
+ * Per-kernel-class timing with HIP events recorded on the handle's stream around every launch
+ * (used by bench.py for the roofline object).  Classes are stable small integers. */
+typedef enum {
+    NC_KC_CONV_K7 = 0,   /* dilated k=7 residual-unit convolutions (MFMA implicit GEMM) */
+    NC_KC_CONV_K1 = 1,   /* 1x1 channel-mix convolutions */
+    NC_KC_CONV_DOWN = 2, /* strided down-sampling convolutions */
+    NC_KC_CONV_UP = 3,   /* transposed (polyphase) up-sampling convolutions */
+    NC_KC_CONV_MISC = 4, /* stem / head / k3 / decoder-input convolutions */
+    NC_KC_RVQ = 5,       /* codebook argmin + gather kernels */
+    NC_KC_COUNT = 6
+} nc_kernel_class;
+
+typedef struct {
+    int64_t launches;
+    double ms;          /* sum of event-to-event durations */
+    double flops;       /* algorithmic flops of those launches (2*Cout*Cin/g*K*Tout*B) */
+    double bytes;       /* algorithmic HBM bytes (input read once + output written once + weights once) */
+} nc_profile_entry;
+
+NC_API nc_status nc_codec_profile_enable(nc_codec* h, int32_t on);
+NC_API nc_status nc_codec_profile_reset(nc_codec* h);
+/* synchronises the stream, resolves pending events, fills out[NC_KC_COUNT] */
+NC_API nc_status nc_codec_profile_read(nc_codec* h, nc_profile_entry* out);
+
+/* ------------------------------------------------------------------------ op-level test hooks
+ * Host-pointer, synchronous single-operator entry points over the same kernels the codecs use.
+ * They exist so the parity tests can compare each HIP kernel with the oracle in isolation. */
+typedef struct {
+    int32_t B, Cin, Cout, K, stride, pad, dil, out_pad;
+    int64_t Tin;
+    int32_t transposed;      /* 0: conv1d weight [Cout,Cin,K]; 1: conv_transpose1d weight [Cin,Cout,K] */
+    int32_t tanh_out;        /* apply tanh after bias/residual */
+} nc_conv_desc;
+
+/* y = epilogue(conv(snake_in?(x))), weight is the already-folded dense weight.
+ * alpha_in [Cin] / alpha_out [Cout] / bias [Cout] / residual [B,Cout,Tout] are nullable. */
+NC_API nc_status nc_op_conv1d(int device_index, const nc_conv_desc* d, const float* x, const float* weight, const float* bias,
+                              const float* alpha_in, const float* alpha_out, const float* residual, float* y, int64_t* Tout);
+/* one VQ stage on projected latents z_e [B,D,T] against codebook [N,D] -> idx [B,T], st [B,D,T] */
+NC_API nc_status nc_op_vq_argmin(int device_index, const float* z_e, int32_t B, int32_t D, int64_t T, const float* codebook,
+                                 int32_t N, int64_t* idx, float* st);
+/* weight-norm fold w = v/(||v||+1e-7)*g over dim-0 slices (host-side, what load_weights does) */
+NC_API nc_status nc_op_fold_weight_norm(const float* v, const float* g, int64_t d0, int64_t inner, float* w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NC_MI355X_H */

@@ -1,0 +1,111 @@
+"""ctypes binding of libnc_mi355x.so (the C ABI declared in include/nc_mi355x.h).
+
+The library is the product: if it is missing or cannot be loaded this module raises -- there is
+no Python/torch fallback for any operator.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnc_mi355x.so")
+
+NC_OK, NC_EINVAL, NC_ENOTFOUND, NC_ESTATE, NC_EDEVICE, NC_ENOMEM, NC_EUNSUPPORTED = range(7)
+NC_KC_NAMES = ("conv_k7", "conv_k1", "conv_down", "conv_up", "conv_misc", "rvq")
+
+
+class NcError(RuntimeError):
+    """Base of engine errors (the reference's NeuralCodecException, Core/Exceptions/NeuralCodecException.cs:10-73)."""
+
+
+class NcDeviceError(NcError):
+    pass
+
+
+class NcDacConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_int32), ("encoder_dim", C.c_int32), ("n_encoder_rates", C.c_int32),
+                ("encoder_rates", C.c_int32 * 8), ("decoder_dim", C.c_int32), ("n_decoder_rates", C.c_int32),
+                ("decoder_rates", C.c_int32 * 8), ("latent_dim", C.c_int32), ("n_codebooks", C.c_int32),
+                ("codebook_size", C.c_int32), ("codebook_dim", C.c_int32)]
+
+
+class NcProfileEntry(C.Structure):
+    _fields_ = [("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+class NcConvDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("K", C.c_int32), ("stride", C.c_int32),
+                ("pad", C.c_int32), ("dil", C.c_int32), ("out_pad", C.c_int32), ("Tin", C.c_int64),
+                ("transposed", C.c_int32), ("tanh_out", C.c_int32)]
+
+
+_lib = None
+
+# every symbol include/nc_mi355x.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("nc_last_error", C.c_char_p, []),
+    ("nc_version", C.c_char_p, []),
+    ("nc_device_count", C.c_int, []),
+    ("nc_dac_create", C.c_int, [C.POINTER(NcDacConfig), C.c_int, C.POINTER(_P)]),
+    ("nc_codec_destroy", C.c_int, [_P]),
+    ("nc_codec_load_weights", C.c_int, [_P, C.c_char_p]),
+    ("nc_codec_load_weights_mem", C.c_int, [_P, _P, C.c_size_t]),
+    ("nc_codec_set_stream", C.c_int, [_P, _P]),
+    ("nc_codec_synchronize", C.c_int, [_P]),
+    ("nc_dac_query", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("nc_dac_encode", C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P]),
+    ("nc_dac_encode_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P]),
+    ("nc_dac_decode", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
+    ("nc_dac_decode_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
+    ("nc_dac_from_codes", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, _P]),
+    ("nc_dac_from_codes_dev", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, _P]),
+    ("nc_codec_profile_enable", C.c_int, [_P, C.c_int32]),
+    ("nc_codec_profile_reset", C.c_int, [_P]),
+    ("nc_codec_profile_read", C.c_int, [_P, C.POINTER(NcProfileEntry)]),
+    ("nc_op_conv1d", C.c_int, [C.c_int, C.POINTER(NcConvDesc), _P, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_int64)]),
+    ("nc_op_vq_argmin", C.c_int, [C.c_int, _P, C.c_int32, C.c_int32, C.c_int64, _P, C.c_int32, _P, _P]),
+    ("nc_op_fold_weight_norm", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
+]
+
+
+def lib():
+    """Load the engine.  Importing torch first (when present) makes the loader bind the already
+    loaded libamdhip64.so.7 of the torch wheel, so both share one HIP runtime in this process."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NcError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(make -C neuralcodecs_amd/csrc). There is no fallback implementation.")
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401  (shares its HIP runtime with the engine)
+        except Exception:
+            pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, res, args in SYMBOLS:
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(status: int) -> None:
+    if status == NC_OK:
+        return
+    msg = lib().nc_last_error().decode(errors="replace")
+    if status == NC_EINVAL:
+        raise ValueError(msg)              # ArgumentException / ArgumentNullException
+    if status == NC_ENOTFOUND:
+        raise FileNotFoundError(msg)       # FileNotFoundException
+    if status == NC_ESTATE:
+        raise RuntimeError(msg)            # InvalidOperationException
+    if status == NC_ENOMEM:
+        raise MemoryError(msg)
+    if status == NC_EDEVICE:
+        raise NcDeviceError(msg)
+    raise NcError(f"status {status}: {msg}")

@@ -1,0 +1,285 @@
+// C ABI (include/nc_mi355x.h): argument validation, exception -> status translation, host-buffer variants.
+#include <cstdio>
+#include <fstream>
+
+#include "nc_model.h"
+
+using namespace nc;
+
+struct nc_codec {
+    std::unique_ptr<Codec> impl;
+    int kind = 0;  // 0 = DAC
+};
+
+namespace {
+
+template <class F>
+nc_status guard(F&& f) {
+    try {
+        f();
+        return NC_OK;
+    } catch (const Error& e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        set_last_error("host allocation failed");
+        return NC_ENOMEM;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return NC_ESTATE;
+    }
+}
+
+DacModel& as_dac(nc_codec* h) {
+    if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");
+    if (h->kind != 0) fail(NC_EINVAL, "handle is not a DAC codec");
+    return static_cast<DacModel&>(*h->impl);
+}
+
+void h2d(void* d, const void* h, size_t n, hipStream_t s) { NC_HIP(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s)); }
+void d2h(void* h, const void* d, size_t n, hipStream_t s) { NC_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s)); }
+
+}  // namespace
+
+extern "C" {
+
+const char* nc_last_error(void) { return get_last_error(); }
+const char* nc_version(void) { return "nc_mi355x 0.1 (gfx950)"; }
+
+int nc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+nc_status nc_dac_create(const nc_dac_config* cfg, int device_index, nc_codec** out) {
+    return guard([&] {
+        if (!cfg || !out) fail(NC_EINVAL, "cfg and out must not be null");
+        *out = nullptr;
+        std::unique_ptr<DacModel> m(new DacModel(*cfg));
+        m->init_device(device_index);
+        nc_codec* h = new nc_codec();
+        h->impl = std::move(m);
+        h->kind = 0;
+        *out = h;
+    });
+}
+
+nc_status nc_codec_destroy(nc_codec* h) {
+    return guard([&] {
+        if (!h) return;
+        if (h->impl) {
+            h->impl->use_device();
+            (void)hipStreamSynchronize(h->impl->stream);
+        }
+        delete h;
+    });
+}
+
+nc_status nc_codec_load_weights_mem(nc_codec* h, const void* blob, size_t nbytes) {
+    return guard([&] {
+        if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");
+        if (!blob) fail(NC_EINVAL, "blob must not be null");
+        Blob b;
+        b.parse(blob, nbytes);
+        h->impl->load(b);
+    });
+}
+
+nc_status nc_codec_load_weights(nc_codec* h, const char* path) {
+    return guard([&] {
+        if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");
+        if (!path) fail(NC_EINVAL, "path must not be null");
+        std::ifstream f(path, std::ios::binary | std::ios::ate);
+        if (!f) fail(NC_ENOTFOUND, "Weights not found at %s", path);  // DAC.cs:347-350 FileNotFoundException
+        const std::streamsize n = f.tellg();
+        f.seekg(0);
+        std::vector<char> buf((size_t)n);
+        if (!f.read(buf.data(), n)) fail(NC_ESTATE, "Failed to read weights from %s", path);
+        Blob b;
+        b.parse(buf.data(), buf.size());
+        h->impl->load(b);
+    });
+}
+
+nc_status nc_codec_set_stream(nc_codec* h, void* hip_stream) {
+    return guard([&] {
+        if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");
+        h->impl->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->impl->own_stream;
+    });
+}
+
+nc_status nc_codec_synchronize(nc_codec* h) {
+    return guard([&] {
+        if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");
+        h->impl->use_device();
+        NC_HIP(hipStreamSynchronize(h->impl->stream));
+    });
+}
+
+nc_status nc_dac_query(const nc_codec* h, int64_t T, int64_t* T_padded, int64_t* frames) {
+    return guard([&] {
+        DacModel& m = as_dac(const_cast<nc_codec*>(h));
+        if (T <= 0) fail(NC_EINVAL, "T must be positive");
+        if (T_padded) *T_padded = m.padded_len(T);
+        if (frames) *frames = m.frames(T);
+    });
+}
+
+nc_status nc_dac_encode_dev(nc_codec* h, const float* pcm, int32_t B, int64_t T, int32_t sample_rate, int32_t n_q, int64_t* codes,
+                            float* z, float* latents) {
+    return guard([&] { as_dac(h).encode_dev(pcm, B, T, sample_rate, n_q, codes, z, latents); });
+}
+
+nc_status nc_dac_decode_dev(nc_codec* h, const float* z, int32_t B, int64_t frames, float* pcm) {
+    return guard([&] { as_dac(h).decode_dev(z, B, frames, pcm); });
+}
+
+nc_status nc_dac_from_codes_dev(nc_codec* h, const int64_t* codes, int32_t B, int32_t n_q, int64_t frames, float* z) {
+    return guard([&] { as_dac(h).from_codes_dev(codes, B, n_q, frames, z); });
+}
+
+nc_status nc_dac_encode(nc_codec* h, const float* pcm, int32_t B, int64_t T, int32_t sample_rate, int32_t n_q, int64_t* codes,
+                        float* z, float* latents) {
+    return guard([&] {
+        DacModel& m = as_dac(h);
+        if (!pcm || !codes) fail(NC_EINVAL, "pcm and codes must not be null");
+        if (B <= 0 || T <= 0) fail(NC_EINVAL, "B and T must be positive");
+        m.use_device();
+        const int nq = (n_q <= 0 || n_q > m.cfg.n_codebooks) ? m.cfg.n_codebooks : n_q;
+        const int64_t Tz = m.frames(T);
+        const size_t n_in = (size_t)B * T * 4, n_codes = (size_t)B * nq * Tz * 8, n_z = (size_t)B * m.latent * Tz * 4,
+                     n_lat = (size_t)B * nq * m.cfg.codebook_dim * Tz * 4;
+        m.h_in.reserve(n_in); m.h_codes.reserve(n_codes); m.h_aux0.reserve(n_z); m.h_aux1.reserve(n_lat);
+        h2d(m.h_in.p, pcm, n_in, m.stream);
+        m.encode_dev(m.h_in.as<float>(), B, T, sample_rate, n_q, m.h_codes.as<int64_t>(), m.h_aux0.as<float>(), m.h_aux1.as<float>());
+        d2h(codes, m.h_codes.p, n_codes, m.stream);
+        if (z) d2h(z, m.h_aux0.p, n_z, m.stream);
+        if (latents) d2h(latents, m.h_aux1.p, n_lat, m.stream);
+        NC_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
+nc_status nc_dac_decode(nc_codec* h, const float* z, int32_t B, int64_t frames, float* pcm) {
+    return guard([&] {
+        DacModel& m = as_dac(h);
+        if (!z || !pcm) fail(NC_EINVAL, "z and pcm must not be null");
+        if (B <= 0 || frames <= 0) fail(NC_EINVAL, "B and frames must be positive");
+        m.use_device();
+        const size_t n_z = (size_t)B * m.latent * frames * 4, n_out = (size_t)B * m.decoded_len(frames) * 4;
+        m.h_aux0.reserve(n_z); m.h_out.reserve(n_out);
+        h2d(m.h_aux0.p, z, n_z, m.stream);
+        m.decode_dev(m.h_aux0.as<float>(), B, frames, m.h_out.as<float>());
+        d2h(pcm, m.h_out.p, n_out, m.stream);
+        NC_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
+nc_status nc_dac_from_codes(nc_codec* h, const int64_t* codes, int32_t B, int32_t n_q, int64_t frames, float* z) {
+    return guard([&] {
+        DacModel& m = as_dac(h);
+        if (!codes || !z) fail(NC_EINVAL, "codes and z must not be null");
+        if (B <= 0 || frames <= 0 || n_q <= 0) fail(NC_EINVAL, "bad codes shape");
+        m.use_device();
+        const size_t n_codes = (size_t)B * n_q * frames * 8, n_z = (size_t)B * m.latent * frames * 4;
+        m.h_codes.reserve(n_codes); m.h_aux0.reserve(n_z);
+        h2d(m.h_codes.p, codes, n_codes, m.stream);
+        m.from_codes_dev(m.h_codes.as<int64_t>(), B, n_q, frames, m.h_aux0.as<float>());
+        d2h(z, m.h_aux0.p, n_z, m.stream);
+        NC_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
+nc_status nc_codec_profile_enable(nc_codec* h, int32_t on) {
+    return guard([&] {
+        if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");
+        h->impl->prof.on = on != 0;
+    });
+}
+
+nc_status nc_codec_profile_reset(nc_codec* h) {
+    return guard([&] {
+        if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");
+        h->impl->use_device();
+        h->impl->prof.reset();
+    });
+}
+
+nc_status nc_codec_profile_read(nc_codec* h, nc_profile_entry* out) {
+    return guard([&] {
+        if (!h || !h->impl || !out) fail(NC_EINVAL, "null argument");
+        h->impl->use_device();
+        NC_HIP(hipStreamSynchronize(h->impl->stream));
+        h->impl->prof.resolve();
+        for (int i = 0; i < NC_KC_COUNT; ++i) out[i] = h->impl->prof.acc[i];
+    });
+}
+
+// ---- op-level test hooks -----------------------------------------------------------------------
+nc_status nc_op_fold_weight_norm(const float* v, const float* g, int64_t d0, int64_t inner, float* w) {
+    return guard([&] {
+        if (!v || !g || !w || d0 <= 0 || inner <= 0) fail(NC_EINVAL, "bad arguments");
+        fold_weight_norm_dac(v, g, d0, inner, w);
+    });
+}
+
+static void op_set_device(int device_index) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) fail(NC_EDEVICE, "no HIP device available (the engine has no CPU fallback)");
+    if (device_index < 0 || device_index >= n) fail(NC_EINVAL, "device index out of range");
+    NC_HIP(hipSetDevice(device_index));
+}
+
+nc_status nc_op_conv1d(int device_index, const nc_conv_desc* d, const float* x, const float* weight, const float* bias,
+                       const float* alpha_in, const float* alpha_out, const float* residual, float* y, int64_t* Tout_p) {
+    return guard([&] {
+        if (!d || !x || !weight || !y) fail(NC_EINVAL, "null argument");
+        if (d->B <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->K <= 0 || d->stride <= 0 || d->Tin <= 0) fail(NC_EINVAL, "bad conv shape");
+        op_set_device(device_index);
+        ConvLayer L;
+        L.build(weight, bias, d->Cin, d->Cout, d->K, d->stride, d->pad, d->dil, d->out_pad, d->transposed != 0);
+        const int64_t Tout = L.out_len(d->Tin);
+        if (Tout <= 0) fail(NC_EINVAL, "empty output");
+        if (Tout_p) *Tout_p = Tout;
+        DevBuf dx, dy, dai, dao, dr;
+        const size_t nx = (size_t)d->B * d->Cin * d->Tin * 4, ny = (size_t)d->B * d->Cout * Tout * 4;
+        dx.reserve(nx); dy.reserve(ny);
+        NC_HIP(hipMemcpy(dx.p, x, nx, hipMemcpyHostToDevice));
+        NC_HIP(hipMemset(dy.p, 0, ny));
+        if (alpha_in) { dai.reserve(d->Cin * 4); NC_HIP(hipMemcpy(dai.p, alpha_in, d->Cin * 4, hipMemcpyHostToDevice)); }
+        if (alpha_out) { dao.reserve(d->Cout * 4); NC_HIP(hipMemcpy(dao.p, alpha_out, d->Cout * 4, hipMemcpyHostToDevice)); }
+        if (residual) { dr.reserve(ny); NC_HIP(hipMemcpy(dr.p, residual, ny, hipMemcpyHostToDevice)); }
+        ConvIO io{};
+        io.x = dx.as<float>(); io.x_bstride = (int64_t)d->Cin * d->Tin; io.x_cstride = d->Tin; io.x_len = (int32_t)d->Tin; io.Tin = d->Tin;
+        io.alpha_in = alpha_in ? dai.as<float>() : nullptr;
+        io.alpha_out = alpha_out ? dao.as<float>() : nullptr;
+        io.res = residual ? dr.as<float>() : nullptr;
+        io.y = dy.as<float>(); io.y_bstride = (int64_t)d->Cout * Tout; io.y_cstride = Tout;
+        io.epi = d->tanh_out ? EPI_TANH : 0;
+        launch_conv(L, io, d->B, nullptr, nullptr);
+        NC_HIP(hipDeviceSynchronize());
+        NC_HIP(hipMemcpy(y, dy.p, ny, hipMemcpyDeviceToHost));
+        dx.release(); dy.release(); dai.release(); dao.release(); dr.release(); L.w.release(); L.bias.release();
+    });
+}
+
+nc_status nc_op_vq_argmin(int device_index, const float* z_e, int32_t B, int32_t D, int64_t T, const float* codebook, int32_t N,
+                          int64_t* idx, float* st) {
+    return guard([&] {
+        if (!z_e || !codebook || !idx || !st || B <= 0 || D <= 0 || T <= 0 || N <= 0) fail(NC_EINVAL, "bad arguments");
+        op_set_device(device_index);
+        Codebook cb;
+        cb.build(codebook, N, D);
+        DevBuf dz, di, ds;
+        const size_t nz = (size_t)B * D * T * 4;
+        dz.reserve(nz); ds.reserve(nz); di.reserve((size_t)B * T * 8);
+        NC_HIP(hipMemcpy(dz.p, z_e, nz, hipMemcpyHostToDevice));
+        launch_vq_argmin(cb, dz.as<float>(), (int64_t)D * T, B, T, di.as<int64_t>(), T, ds.as<float>(), nullptr, nullptr);
+        NC_HIP(hipDeviceSynchronize());
+        NC_HIP(hipMemcpy(idx, di.p, (size_t)B * T * 8, hipMemcpyDeviceToHost));
+        NC_HIP(hipMemcpy(st, ds.p, nz, hipMemcpyDeviceToHost));
+        dz.release(); di.release(); ds.release(); cb.cbT.release(); cb.cb.release(); cb.c2.release();
+    });
+}
+
+}  // extern "C"

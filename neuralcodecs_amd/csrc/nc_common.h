@@ -1,0 +1,106 @@
+// Internal helpers shared by the engine's translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/nc_mi355x.h"
+
+namespace nc {
+
+struct Error : std::runtime_error {
+    nc_status code;
+    Error(nc_status c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] inline void fail(nc_status c, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Error(c, buf);
+}
+
+#define NC_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            ::nc::fail(e__ == hipErrorOutOfMemory ? NC_ENOMEM : NC_EDEVICE, "%s failed: %s (%s:%d)", #expr, \
+                       hipGetErrorString(e__), __FILE__, __LINE__);                                    \
+    } while (0)
+
+void set_last_error(const char* msg);
+
+// Grow-only device arena: activations for the largest (B,T) seen so far stay resident
+// (288 GB of HBM per GPU: nothing is ever freed or re-allocated inside a timed region).
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) NC_HIP(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        size_t want = (bytes + (1 << 20) - 1) & ~size_t((1 << 20) - 1);
+        NC_HIP(hipMalloc(&p, want));
+        cap = want;
+    }
+    template <class T>
+    T* as() const { return static_cast<T*>(p); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// ---- weight blob (NCWB0001) ----------------------------------------------------------------
+struct BlobTensor {
+    std::string name;
+    int dtype = 0;
+    std::vector<int64_t> dims;
+    const void* data = nullptr;
+    int64_t nbytes = 0;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto d : dims) n *= d;
+        return n;
+    }
+};
+
+struct Blob {
+    std::vector<uint8_t> storage;
+    std::map<std::string, BlobTensor> tensors;
+    void parse(const void* data, size_t nbytes);  // copies
+    const BlobTensor& get(const std::string& name) const;
+    const BlobTensor* find(const std::string& name) const;
+};
+
+// ---- profiling -----------------------------------------------------------------------------
+struct Profiler {
+    bool on = false;
+    struct Pending {
+        hipEvent_t a, b;
+        int cls;
+        double flops, bytes;
+    };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    nc_profile_entry acc[NC_KC_COUNT] = {};
+    hipEvent_t get_event();
+    void begin(hipStream_t s, int cls, double flops, double bytes);
+    void end(hipStream_t s);
+    void resolve();
+    void reset();
+    ~Profiler();
+};
+
+}  // namespace nc

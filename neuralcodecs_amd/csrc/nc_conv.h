@@ -1,0 +1,89 @@
+// Implicit-GEMM 1-D convolution on the fp32 matrix cores of gfx950 -- host-side descriptors.
+//
+// One kernel template covers every dense convolution of the DAC / SNAC / Encodec hot path:
+//   conv1d (any K, stride, dilation, zero "same" padding)   WNConv1d.cs:152, EncoderBlock.cs:27-33
+//   conv_transpose1d as `stride` polyphase sub-convolutions  WNConvTranspose1d.cs:152
+//   1x1 projections of the quantizer                         VectorQuantizer.cs:47-48
+// with the element-wise neighbours fused: Snake on the input tile (Snake1d.cs:52), bias,
+// residual add (ResidualUnit.cs:58), Snake for the next layer, tanh (Decoder.cs:46) and the
+// RVQ accumulate/subtract (ResidualVectorQuantizer.cs:68-69).
+//
+// GEMM view:  M = Cout (A = weights, pre-packed per tile),  N = output time steps of one clip,
+//             Kdim = Cin*K flattened as kk = ci*K + k  -- the canonical accumulation order.
+// Each output element is ONE chain of v_mfma_f32_32x32x2_f32 updates in ascending kk, which is
+// bit-identical to a scalar fmaf loop (MI355X_MICROARCH.md, "FP32-input MFMA").
+#pragma once
+#include "nc_common.h"
+
+namespace nc {
+
+enum : int { EPI_TANH = 1, EPI_RVQ = 2 };
+
+struct ConvArgs {
+    // input activations [B][Cin][x_len] (row stride x_cstride); positions outside [0,x_len) read as 0
+    const float* x;
+    int64_t x_bstride, x_cstride;
+    int32_t Cin, x_len;
+    const float* alpha_in;  // nullable: Snake applied while staging the input tile
+    // packed weights: [phase][co_tile][ci_block][CB*K][BM]
+    const float* w;
+    int64_t w_phase_stride;
+    const float* bias;       // nullable [Cout]
+    const float* alpha_out;  // nullable [Cout]: Snake of the NEXT layer fused into the store
+    const float* res;        // nullable residual, same geometry as y
+    float* y;
+    int64_t y_bstride, y_cstride;  // elements
+    int32_t y_tstride, y_toff;     // t_out = col*y_tstride + y_toff + phase
+    int32_t Tout;                  // stores outside [0,Tout) are dropped
+    float* rvq_zq;                 // EPI_RVQ: zq += out ; rvq_res -= out  (same geometry as y)
+    float* rvq_res;
+    int32_t Cout, n_cols;          // columns (output steps per phase) handled by this launch
+    int32_t stride, dil, pad;      // x position of (col,k) = col*stride + k*dil - pad
+    int32_t B, n_co_tiles, n_t_tiles, n_cb, n_phase;
+    int32_t xw, xwp, xrow, xneg;   // staged input window geometry (see kernel)
+    int32_t epi;
+};
+
+struct TileCfg {
+    int TM, TN, K, CB;
+    int BM() const { return 32 * TM; }
+    int BN() const { return 128 * TN; }
+    int KB() const { return CB * K; }
+};
+
+// A convolution layer resident on the device: folded + packed weights and launch geometry.
+struct ConvLayer {
+    int Cin = 0, Cout = 0, K = 0, stride = 1, pad = 0, dil = 1, out_pad = 0;
+    bool transposed = false;
+    TileCfg cfg{};
+    int n_phase = 1, Ktaps = 0;  // taps per phase (== K for conv, ceil(K/stride) for conv-transpose)
+    DevBuf w, bias;
+    bool has_bias = false;
+    int64_t w_phase_stride = 0;
+    int kclass = NC_KC_CONV_MISC;
+    // host: dense folded weight in the reference's layout ([Cout,Cin,K] or [Cin,Cout,K])
+    void build(const float* dense_w, const float* bias_h, int Cin, int Cout, int K, int stride, int pad, int dil, int out_pad,
+               bool transposed);
+    int64_t out_len(int64_t Tin) const;
+    double flops(int B, int64_t Tin) const;
+};
+
+struct ConvIO {
+    const float* x = nullptr;
+    int64_t x_bstride = 0, x_cstride = 0;
+    int32_t x_len = 0;     // valid samples
+    int64_t Tin = 0;       // logical input length (>= x_len; the tail is zero: DAC.Preprocess right-pad)
+    const float* alpha_in = nullptr;
+    const float* alpha_out = nullptr;
+    const float* res = nullptr;
+    float* y = nullptr;
+    int64_t y_bstride = 0, y_cstride = 0;
+    float* rvq_zq = nullptr;
+    float* rvq_res = nullptr;
+    int epi = 0;
+};
+
+TileCfg pick_tile(int Cout, int Ktaps);  // TN is chosen per launch from the column count
+void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream, Profiler* prof);
+
+}  // namespace nc

@@ -1,0 +1,189 @@
+// Host side of the implicit-GEMM convolution: tile selection, weight packing, launch.
+#include <algorithm>
+#include <mutex>
+#include <set>
+
+#include "nc_conv.h"
+
+namespace nc {
+
+typedef void (*conv_kernel_fn)(const ConvArgs);
+conv_kernel_fn conv_kernel_table_k1(int, int);
+conv_kernel_fn conv_kernel_table_k2(int, int);
+conv_kernel_fn conv_kernel_table_k3(int, int);
+conv_kernel_fn conv_kernel_table_k4(int, int);
+conv_kernel_fn conv_kernel_table_k6(int, int);
+conv_kernel_fn conv_kernel_table_k7(int, int);
+conv_kernel_fn conv_kernel_table_k8(int, int);
+conv_kernel_fn conv_kernel_table_k10(int, int);
+conv_kernel_fn conv_kernel_table_k16(int, int);
+
+static int cb_for_k(int K) {
+    switch (K) {
+        case 1: return 32;
+        case 2: return 16;
+        case 3: return 16;
+        case 4: return 8;
+        case 6: return 8;
+        case 7: return 8;
+        case 8: return 8;
+        case 10: return 4;
+        case 16: return 4;
+    }
+    fail(NC_EUNSUPPORTED, "convolution with %d taps per phase has no kernel instantiation", K);
+}
+
+static conv_kernel_fn lookup_kernel(const TileCfg& c) {
+    conv_kernel_fn f = nullptr;
+    switch (c.K) {
+        case 1: f = conv_kernel_table_k1(c.TM, c.TN); break;
+        case 2: f = conv_kernel_table_k2(c.TM, c.TN); break;
+        case 3: f = conv_kernel_table_k3(c.TM, c.TN); break;
+        case 4: f = conv_kernel_table_k4(c.TM, c.TN); break;
+        case 6: f = conv_kernel_table_k6(c.TM, c.TN); break;
+        case 7: f = conv_kernel_table_k7(c.TM, c.TN); break;
+        case 8: f = conv_kernel_table_k8(c.TM, c.TN); break;
+        case 10: f = conv_kernel_table_k10(c.TM, c.TN); break;
+        case 16: f = conv_kernel_table_k16(c.TM, c.TN); break;
+    }
+    if (!f) fail(NC_EUNSUPPORTED, "no conv kernel for TM=%d TN=%d K=%d", c.TM, c.TN, c.K);
+    return f;
+}
+
+TileCfg pick_tile(int Cout, int Ktaps) {
+    TileCfg c{};
+    int best = 1 << 30;
+    for (int tm = 4; tm >= 1; --tm) {
+        int bm = 32 * tm;
+        int padded = (Cout + bm - 1) / bm * bm;
+        if (padded < best) {
+            best = padded;
+            c.TM = tm;
+        }
+    }
+    c.TN = 2;
+    c.K = Ktaps;
+    c.CB = cb_for_k(Ktaps);
+    return c;
+}
+
+int64_t ConvLayer::out_len(int64_t Tin) const {
+    if (transposed) return (Tin - 1) * stride - 2 * (int64_t)pad + K + out_pad;
+    return (Tin + 2 * (int64_t)pad - (int64_t)dil * (K - 1) - 1) / stride + 1;
+}
+
+double ConvLayer::flops(int B, int64_t Tin) const {
+    if (transposed) return 2.0 * Cin * Cout * K * (double)Tin * B;  // counted on L_in
+    return 2.0 * Cin * Cout * K * (double)out_len(Tin) * B;
+}
+
+void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int Cout_, int K_, int stride_, int pad_, int dil_,
+                      int out_pad_, bool transposed_) {
+    Cin = Cin_; Cout = Cout_; K = K_; stride = stride_; pad = pad_; dil = dil_; out_pad = out_pad_; transposed = transposed_;
+    if (transposed) {
+        if (dil != 1) fail(NC_EUNSUPPORTED, "dilated conv_transpose1d is not on the hot path");
+        n_phase = stride;
+        Ktaps = (K + stride - 1) / stride;
+    } else {
+        if (stride > 1 && dil != 1) fail(NC_EUNSUPPORTED, "strided+dilated conv1d is not on the hot path");
+        n_phase = 1;
+        Ktaps = K;
+    }
+    cfg = pick_tile(Cout, Ktaps);
+    const int BM = cfg.BM(), CB = cfg.CB, KB = cfg.KB();
+    const int n_co = (Cout + BM - 1) / BM;
+    const int n_cb = (Cin + CB - 1) / CB;
+    w_phase_stride = (int64_t)n_co * n_cb * KB * BM;
+    std::vector<float> packed((size_t)w_phase_stride * n_phase, 0.0f);
+    for (int ph = 0; ph < n_phase; ++ph)
+        for (int ct = 0; ct < n_co; ++ct)
+            for (int cb = 0; cb < n_cb; ++cb) {
+                float* dst = packed.data() + (size_t)ph * w_phase_stride + ((size_t)ct * n_cb + cb) * KB * BM;
+                for (int kk = 0; kk < KB; ++kk) {
+                    const int ci = cb * CB + kk / Ktaps, k = kk % Ktaps;
+                    if (ci >= Cin) continue;
+                    for (int r = 0; r < BM; ++r) {
+                        const int co = ct * BM + r;
+                        if (co >= Cout) continue;
+                        float v;
+                        if (transposed) {
+                            const int kt = ph + k * stride;  // tap of this phase, ascending (canonical order)
+                            if (kt >= K) continue;
+                            v = dense_w[((size_t)ci * Cout + co) * K + kt];
+                        } else {
+                            v = dense_w[((size_t)co * Cin + ci) * K + k];
+                        }
+                        dst[(size_t)kk * BM + r] = v;
+                    }
+                }
+            }
+    w.reserve(packed.size() * sizeof(float));
+    NC_HIP(hipMemcpy(w.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    has_bias = bias_h != nullptr;
+    if (has_bias) {
+        bias.reserve(sizeof(float) * Cout);
+        NC_HIP(hipMemcpy(bias.p, bias_h, sizeof(float) * Cout, hipMemcpyHostToDevice));
+    }
+}
+
+static std::mutex g_attr_mu;
+static std::set<const void*> g_attr_done;
+
+void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream, Profiler* prof) {
+    TileCfg c = L.cfg;
+    const int64_t Tout = L.out_len(io.Tin);
+    const int64_t n_cols_all = L.transposed ? io.Tin + L.Ktaps - 1 : Tout;
+    c.TN = n_cols_all >= 192 ? 2 : 1;  // 256-column tiles for long clips, 128 for the deep (short) layers
+    const int BM = c.BM(), BN = c.BN(), CB = c.CB, KB = c.KB();
+    ConvArgs a{};
+    a.x = io.x; a.x_bstride = io.x_bstride; a.x_cstride = io.x_cstride; a.Cin = L.Cin; a.x_len = io.x_len;
+    a.alpha_in = io.alpha_in;
+    a.w = L.w.as<float>(); a.w_phase_stride = L.w_phase_stride;
+    a.bias = L.has_bias ? L.bias.as<float>() : nullptr;
+    a.alpha_out = io.alpha_out; a.res = io.res;
+    a.y = io.y; a.y_bstride = io.y_bstride; a.y_cstride = io.y_cstride;
+    a.rvq_zq = io.rvq_zq; a.rvq_res = io.rvq_res;
+    a.Cout = L.Cout; a.B = B; a.epi = io.epi;
+    a.Tout = (int32_t)Tout;
+    int sx;  // x step per output column
+    if (L.transposed) {
+        sx = 1; a.stride = 1; a.dil = -1; a.pad = 0;
+        a.n_cols = (int32_t)(io.Tin + L.Ktaps - 1);
+        a.y_tstride = L.stride; a.y_toff = -L.pad;
+        a.n_phase = L.n_phase;
+    } else {
+        sx = L.stride; a.stride = L.stride; a.dil = L.dil; a.pad = L.pad;
+        a.n_cols = (int32_t)Tout;
+        a.y_tstride = 1; a.y_toff = 0;
+        a.n_phase = 1;
+    }
+    const int ad = a.dil < 0 ? -a.dil : a.dil;
+    a.xneg = a.dil < 0 ? (L.Ktaps - 1) * ad : 0;
+    a.xw = (BN - 1) * sx + (L.Ktaps - 1) * ad + 1;
+    a.xwp = (a.xw + sx - 1) / sx;
+    a.xrow = sx == 1 ? a.xw : sx * a.xwp;
+    a.n_co_tiles = (L.Cout + BM - 1) / BM;
+    a.n_t_tiles = (a.n_cols + BN - 1) / BN;
+    a.n_cb = (L.Cin + CB - 1) / CB;
+    const size_t lds = sizeof(float) * ((size_t)KB * BM + (size_t)CB * a.xrow);
+    if (lds > 160 * 1024) fail(NC_EUNSUPPORTED, "conv tile needs %zu B of LDS", lds);
+    conv_kernel_fn fn = lookup_kernel(c);
+    {
+        std::lock_guard<std::mutex> g(g_attr_mu);
+        if (!g_attr_done.count((const void*)fn)) {
+            NC_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            g_attr_done.insert((const void*)fn);
+        }
+    }
+    const int64_t grid = (int64_t)a.n_phase * a.n_co_tiles * B * a.n_t_tiles;
+    if (grid <= 0) return;
+    if (prof && prof->on) {
+        const double bytes = 4.0 * ((double)B * L.Cin * io.Tin + (double)B * L.Cout * Tout + (double)L.Cin * L.Cout * L.K);
+        prof->begin(stream, L.kclass, L.flops(B, io.Tin), bytes);
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, stream, a);
+    NC_HIP(hipGetLastError());
+    if (prof && prof->on) prof->end(stream);
+}
+
+}  // namespace nc

@@ -1,0 +1,3 @@
+// Instantiates the implicit-GEMM convolution for taps-per-phase K=3 (reduction block of 16 input channels).
+#include "nc_conv_kernel.hip.h"
+NC_INSTANTIATE_CONV_K(3, 16)

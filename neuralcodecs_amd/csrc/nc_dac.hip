@@ -1,0 +1,328 @@
+// DAC on the engine: weight import (fold + pack) and the Encode / Decode / FromCodes launch sequences.
+//
+// Reference call stacks restated as kernel launches:
+//   DAC.Encode     Models/DAC.cs:163-181  -> Encoder.cs:21-58 -> ResidualVectorQuantizer.cs:54-103
+//   DAC.Decode     Models/DAC.cs:231-234  -> Decoder.cs:22-58 / DecoderBlock.cs:20-44
+//   DAC.FromCodes  Models/DAC.cs:101-106  -> ResidualVectorQuantizer.cs:211-238
+// Fusion plan per ResidualUnit (ResidualUnit.cs:29-34,50-59):
+//   launch 1: conv k7 dil d   [Snake(a1) on the input tile | bias | Snake(a2) on the store]
+//   launch 2: conv k1         [bias | + x residual]
+// so no activation makes an HBM round trip of its own.
+#include "nc_model.h"
+
+namespace nc {
+
+Codec::~Codec() {
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+}
+
+void Codec::init_device(int device_index) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) fail(NC_EDEVICE, "no HIP device available (the engine has no CPU fallback)");
+    if (device_index < 0 || device_index >= n) fail(NC_EINVAL, "device index %d out of range (0..%d)", device_index, n - 1);
+    device = device_index;
+    NC_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    NC_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        fail(NC_EDEVICE, "device %d is %s; this engine is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    NC_HIP(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+    stream = own_stream;
+}
+
+void Codec::use_device() const { NC_HIP(hipSetDevice(device)); }
+
+static void upload(DevBuf& d, const float* h, size_t n) {
+    d.reserve(n * sizeof(float));
+    NC_HIP(hipMemcpy(d.p, h, n * sizeof(float), hipMemcpyHostToDevice));
+}
+
+static void load_alpha(const Blob& b, const std::string& name, int C, DevBuf& dst) {
+    const BlobTensor& t = b.get(name);
+    if (t.numel() != C) fail(NC_EINVAL, "%s: expected %d elements, found %lld", name.c_str(), C, (long long)t.numel());
+    upload(dst, static_cast<const float*>(t.data), C);
+}
+
+// weight_v / weight_g / bias -> folded dense weight -> packed device image
+static void load_wn_conv(const Blob& b, const std::string& prefix, ConvLayer& L, int Cin, int Cout, int K, int stride, int pad,
+                         int dil, bool transposed, int kclass) {
+    const BlobTensor& v = b.get(prefix + ".weight_v");
+    const BlobTensor& g = b.get(prefix + ".weight_g");
+    const BlobTensor* bias = b.find(prefix + ".bias");
+    const int64_t d0 = transposed ? Cin : Cout, d1 = transposed ? Cout : Cin;
+    if (v.dims.size() != 3 || v.dims[0] != d0 || v.dims[1] != d1 || v.dims[2] != K)
+        fail(NC_EINVAL, "%s.weight_v has the wrong shape", prefix.c_str());
+    if (g.numel() != d0) fail(NC_EINVAL, "%s.weight_g: expected %lld elements (one per dim-0 slice)", prefix.c_str(), (long long)d0);
+    if (bias && bias->numel() != Cout) fail(NC_EINVAL, "%s.bias has the wrong length", prefix.c_str());
+    std::vector<float> w((size_t)v.numel());
+    fold_weight_norm_dac(static_cast<const float*>(v.data), static_cast<const float*>(g.data), d0, d1 * K, w.data());
+    L.kclass = kclass;
+    L.build(w.data(), bias ? static_cast<const float*>(bias->data) : nullptr, Cin, Cout, K, stride, pad, dil, 0, transposed);
+}
+
+DacModel::DacModel(const nc_dac_config& c) : cfg(c) {
+    if (c.n_encoder_rates <= 0 || c.n_encoder_rates > 8 || c.n_decoder_rates <= 0 || c.n_decoder_rates > 8)
+        fail(NC_EINVAL, "encoder/decoder rate lists must hold 1..8 entries");
+    if (c.encoder_dim <= 0 || c.decoder_dim <= 0 || c.n_codebooks <= 0 || c.codebook_size <= 0 || c.codebook_dim <= 0 ||
+        c.sample_rate <= 0)
+        fail(NC_EINVAL, "DAC config fields must be positive");
+    hop = 1;
+    for (int i = 0; i < c.n_encoder_rates; ++i) {
+        if (c.encoder_rates[i] <= 0) fail(NC_EINVAL, "encoder rate must be positive");
+        hop *= c.encoder_rates[i];
+    }
+    for (int i = 0; i < c.n_decoder_rates; ++i)
+        if (c.decoder_rates[i] <= 0) fail(NC_EINVAL, "decoder rate must be positive");
+    if ((c.decoder_dim >> c.n_decoder_rates) <= 0) fail(NC_EINVAL, "decoder_dim too small for the number of decoder blocks");
+    latent = c.latent_dim > 0 ? c.latent_dim : c.encoder_dim * (1 << c.n_encoder_rates);  // DAC.cs:64
+    cfg.latent_dim = latent;
+}
+
+static const int kDil[3] = {1, 3, 9};  // EncoderBlock.cs:23-25 / DecoderBlock.cs:32-34
+
+void DacModel::load(const Blob& b) {
+    use_device();
+    char nm[256];
+    int d = cfg.encoder_dim;
+    load_wn_conv(b, "encoder.block.0", enc_stem, 1, d, 7, 1, 3, 1, false, NC_KC_CONV_MISC);
+    for (int bi = 0; bi < cfg.n_encoder_rates; ++bi) {
+        const int s = cfg.encoder_rates[bi];
+        for (int u = 0; u < 3; ++u) {
+            snprintf(nm, sizeof nm, "encoder.block.%d.block.%d", bi + 1, u);
+            const std::string q = nm;
+            load_alpha(b, q + ".block.0.alpha", d, enc[bi].ru[u].a1);
+            load_wn_conv(b, q + ".block.1", enc[bi].ru[u].c7, d, d, 7, 1, 3 * kDil[u], kDil[u], false, NC_KC_CONV_K7);
+            load_alpha(b, q + ".block.2.alpha", d, enc[bi].ru[u].a2);
+            load_wn_conv(b, q + ".block.3", enc[bi].ru[u].c1, d, d, 1, 1, 0, 1, false, NC_KC_CONV_K1);
+        }
+        snprintf(nm, sizeof nm, "encoder.block.%d", bi + 1);
+        const std::string p = nm;
+        load_alpha(b, p + ".block.3.alpha", d, enc[bi].a_down);
+        load_wn_conv(b, p + ".block.4", enc[bi].down, d, 2 * d, 2 * s, s, (s + 1) / 2, 1, false, NC_KC_CONV_DOWN);
+        d *= 2;
+    }
+    snprintf(nm, sizeof nm, "encoder.block.%d.alpha", cfg.n_encoder_rates + 1);
+    load_alpha(b, nm, d, enc_alpha_out);
+    snprintf(nm, sizeof nm, "encoder.block.%d", cfg.n_encoder_rates + 2);
+    load_wn_conv(b, nm, enc_out, d, latent, 3, 1, 1, 1, false, NC_KC_CONV_MISC);
+
+    in_proj.clear(); out_proj.clear(); codebooks.clear();
+    for (int i = 0; i < cfg.n_codebooks; ++i) {
+        snprintf(nm, sizeof nm, "quantizer.quantizers.%d", i);
+        const std::string p = nm;
+        in_proj.emplace_back(new ConvLayer());
+        out_proj.emplace_back(new ConvLayer());
+        codebooks.emplace_back(new Codebook());
+        load_wn_conv(b, p + ".in_proj", *in_proj.back(), latent, cfg.codebook_dim, 1, 1, 0, 1, false, NC_KC_CONV_K1);
+        load_wn_conv(b, p + ".out_proj", *out_proj.back(), cfg.codebook_dim, latent, 1, 1, 0, 1, false, NC_KC_CONV_K1);
+        const BlobTensor& cb = b.get(p + ".codebook.weight");
+        if (cb.dims.size() != 2 || cb.dims[0] != cfg.codebook_size || cb.dims[1] != cfg.codebook_dim)
+            fail(NC_EINVAL, "%s.codebook.weight has the wrong shape", p.c_str());
+        codebooks.back()->build(static_cast<const float*>(cb.data), cfg.codebook_size, cfg.codebook_dim);
+    }
+
+    int ch = cfg.decoder_dim;
+    load_wn_conv(b, "decoder.model.0", dec_in, latent, ch, 7, 1, 3, 1, false, NC_KC_CONV_MISC);
+    int out_dim = ch;
+    for (int bi = 0; bi < cfg.n_decoder_rates; ++bi) {
+        const int s = cfg.decoder_rates[bi];
+        const int in_dim = ch >> bi;
+        out_dim = ch >> (bi + 1);
+        snprintf(nm, sizeof nm, "decoder.model.%d", bi + 1);
+        const std::string p = nm;
+        load_alpha(b, p + ".block.0.alpha", in_dim, dec[bi].a_up);
+        load_wn_conv(b, p + ".block.1", dec[bi].up, in_dim, out_dim, 2 * s, s, (s + 1) / 2, 1, true, NC_KC_CONV_UP);
+        for (int u = 0; u < 3; ++u) {
+            snprintf(nm, sizeof nm, "decoder.model.%d.block.%d", bi + 1, u + 2);
+            const std::string q = nm;
+            load_alpha(b, q + ".block.0.alpha", out_dim, dec[bi].ru[u].a1);
+            load_wn_conv(b, q + ".block.1", dec[bi].ru[u].c7, out_dim, out_dim, 7, 1, 3 * kDil[u], kDil[u], false, NC_KC_CONV_K7);
+            load_alpha(b, q + ".block.2.alpha", out_dim, dec[bi].ru[u].a2);
+            load_wn_conv(b, q + ".block.3", dec[bi].ru[u].c1, out_dim, out_dim, 1, 1, 0, 1, false, NC_KC_CONV_K1);
+        }
+    }
+    snprintf(nm, sizeof nm, "decoder.model.%d.alpha", cfg.n_decoder_rates + 1);
+    load_alpha(b, nm, out_dim, dec_alpha_out);
+    snprintf(nm, sizeof nm, "decoder.model.%d", cfg.n_decoder_rates + 2);
+    load_wn_conv(b, nm, dec_out, out_dim, 1, 7, 1, 3, 1, false, NC_KC_CONV_MISC);
+    NC_HIP(hipDeviceSynchronize());
+    loaded = true;
+}
+
+int64_t DacModel::decoded_len(int64_t fr) const {
+    int64_t L = fr;
+    for (int i = 0; i < cfg.n_decoder_rates; ++i) {
+        const int s = cfg.decoder_rates[i];
+        L = (L - 1) * s - 2 * ((s + 1) / 2) + 2 * s;
+    }
+    return L;
+}
+
+// x + conv1(snake(conv7(snake(x))));  buffers rotate through act[0..2]
+float* DacModel::run_res_unit(ResUnit& ru, int dil, float* cur, int C, int64_t L, int B, int& cur_idx) {
+    (void)dil;
+    const int h_idx = (cur_idx + 1) % 3, o_idx = (cur_idx + 2) % 3;
+    float* h = act[h_idx].as<float>();
+    float* o = act[o_idx].as<float>();
+    ConvIO io{};
+    io.x = cur; io.x_bstride = (int64_t)C * L; io.x_cstride = L; io.x_len = (int32_t)L; io.Tin = L;
+    io.alpha_in = ru.a1.as<float>(); io.alpha_out = ru.a2.as<float>();
+    io.y = h; io.y_bstride = (int64_t)C * L; io.y_cstride = L;
+    launch_conv(ru.c7, io, B, stream, &prof);
+    ConvIO i2{};
+    i2.x = h; i2.x_bstride = (int64_t)C * L; i2.x_cstride = L; i2.x_len = (int32_t)L; i2.Tin = L;
+    i2.res = cur;
+    i2.y = o; i2.y_bstride = (int64_t)C * L; i2.y_cstride = L;
+    launch_conv(ru.c1, i2, B, stream, &prof);
+    cur_idx = o_idx;
+    return o;
+}
+
+void DacModel::encode_dev(const float* pcm, int B, int64_t T, int sample_rate, int n_q, int64_t* codes, float* z, float* latents) {
+    if (!loaded) fail(NC_ESTATE, "weights not loaded (call nc_codec_load_weights first)");
+    if (!pcm || !codes) fail(NC_EINVAL, "pcm and codes must not be null");
+    if (B <= 0 || T <= 0) fail(NC_EINVAL, "B and T must be positive");
+    if (sample_rate != 0 && sample_rate != cfg.sample_rate)
+        fail(NC_EINVAL, "Input audio sample rate %dHz does not match model sample rate %dHz", sample_rate, cfg.sample_rate);
+    if (T > (int64_t)1 << 30) fail(NC_EINVAL, "clip too long");
+    use_device();
+    const int nq = (n_q <= 0 || n_q > cfg.n_codebooks) ? cfg.n_codebooks : n_q;
+    const int64_t Tp = padded_len(T), Tz = frames(T);
+    // activation arena: the widest tensor is encoder_dim x Tp (stem output)
+    int64_t maxel = 0;
+    {
+        int c = cfg.encoder_dim;
+        int64_t L = Tp;
+        maxel = (int64_t)c * L;
+        for (int i = 0; i < cfg.n_encoder_rates; ++i) {
+            c *= 2;
+            L /= cfg.encoder_rates[i];
+            if ((int64_t)c * L > maxel) maxel = (int64_t)c * L;
+        }
+    }
+    for (auto& a : act) a.reserve((size_t)B * maxel * sizeof(float));
+    const int D = cfg.codebook_dim;
+    resid.reserve((size_t)B * latent * Tz * 4);
+    zq.reserve((size_t)B * latent * Tz * 4);
+    lat.reserve((size_t)B * nq * D * Tz * 4);
+    st.reserve((size_t)B * D * Tz * 4);
+
+    int C = cfg.encoder_dim;
+    int64_t L = Tp;
+    int cur_idx = 0;
+    float* cur = act[0].as<float>();
+    {  // stem; DAC.Preprocess right zero-pad is the x_len < Tin bound
+        ConvIO io{};
+        io.x = pcm; io.x_bstride = T; io.x_cstride = T; io.x_len = (int32_t)T; io.Tin = Tp;
+        io.y = cur; io.y_bstride = (int64_t)C * L; io.y_cstride = L;
+        launch_conv(enc_stem, io, B, stream, &prof);
+    }
+    for (int bi = 0; bi < cfg.n_encoder_rates; ++bi) {
+        for (int u = 0; u < 3; ++u) cur = run_res_unit(enc[bi].ru[u], kDil[u], cur, C, L, B, cur_idx);
+        const int s = cfg.encoder_rates[bi];
+        const int64_t Lo = enc[bi].down.out_len(L);
+        const int o_idx = (cur_idx + 1) % 3;
+        float* o = act[o_idx].as<float>();
+        ConvIO io{};
+        io.x = cur; io.x_bstride = (int64_t)C * L; io.x_cstride = L; io.x_len = (int32_t)L; io.Tin = L;
+        io.alpha_in = enc[bi].a_down.as<float>();
+        io.y = o; io.y_bstride = (int64_t)2 * C * Lo; io.y_cstride = Lo;
+        launch_conv(enc[bi].down, io, B, stream, &prof);
+        (void)s;
+        cur = o; cur_idx = o_idx; C *= 2; L = Lo;
+    }
+    if (L != Tz) fail(NC_ESTATE, "internal: encoder produced %lld frames, expected %lld", (long long)L, (long long)Tz);
+    float* residual = resid.as<float>();
+    {  // Snake -> conv k3 -> z, written straight into the RVQ residual buffer (residual = z.clone())
+        ConvIO io{};
+        io.x = cur; io.x_bstride = (int64_t)C * L; io.x_cstride = L; io.x_len = (int32_t)L; io.Tin = L;
+        io.alpha_in = enc_alpha_out.as<float>();
+        io.y = residual; io.y_bstride = (int64_t)latent * Tz; io.y_cstride = Tz;
+        launch_conv(enc_out, io, B, stream, &prof);
+    }
+    // ---- residual vector quantizer (ResidualVectorQuantizer.cs:54-103)
+    float* zq_d = z ? z : zq.as<float>();
+    float* lat_d = latents ? latents : lat.as<float>();
+    NC_HIP(hipMemsetAsync(zq_d, 0, (size_t)B * latent * Tz * 4, stream));
+    for (int i = 0; i < nq; ++i) {
+        ConvIO pi{};  // in_proj 1x1: residual -> z_e, stored as channel slice i of `latents`
+        pi.x = residual; pi.x_bstride = (int64_t)latent * Tz; pi.x_cstride = Tz; pi.x_len = (int32_t)Tz; pi.Tin = Tz;
+        pi.y = lat_d + (int64_t)i * D * Tz; pi.y_bstride = (int64_t)nq * D * Tz; pi.y_cstride = Tz;
+        launch_conv(*in_proj[i], pi, B, stream, &prof);
+        launch_vq_argmin(*codebooks[i], lat_d + (int64_t)i * D * Tz, (int64_t)nq * D * Tz, B, Tz, codes + (int64_t)i * Tz,
+                         (int64_t)nq * Tz, st.as<float>(), stream, &prof);
+        ConvIO po{};  // out_proj 1x1 with fused zq += q ; residual -= q
+        po.x = st.as<float>(); po.x_bstride = (int64_t)D * Tz; po.x_cstride = Tz; po.x_len = (int32_t)Tz; po.Tin = Tz;
+        po.y = zq_d; po.y_bstride = (int64_t)latent * Tz; po.y_cstride = Tz;
+        po.rvq_zq = zq_d; po.rvq_res = residual; po.epi = EPI_RVQ;
+        launch_conv(*out_proj[i], po, B, stream, &prof);
+    }
+}
+
+void DacModel::from_codes_dev(const int64_t* codes, int B, int n_q, int64_t Tz, float* z) {
+    if (!loaded) fail(NC_ESTATE, "weights not loaded (call nc_codec_load_weights first)");
+    if (!codes || !z) fail(NC_EINVAL, "codes and z must not be null");
+    if (B <= 0 || Tz <= 0 || n_q <= 0 || n_q > cfg.n_codebooks) fail(NC_EINVAL, "bad codes shape [%d,%d,%lld]", B, n_q, (long long)Tz);
+    use_device();
+    const int D = cfg.codebook_dim;
+    st.reserve((size_t)B * D * Tz * 4);
+    NC_HIP(hipMemsetAsync(z, 0, (size_t)B * latent * Tz * 4, stream));
+    for (int i = 0; i < n_q; ++i) {
+        launch_vq_gather(*codebooks[i], codes + (int64_t)i * Tz, (int64_t)n_q * Tz, B, Tz, st.as<float>(), stream, &prof);
+        ConvIO po{};
+        po.x = st.as<float>(); po.x_bstride = (int64_t)D * Tz; po.x_cstride = Tz; po.x_len = (int32_t)Tz; po.Tin = Tz;
+        po.y = z; po.y_bstride = (int64_t)latent * Tz; po.y_cstride = Tz;
+        po.rvq_zq = z; po.rvq_res = nullptr; po.epi = EPI_RVQ;
+        launch_conv(*out_proj[i], po, B, stream, &prof);
+    }
+}
+
+void DacModel::decode_dev(const float* z, int B, int64_t Tz, float* pcm) {
+    if (!loaded) fail(NC_ESTATE, "weights not loaded (call nc_codec_load_weights first)");
+    if (!z || !pcm) fail(NC_EINVAL, "z and pcm must not be null");
+    if (B <= 0 || Tz <= 0) fail(NC_EINVAL, "B and frames must be positive");
+    use_device();
+    int64_t maxel = (int64_t)cfg.decoder_dim * Tz;
+    {
+        int64_t L = Tz;
+        for (int i = 0; i < cfg.n_decoder_rates; ++i) {
+            L = dec[i].up.out_len(L);
+            const int64_t c = cfg.decoder_dim >> (i + 1);
+            if (c * L > maxel) maxel = c * L;
+        }
+    }
+    for (auto& a : act) a.reserve((size_t)B * maxel * sizeof(float));
+    int C = cfg.decoder_dim;
+    int64_t L = Tz;
+    int cur_idx = 0;
+    float* cur = act[0].as<float>();
+    {
+        ConvIO io{};
+        io.x = z; io.x_bstride = (int64_t)latent * Tz; io.x_cstride = Tz; io.x_len = (int32_t)Tz; io.Tin = Tz;
+        io.y = cur; io.y_bstride = (int64_t)C * L; io.y_cstride = L;
+        launch_conv(dec_in, io, B, stream, &prof);
+    }
+    for (int bi = 0; bi < cfg.n_decoder_rates; ++bi) {
+        const int Co = C / 2;
+        const int64_t Lo = dec[bi].up.out_len(L);
+        const int o_idx = (cur_idx + 1) % 3;
+        float* o = act[o_idx].as<float>();
+        ConvIO io{};
+        io.x = cur; io.x_bstride = (int64_t)C * L; io.x_cstride = L; io.x_len = (int32_t)L; io.Tin = L;
+        io.alpha_in = dec[bi].a_up.as<float>();
+        io.y = o; io.y_bstride = (int64_t)Co * Lo; io.y_cstride = Lo;
+        launch_conv(dec[bi].up, io, B, stream, &prof);
+        cur = o; cur_idx = o_idx; C = Co; L = Lo;
+        for (int u = 0; u < 3; ++u) cur = run_res_unit(dec[bi].ru[u], kDil[u], cur, C, L, B, cur_idx);
+    }
+    {
+        ConvIO io{};
+        io.x = cur; io.x_bstride = (int64_t)C * L; io.x_cstride = L; io.x_len = (int32_t)L; io.Tin = L;
+        io.alpha_in = dec_alpha_out.as<float>();
+        io.y = pcm; io.y_bstride = L; io.y_cstride = L;
+        io.epi = EPI_TANH;
+        launch_conv(dec_out, io, B, stream, &prof);
+    }
+}
+
+}  // namespace nc

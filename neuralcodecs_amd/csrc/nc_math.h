@@ -1,0 +1,80 @@
+// Canonical elementary functions of the engine (device + host), see DESIGN.md "Canonical arithmetic".
+//
+// The reference evaluates these inside libtorch (Snake1d.cs:52 sin, Decoder.cs:46 Tanh,
+// Utils/TorchUtils.cs:26-30 ELU).  To make results reproducible bit-for-bit between gfx950 and
+// any IEEE-754 host, each function is ONE fixed sequence of binary32 +,-,*,/,fma,rint
+// (no libm / ocml calls, compiled with -ffp-contract=off so nothing is re-associated or fused).
+// Coefficients: tools/fit_math_poly.py.  Accuracy: sin <= 1.9 ulp(1) on |x|<=40; exp/tanh <= 2 ulp.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define NC_HD __host__ __device__ __forceinline__
+#else
+#define NC_HD inline
+#endif
+
+NC_HD float nc_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+NC_HD float nc_sinf(float x) {
+    float n = __builtin_rintf(x * 0x1.45f306p-2f);  // x * fl(1/pi)
+    float r = nc_fma(n, -3.140625f, x);             // Cody-Waite, pi = A + B + C
+    r = nc_fma(n, -9.67502593994140625e-4f, r);
+    r = nc_fma(n, -1.509957990978376432e-7f, r);
+    float u = r * r;
+    float p = -0x1.9d5778p-26f;
+    p = nc_fma(p, u, 0x1.71936ap-19f);
+    p = nc_fma(p, u, -0x1.a018f4p-13f);
+    p = nc_fma(p, u, 0x1.111110p-7f);
+    p = nc_fma(p, u, -0x1.555556p-3f);
+    float s = nc_fma(r * u, p, r);
+    int ni = (int)n;
+    return (ni & 1) ? -s : s;
+}
+
+NC_HD float nc_expf(float x) {
+    if (x > 88.0f) x = 88.0f;
+    if (x < -87.0f) x = -87.0f;
+    float n = __builtin_rintf(x * 0x1.715476p+0f);  // x * fl(log2 e)
+    float r = nc_fma(n, -0x1.62e400p-1f, x);
+    r = nc_fma(n, -0x1.7f7d1cp-20f, r);
+    float q = 0x1.6d5accp-10f;
+    q = nc_fma(q, r, 0x1.121f36p-7f);
+    q = nc_fma(q, r, 0x1.5554d8p-5f);
+    q = nc_fma(q, r, 0x1.5554cap-3f);
+    q = nc_fma(q, r, 0x1.000000p-1f);
+    float e = nc_fma(r * r, q, r) + 1.0f;
+    int32_t ni = (int32_t)n;
+    uint32_t bits = (uint32_t)(ni + 127) << 23;
+    float sc = __builtin_bit_cast(float, bits);
+    return e * sc;
+}
+
+NC_HD float nc_tanhf(float x) {
+    float ax = __builtin_fabsf(x);
+    if (ax < 0.55f) {
+        float u = x * x;
+        float p = -0x1.ad2786p-8f;
+        p = nc_fma(p, u, 0x1.5c97c6p-6f);
+        p = nc_fma(p, u, -0x1.b99508p-5f);
+        p = nc_fma(p, u, 0x1.110fc6p-3f);
+        p = nc_fma(p, u, -0x1.555554p-2f);
+        return nc_fma(x * u, p, x);
+    }
+    float t;
+    if (ax > 9.0f) {
+        t = 1.0f;
+    } else {
+        float e = nc_expf(2.0f * ax);
+        t = 1.0f - 2.0f / (e + 1.0f);
+    }
+    return __builtin_copysignf(t, x);
+}
+
+// Snake1d.cs:52  where(alpha == 0, x, addcdiv(x, sin(alpha*x)^2, alpha, 1))
+NC_HD float nc_snakef(float x, float alpha) {
+    if (alpha == 0.0f) return x;
+    float s = nc_sinf(alpha * x);
+    return x + (s * s) / alpha;
+}

@@ -1,0 +1,88 @@
+// Engine objects behind the opaque nc_codec handle.
+#pragma once
+#include <memory>
+
+#include "nc_common.h"
+#include "nc_conv.h"
+
+namespace nc {
+
+const char* get_last_error();
+void fold_weight_norm_dac(const float* v, const float* g, int64_t d0, int64_t inner, float* w);
+
+// ---- RVQ kernels (nc_rvq.hip) ----------------------------------------------------------------
+// Codebook resident on the device in the two layouts the kernels want.
+struct Codebook {
+    int N = 0, D = 0;
+    DevBuf cbT;  // [D][N] transposed copy: conflict-free LDS image for the argmin
+    DevBuf cb;   // [N][D] row-major: gather
+    DevBuf c2;   // [N] squared norms (canonical fma chain, computed once on the host)
+    void build(const float* host_cb, int N, int D);
+};
+// z_e [B,D,T] (batch stride ze_bstride) -> codes[b*codes_bstride + t] (int64) and st [B,D,T] = z_e + (cb[idx] - z_e)
+void launch_vq_argmin(const Codebook& cb, const float* z_e, int64_t ze_bstride, int B, int64_t T, int64_t* codes,
+                      int64_t codes_bstride, float* st, hipStream_t s, Profiler* prof);
+// codes -> out [B,D,T] = cb[codes]  (Embedding + transpose, VectorQuantizer.cs:135-142)
+void launch_vq_gather(const Codebook& cb, const int64_t* codes, int64_t codes_bstride, int B, int64_t T, float* out, hipStream_t s,
+                      Profiler* prof);
+
+// ---- codec objects ---------------------------------------------------------------------------
+struct Codec {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool loaded = false;
+    Profiler prof;
+    virtual ~Codec();
+    virtual void load(const Blob& blob) = 0;
+    void init_device(int device_index);
+    void use_device() const;
+};
+
+struct DacModel : Codec {
+    nc_dac_config cfg{};
+    int latent = 0, hop = 1;
+
+    struct ResUnit {
+        DevBuf a1, a2;
+        ConvLayer c7, c1;
+    };
+    ConvLayer enc_stem;
+    struct EncBlk {
+        ResUnit ru[3];
+        DevBuf a_down;
+        ConvLayer down;
+    } enc[8];
+    DevBuf enc_alpha_out;
+    ConvLayer enc_out;
+
+    std::vector<std::unique_ptr<ConvLayer>> in_proj, out_proj;
+    std::vector<std::unique_ptr<Codebook>> codebooks;
+
+    ConvLayer dec_in;
+    struct DecBlk {
+        DevBuf a_up;
+        ConvLayer up;
+        ResUnit ru[3];
+    } dec[8];
+    DevBuf dec_alpha_out;
+    ConvLayer dec_out;
+
+    // workspace (grow-only)
+    DevBuf act[3], resid, zq, lat, st, codes_ws, h_in, h_out, h_codes, h_aux0, h_aux1;
+
+    explicit DacModel(const nc_dac_config& c);
+    void load(const Blob& blob) override;
+    int64_t padded_len(int64_t T) const { return (T + hop - 1) / hop * hop; }
+    int64_t frames(int64_t T) const { return (T + hop - 1) / hop; }
+    int64_t decoded_len(int64_t frames) const;
+    // device-pointer entry points (async on `stream`)
+    void encode_dev(const float* pcm, int B, int64_t T, int sample_rate, int n_q, int64_t* codes, float* z, float* latents);
+    void decode_dev(const float* z, int B, int64_t frames, float* pcm);
+    void from_codes_dev(const int64_t* codes, int B, int n_q, int64_t frames, float* z);
+
+  private:
+    float* run_res_unit(ResUnit& ru, int dil, float* cur, int C, int64_t L, int B, int& cur_idx);
+};
+
+}  // namespace nc

@@ -1,0 +1,49 @@
+"""Op-level test hooks over the engine's kernels (nc_op_* in include/nc_mi355x.h): host numpy in/out."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+def conv1d(x, weight, bias=None, stride=1, pad=0, dil=1, alpha_in=None, alpha_out=None, residual=None, transposed=False,
+           out_pad=0, tanh_out=False, device_index=0):
+    x = np.ascontiguousarray(x, np.float32); w = np.ascontiguousarray(weight, np.float32)
+    B, Cin, Tin = x.shape
+    if transposed:
+        Cout, K = w.shape[1], w.shape[2]
+        Tout = (Tin - 1) * stride - 2 * pad + K + out_pad
+    else:
+        Cout, K = w.shape[0], w.shape[2]
+        Tout = (Tin + 2 * pad - dil * (K - 1) - 1) // stride + 1
+    d = _lib.NcConvDesc(B, Cin, Cout, K, stride, pad, dil, out_pad, Tin, 1 if transposed else 0, 1 if tanh_out else 0)
+    f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
+    b, ai, ao, r = f(bias), f(alpha_in), f(alpha_out), f(residual)
+    y = np.empty((B, Cout, Tout), np.float32)
+    to = C.c_int64()
+    _lib.check(_lib.lib().nc_op_conv1d(device_index, C.byref(d), x.ctypes.data, w.ctypes.data, _p(b), _p(ai), _p(ao), _p(r),
+                                       y.ctypes.data, C.byref(to)))
+    assert to.value == Tout
+    return y
+
+
+def vq_argmin(z_e, codebook, device_index=0):
+    z = np.ascontiguousarray(z_e, np.float32); cb = np.ascontiguousarray(codebook, np.float32)
+    B, D, T = z.shape
+    idx = np.empty((B, T), np.int64); st = np.empty_like(z)
+    _lib.check(_lib.lib().nc_op_vq_argmin(device_index, z.ctypes.data, B, D, T, cb.ctypes.data, cb.shape[0], idx.ctypes.data,
+                                          st.ctypes.data))
+    return idx, st
+
+
+def fold_weight_norm(v, g):
+    v = np.ascontiguousarray(v, np.float32); g = np.ascontiguousarray(g, np.float32).reshape(-1)
+    w = np.empty_like(v)
+    _lib.check(_lib.lib().nc_op_fold_weight_norm(v.ctypes.data, g.ctypes.data, v.shape[0], int(np.prod(v.shape[1:])), w.ctypes.data))
+    return w

@@ -1,0 +1,159 @@
+"""GPU suite: DAC Encode / Decode / FromCodes through the C ABI against the oracle and the golden vectors."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from conftest import audit_code_mismatches, dac_cfg_from_meta  # noqa: E402
+from neuralcodecs_amd import DAC, DACConfig  # noqa: E402
+from neuralcodecs_amd.weights import dac_synthetic_state_dict, save_blob, synthetic_pcm  # noqa: E402
+from oracle import c_oracle  # noqa: E402
+
+PCM_TOL = 1e-4
+LATENT_TOL = 2e-5
+GAP_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def small(golden_small):
+    cfg = dac_cfg_from_meta(golden_small["meta"])
+    blob = save_blob(dac_synthetic_state_dict(cfg, seed=golden_small["meta"]["weight_seed"]))
+    m = DAC(cfg)
+    m.load_blob(blob)
+    yield cfg, m, c_oracle.RefDAC(cfg, blob)
+    m.dispose()
+
+
+@pytest.fixture(scope="module")
+def full(golden_full):
+    cfg = dac_cfg_from_meta(golden_full["meta"])
+    blob = save_blob(dac_synthetic_state_dict(cfg, seed=golden_full["meta"]["weight_seed"]))
+    m = DAC(cfg)
+    m.load_blob(blob)
+    yield cfg, m, c_oracle.RefDAC(cfg, blob)
+    m.dispose()
+
+
+def test_small_encode_decode_vs_golden(small, golden_small):
+    cfg, m, ref = small
+    z, codes, lat, cl, cbl = m.encode(golden_small["pcm"])
+    assert codes.dtype == np.int64 and codes.shape == (2, 4, 7)
+    assert float(cl) == 0.0 and float(cbl) == 0.0                      # D5: dummy losses
+    audit_code_mismatches(codes, golden_small["codes"], golden_small["gap"], GAP_TOL)
+    if np.array_equal(codes, golden_small["codes"]):
+        assert np.abs(z - golden_small["zq"]).max() < LATENT_TOL
+        assert np.abs(lat - golden_small["latents"]).max() < LATENT_TOL
+    audio = m.decode(golden_small["zq"])
+    assert audio.shape == golden_small["audio"].shape
+    assert np.abs(audio - golden_small["audio"]).max() < PCM_TOL
+
+
+def test_small_bit_exact_vs_c_oracle(small, golden_small):
+    cfg, m, ref = small
+    z, codes, lat, _, _ = m.encode(golden_small["pcm"])
+    rz, rcodes, rlat, _ = ref.encode(golden_small["pcm"])
+    assert np.array_equal(codes, rcodes)
+    assert np.array_equal(lat, rlat)
+    assert np.array_equal(z, rz)
+    assert np.array_equal(m.decode(z), ref.decode(rz))
+    assert np.array_equal(m.from_codes(codes), ref.from_codes(rcodes))
+
+
+def test_small_n_quantizers_and_from_codes(small, golden_small):
+    cfg, m, ref = small
+    z2, codes2, lat2, _, _ = m.encode(golden_small["pcm"], n_quantizers=2)
+    assert codes2.shape == (2, 2, 7) and lat2.shape == (2, 16, 7)
+    assert np.array_equal(codes2, golden_small["codes_nq2"])
+    assert np.abs(z2 - golden_small["zq_nq2"]).max() < LATENT_TOL
+    zf = m.from_codes(golden_small["codes"].astype(np.int64))
+    assert np.abs(zf - golden_small["from_codes"]).max() < LATENT_TOL
+
+
+def test_float_array_overloads(small, golden_small):
+    """DAC.Encode(float[]) returns the flattened zQ latents, Decode(float[]) consumes them (D12)."""
+    cfg, m, ref = small
+    pcm = golden_small["pcm"][0, 0]
+    zflat = m.encode_array(pcm)
+    assert zflat.shape == (128 * 7,)
+    rz = ref.encode(pcm.reshape(1, 1, -1))[0]
+    assert np.array_equal(zflat, rz.reshape(-1))
+    out = m.decode_array(zflat)
+    assert np.array_equal(out, ref.decode(rz).reshape(-1))
+    assert np.array_equal(m.forward_array(pcm), out)
+
+
+def test_error_conventions(small, golden_small):
+    cfg, m, ref = small
+    with pytest.raises(ValueError, match="sample rate"):
+        m.encode(golden_small["pcm"], sample_rate=cfg.sample_rate + 1)          # ArgumentException, DAC.cs:146
+    with pytest.raises(ValueError):
+        m.encode(None)
+    with pytest.raises(ValueError):
+        m.decode(np.zeros((1, 3, 7), np.float32))
+    with pytest.raises(FileNotFoundError):
+        m.load_weights("/nonexistent/weights.ncwb")                               # FileNotFoundException, DAC.cs:347
+    fresh = DAC(cfg)
+    with pytest.raises(RuntimeError):
+        fresh.encode(golden_small["pcm"])                                         # weights not loaded
+    fresh.dispose()
+
+
+def test_ragged_and_tiny_inputs(small):
+    cfg, m, ref = small
+    for T in (1, 319, 320, 321, 5000):
+        pcm = synthetic_pcm(1, 1, T, cfg.sample_rate, seed=T)
+        z, codes, lat, _, _ = m.encode(pcm)
+        rz, rcodes, rlat, _ = ref.encode(pcm)
+        assert codes.shape == (1, cfg.n_codebooks, -(-T // cfg.hop_length))
+        assert np.array_equal(codes, rcodes) and np.array_equal(z, rz)
+        assert np.array_equal(m.decode(z), ref.decode(rz))
+
+
+def test_full_size_dac44k_vs_golden_and_oracle(full, golden_full):
+    """BASELINE config C2 shape at B=2: clip 0 is the golden clip; both clips must equal the C oracle bit for bit."""
+    cfg, m, ref = full
+    meta = golden_full["meta"]
+    pcm = synthetic_pcm(2, 1, meta["T"], cfg.sample_rate, seed=meta["pcm_seed"])
+    z, codes, lat, _, _ = m.encode(pcm)
+    assert codes.shape == (2, 9, 87)
+    diverged = audit_code_mismatches(codes[:1], golden_full["codes"], golden_full["gap"], GAP_TOL)
+    audio = m.decode(z)
+    assert audio.shape == (2, 1, 44544)
+    if diverged == 0:
+        assert np.abs(z[:1, ::16, :] - golden_full["zq_slice"]).max() < LATENT_TOL
+        assert np.abs(audio[:1, :, ::29] - golden_full["audio_slice"]).max() < PCM_TOL
+    rz, rcodes, rlat, _ = ref.encode(pcm)
+    assert np.array_equal(codes, rcodes)
+    assert np.array_equal(z, rz)
+    assert np.array_equal(audio, ref.decode(rz))
+
+
+def test_device_tensor_api_matches_host_api(full, golden_full):
+    """torch CUDA tensors in/out (zero-copy *_dev entry points on torch's stream) == host-buffer API."""
+    import torch
+    cfg, m, ref = full
+    meta = golden_full["meta"]
+    pcm = synthetic_pcm(2, 1, meta["T"], cfg.sample_rate, seed=meta["pcm_seed"])
+    z, codes, lat, _, _ = m.encode(pcm)
+    audio = m.decode(z)
+    xd = torch.from_numpy(pcm).cuda()
+    zd, cd, ld, _, _ = m.encode(xd)
+    ad = m.decode(zd)
+    fd = m.from_codes(cd)
+    torch.cuda.synchronize()
+    assert np.array_equal(cd.cpu().numpy(), codes)
+    assert np.array_equal(zd.cpu().numpy(), z)
+    assert np.array_equal(ad.cpu().numpy(), audio)
+    assert np.array_equal(fd.cpu().numpy(), m.from_codes(codes))
+
+
+def test_batch_invariance_and_determinism(full, golden_full):
+    """Clips are independent: clip i of a batch equals the same clip encoded alone; repeated calls are identical."""
+    cfg, m, ref = full
+    meta = golden_full["meta"]
+    pcm = synthetic_pcm(3, 1, meta["T"], cfg.sample_rate, seed=meta["pcm_seed"])
+    z, codes, _, _, _ = m.encode(pcm)
+    z1, codes1, _, _, _ = m.encode(pcm[2:3])
+    assert np.array_equal(codes[2:3], codes1) and np.array_equal(z[2:3], z1)
+    z_again, codes_again, _, _, _ = m.encode(pcm)
+    assert np.array_equal(codes, codes_again) and np.array_equal(z, z_again)

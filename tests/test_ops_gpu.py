@@ -1,0 +1,110 @@
+"""GPU suite: each HIP kernel against the C oracle, bit for bit (same canonical fma chains on both sides)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from neuralcodecs_amd import ops  # noqa: E402
+from oracle import c_oracle  # noqa: E402
+
+
+def _rand(rng, *shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float32)
+
+
+def _alpha(rng, c):
+    a = (0.5 + 1.5 * rng.random(c)).astype(np.float32)
+    a[::5] = 0.0
+    return a
+
+
+CONV_CASES = [
+    # (Cin, Cout, K, stride, pad, dil, T, B)       the DAC layer families at reduced width, plus ragged sizes
+    (1, 64, 7, 1, 3, 1, 1000, 2),      # stem (Cin=1)
+    (64, 64, 7, 1, 3, 1, 777, 2),      # residual unit d=1
+    (96, 96, 7, 1, 9, 3, 640, 1),      # d=3, TM=3 tile
+    (128, 128, 7, 1, 27, 9, 300, 2),   # d=9 halo 54, TM=4
+    (40, 24, 7, 1, 27, 9, 50, 1),      # ragged channels, clip shorter than the halo
+    (64, 64, 1, 1, 0, 1, 515, 2),      # 1x1
+    (64, 128, 4, 2, 1, 1, 1024, 2),    # down s=2
+    (32, 64, 8, 4, 2, 1, 1000, 1),     # down s=4
+    (32, 64, 16, 8, 4, 1, 2048, 1),    # down s=8
+    (16, 32, 10, 5, 3, 1, 995, 1),     # down s=5 (DAC 16/24 kHz)
+    (1024, 8, 1, 1, 0, 1, 87, 2),      # RVQ in_proj
+    (8, 1024, 1, 1, 0, 1, 87, 2),      # RVQ out_proj
+    (128, 96, 3, 1, 1, 1, 87, 2),      # encoder tail k3
+    (96, 1, 7, 1, 3, 1, 900, 2),       # head (Cout=1)
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,d,T,B", CONV_CASES)
+def test_conv1d_bit_exact(cin, cout, k, s, p, d, T, B):
+    rng = np.random.default_rng(cin * 1000 + cout + k)
+    x = _rand(rng, B, cin, T)
+    w = _rand(rng, cout, cin, k, scale=1.0 / np.sqrt(cin * k))
+    b = _rand(rng, cout, scale=0.1)
+    want = c_oracle.conv1d(x, w, b, s, p, d)
+    got = ops.conv1d(x, w, b, s, p, d)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+
+
+def test_conv1d_fused_snake_residual_bit_exact():
+    """The ResidualUnit fusion: Snake on the input tile, bias, Snake for the next conv; then 1x1 + residual."""
+    rng = np.random.default_rng(5)
+    B, C, T, d = 2, 96, 700, 3
+    x = _rand(rng, B, C, T, scale=1.5)
+    a1, a2 = _alpha(rng, C), _alpha(rng, C)
+    w7 = _rand(rng, C, C, 7, scale=1.0 / np.sqrt(C * 7)); b7 = _rand(rng, C, scale=0.1)
+    w1 = _rand(rng, C, C, 1, scale=1.0 / np.sqrt(C)); b1 = _rand(rng, C, scale=0.1)
+    h_ref = c_oracle.snake(c_oracle.conv1d(c_oracle.snake(x, a1), w7, b7, 1, 3 * d, d), a2)
+    y_ref = c_oracle.conv1d(h_ref, w1, b1, residual=x)
+    h = ops.conv1d(x, w7, b7, 1, 3 * d, d, alpha_in=a1, alpha_out=a2)
+    assert np.array_equal(h, h_ref)
+    y = ops.conv1d(h, w1, b1, residual=x)
+    assert np.array_equal(y, y_ref)
+
+
+def test_conv1d_tanh_head_bit_exact():
+    rng = np.random.default_rng(6)
+    x = _rand(rng, 2, 96, 1000, scale=2.0)
+    a = _alpha(rng, 96)
+    w = _rand(rng, 1, 96, 7, scale=0.05); b = _rand(rng, 1, scale=0.1)
+    want = c_oracle.tanh(c_oracle.conv1d(c_oracle.snake(x, a), w, b, 1, 3, 1))
+    got = ops.conv1d(x, w, b, 1, 3, 1, alpha_in=a, tanh_out=True)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("cin,cout,s,T,B", [(64, 32, 2, 500, 2), (96, 48, 4, 300, 1), (128, 64, 8, 87, 2), (48, 24, 5, 56, 2),
+                                            (1536, 768, 8, 20, 1)])
+def test_conv_transpose1d_bit_exact(cin, cout, s, T, B):
+    rng = np.random.default_rng(cin + s)
+    k, p = 2 * s, (s + 1) // 2
+    x = _rand(rng, B, cin, T)
+    a = _alpha(rng, cin)
+    w = _rand(rng, cin, cout, k, scale=1.0 / np.sqrt(cin * 2)); b = _rand(rng, cout, scale=0.1)
+    want = c_oracle.conv_transpose1d(c_oracle.snake(x, a), w, b, s, p)
+    got = ops.conv1d(x, w, b, s, p, 1, alpha_in=a, transposed=True)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+
+
+@pytest.mark.parametrize("N,D,T,B", [(1024, 8, 87, 4), (64, 8, 7, 2), (4096, 8, 100, 1)])
+def test_vq_argmin_bit_exact(N, D, T, B):
+    rng = np.random.default_rng(N)
+    cb = _rand(rng, N, D, scale=0.8)
+    z = _rand(rng, B, D, T)
+    idx_ref, st_ref, _ = c_oracle.vq_argmin(z, cb)
+    idx, st = ops.vq_argmin(z, cb)
+    assert np.array_equal(idx, idx_ref)
+    assert np.array_equal(st, st_ref)
+
+
+def test_vq_argmin_tie_break_first_index():
+    cb = np.zeros((128, 8), np.float32)
+    cb[:, 0] = 1.0
+    cb[70, 0] = 0.0
+    cb[5, 0] = 0.0      # two exact ties in different lanes/iterations: the lower index must win
+    z = np.zeros((1, 8, 3), np.float32)
+    idx, _ = ops.vq_argmin(z, cb)
+    assert idx.tolist() == [[5, 5, 5]]

@@ -1,0 +1,65 @@
+"""Generate tests/golden/*.npz with the PyTorch-CPU restatement of the reference graph (oracle/torch_ref).
+
+Run in the build container (CPU):  python tools/make_golden.py
+The fixtures are DATA (inputs + expected outputs); weights are regenerated from the seed by
+neuralcodecs_amd.weights (integer counter-based generator, bit-reproducible), so only the small
+reduced-width case stores nothing but I/O, and the full-size DAC-44.1kHz case stores codes, the
+top-2 distance gap of every argmin (for near-tie audits) and decimated slices of z / PCM.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from neuralcodecs_amd.config import DACConfig  # noqa: E402
+from neuralcodecs_amd.weights import dac_synthetic_state_dict, synthetic_pcm  # noqa: E402
+from oracle.torch_ref.dac import TorchDAC  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_num_threads(8)
+
+SMALL = dict(sample_rate=16000, encoder_dim=8, encoder_rates=(2, 4, 5, 8), decoder_dim=48, decoder_rates=(8, 5, 4, 2),
+             n_codebooks=4, codebook_size=64, codebook_dim=8)
+
+
+def top2_gap(dists):
+    g = []
+    for d in dists:
+        v, _ = torch.topk(d, 2, dim=1, largest=False)
+        g.append((v[:, 1] - v[:, 0]).numpy())
+    return np.stack(g, 0)  # [nq, B*T']
+
+
+def dac_case(name, cfg_kw, B, T, wseed, pseed, full):
+    cfg = DACConfig(**cfg_kw)
+    sd = dac_synthetic_state_dict(cfg, seed=wseed)
+    m = TorchDAC(cfg, sd)
+    pcm = synthetic_pcm(B, 1, T, cfg.sample_rate, seed=pseed)
+    zq, codes, lat, dists = m.encode(pcm, want_dist=True)
+    audio = m.decode(zq)
+    z_from = m.from_codes(codes)
+    meta = dict(cfg=cfg_kw, B=B, T=T, weight_seed=wseed, pcm_seed=pseed)
+    out = dict(meta=json.dumps(meta), codes=codes.numpy().astype(np.int16), gap=top2_gap(dists).astype(np.float32))
+    if full:
+        out.update(zq_slice=zq.numpy()[:, ::16, :], audio_slice=audio.numpy()[:, :, ::29],
+                   zq_sum=np.float64(zq.double().sum().item()), audio_abs_sum=np.float64(audio.double().abs().sum().item()),
+                   from_codes_slice=z_from.numpy()[:, ::16, :])
+    else:
+        out.update(pcm=pcm, zq=zq.numpy(), latents=lat.numpy(), audio=audio.numpy(), from_codes=z_from.numpy())
+        # n_quantizers = 2 overload (ResidualVectorQuantizer.cs:105-206 eval branch)
+        zq2, codes2, lat2 = m.encode(pcm, n_quantizers=2)
+        out.update(codes_nq2=codes2.numpy().astype(np.int16), zq_nq2=zq2.numpy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k != "meta"})
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    # reduced width, ragged length (not a hop multiple), odd stride 5 (DAC-16/24 kHz presets use it)
+    dac_case("dac_small", SMALL, 2, 2000, 7, 11, False)
+    # full-size DAC 44.1 kHz 8 kbps, one 1 s clip (BASELINE config C2 at B=1)
+    dac_case("dac44k_b1", dict(), 1, 44100, 42, 1234, True)
