@@ -148,6 +148,9 @@ typedef struct {
  * alpha_in [Cin] / alpha_out [Cout] / bias [Cout] / residual [B,Cout,Tout] are nullable. */
 NC_API nc_status nc_op_conv1d(int device_index, const nc_conv_desc* d, const float* x, const float* weight, const float* bias,
                               const float* alpha_in, const float* alpha_out, const float* residual, float* y, int64_t* Tout);
+/* Timing hook over the same launch path: runs the convolution `iters` times on device-resident seeded random data
+ * (fuse bit0: Snake on input, bit1: Snake on output, bit2: residual add) and returns the HIP-event average per launch. */
+NC_API nc_status nc_op_conv1d_bench(int device_index, const nc_conv_desc* d, int32_t fuse, int32_t iters, double* avg_ms);
 /* one VQ stage on projected latents z_e [B,D,T] against codebook [N,D] -> idx [B,T], st [B,D,T] */
 NC_API nc_status nc_op_vq_argmin(int device_index, const float* z_e, int32_t B, int32_t D, int64_t T, const float* codebook,
                                  int32_t N, int64_t* idx, float* st);

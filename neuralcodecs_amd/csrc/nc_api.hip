@@ -1,4 +1,6 @@
 // C ABI (include/nc_mi355x.h): argument validation, exception -> status translation, host-buffer variants.
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <fstream>
 
@@ -259,6 +261,57 @@ nc_status nc_op_conv1d(int device_index, const nc_conv_desc* d, const float* x, 
         launch_conv(L, io, d->B, nullptr, nullptr);
         NC_HIP(hipDeviceSynchronize());
         NC_HIP(hipMemcpy(y, dy.p, ny, hipMemcpyDeviceToHost));
+        dx.release(); dy.release(); dai.release(); dao.release(); dr.release(); L.w.release(); L.bias.release();
+    });
+}
+
+nc_status nc_op_conv1d_bench(int device_index, const nc_conv_desc* d, int32_t fuse, int32_t iters, double* avg_ms) {
+    return guard([&] {
+        if (!d || !avg_ms || iters <= 0) fail(NC_EINVAL, "null argument");
+        if (d->B <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->K <= 0 || d->stride <= 0 || d->Tin <= 0) fail(NC_EINVAL, "bad conv shape");
+        op_set_device(device_index);
+        uint64_t st = 0x9E3779B97F4A7C15ull;
+        auto rnd = [&]() {  // uniform [-1,1)
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            return (float)((int64_t)(st >> 40) - (1 << 23)) * (1.0f / (1 << 23));
+        };
+        const size_t nw = (size_t)d->Cin * d->Cout * d->K;
+        std::vector<float> w(nw), bias(d->Cout), al(std::max(d->Cin, d->Cout));
+        const float sc = 1.0f / std::sqrt((float)d->Cin * (d->transposed ? 2 : d->K));
+        for (auto& v : w) v = rnd() * sc;
+        for (auto& v : bias) v = rnd() * 0.1f;
+        for (auto& v : al) v = 1.25f + 0.75f * rnd();
+        ConvLayer L;
+        L.build(w.data(), bias.data(), d->Cin, d->Cout, d->K, d->stride, d->pad, d->dil, d->out_pad, d->transposed != 0);
+        const int64_t Tout = L.out_len(d->Tin);
+        if (Tout <= 0) fail(NC_EINVAL, "empty output");
+        const size_t nx = (size_t)d->B * d->Cin * d->Tin, ny = (size_t)d->B * d->Cout * Tout;
+        std::vector<float> hx(nx);
+        for (auto& v : hx) v = rnd();
+        DevBuf dx, dy, dai, dao, dr;
+        dx.reserve(nx * 4); dy.reserve(ny * 4); dai.reserve(al.size() * 4); dao.reserve(al.size() * 4); dr.reserve(ny * 4);
+        NC_HIP(hipMemcpy(dx.p, hx.data(), nx * 4, hipMemcpyHostToDevice));
+        NC_HIP(hipMemcpy(dai.p, al.data(), al.size() * 4, hipMemcpyHostToDevice));
+        NC_HIP(hipMemcpy(dao.p, al.data(), al.size() * 4, hipMemcpyHostToDevice));
+        NC_HIP(hipMemset(dr.p, 0, ny * 4));
+        ConvIO io{};
+        io.x = dx.as<float>(); io.x_bstride = (int64_t)d->Cin * d->Tin; io.x_cstride = d->Tin; io.x_len = (int32_t)d->Tin; io.Tin = d->Tin;
+        io.alpha_in = (fuse & 1) ? dai.as<float>() : nullptr;
+        io.alpha_out = (fuse & 2) ? dao.as<float>() : nullptr;
+        io.res = (fuse & 4) ? dr.as<float>() : nullptr;
+        io.y = dy.as<float>(); io.y_bstride = (int64_t)d->Cout * Tout; io.y_cstride = Tout;
+        io.epi = d->tanh_out ? EPI_TANH : 0;
+        hipEvent_t e0, e1;
+        NC_HIP(hipEventCreate(&e0)); NC_HIP(hipEventCreate(&e1));
+        for (int i = 0; i < 2; ++i) launch_conv(L, io, d->B, nullptr, nullptr);
+        NC_HIP(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) launch_conv(L, io, d->B, nullptr, nullptr);
+        NC_HIP(hipEventRecord(e1, nullptr));
+        NC_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        NC_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *avg_ms = (double)ms / iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         dx.release(); dy.release(); dai.release(); dao.release(); dr.release(); L.w.release(); L.bias.release();
     });
 }

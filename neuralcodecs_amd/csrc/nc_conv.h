@@ -41,6 +41,11 @@ struct ConvArgs {
     int32_t stride, dil, pad;      // x position of (col,k) = col*stride + k*dil - pad
     int32_t B, n_co_tiles, n_t_tiles, n_cb, n_phase;
     int32_t xw, xwp, xrow, xneg;   // staged input window geometry (see kernel)
+    int32_t xbuf;                  // floats per window buffer (CB*xrow rounded up to 4)
+    int32_t nchunk, n_items;       // 64-slot chunks per channel row; CB*nchunk wave-level staging items
+    int32_t chunk_magic;           // item / nchunk  == (item * chunk_magic) >> 20   (host-verified)
+    int32_t stride_magic;          // j / stride     == (j * stride_magic) >> 20     (host-verified)
+    int32_t tapoff[16];            // window slot of tap k at column 0 (phase de-interleave folded in)
     int32_t epi;
 };
 

@@ -9,42 +9,68 @@ namespace nc {
 
 typedef void (*conv_kernel_fn)(const ConvArgs);
 conv_kernel_fn conv_kernel_table_k1(int, int);
+int conv_kernel_cb_k1();
+int conv_kernel_nx_k1();
 conv_kernel_fn conv_kernel_table_k2(int, int);
+int conv_kernel_cb_k2();
+int conv_kernel_nx_k2();
 conv_kernel_fn conv_kernel_table_k3(int, int);
+int conv_kernel_cb_k3();
+int conv_kernel_nx_k3();
 conv_kernel_fn conv_kernel_table_k4(int, int);
+int conv_kernel_cb_k4();
+int conv_kernel_nx_k4();
 conv_kernel_fn conv_kernel_table_k6(int, int);
+int conv_kernel_cb_k6();
+int conv_kernel_nx_k6();
 conv_kernel_fn conv_kernel_table_k7(int, int);
+int conv_kernel_cb_k7();
+int conv_kernel_nx_k7();
 conv_kernel_fn conv_kernel_table_k8(int, int);
+int conv_kernel_cb_k8();
+int conv_kernel_nx_k8();
 conv_kernel_fn conv_kernel_table_k10(int, int);
+int conv_kernel_cb_k10();
+int conv_kernel_nx_k10();
 conv_kernel_fn conv_kernel_table_k16(int, int);
+int conv_kernel_cb_k16();
+int conv_kernel_nx_k16();
+
+#define NC_K_CASES(X) X(1) X(2) X(3) X(4) X(6) X(7) X(8) X(10) X(16)
 
 static int cb_for_k(int K) {
     switch (K) {
-        case 1: return 32;
-        case 2: return 16;
-        case 3: return 16;
-        case 4: return 8;
-        case 6: return 8;
-        case 7: return 8;
-        case 8: return 8;
-        case 10: return 4;
-        case 16: return 4;
+#define X(k) case k: return conv_kernel_cb_k##k();
+        NC_K_CASES(X)
+#undef X
     }
     fail(NC_EUNSUPPORTED, "convolution with %d taps per phase has no kernel instantiation", K);
+}
+
+static int nx_for_k(int K) {
+    switch (K) {
+#define X(k) case k: return conv_kernel_nx_k##k();
+        NC_K_CASES(X)
+#undef X
+    }
+    fail(NC_EUNSUPPORTED, "convolution with %d taps per phase has no kernel instantiation", K);
+}
+
+// exact small-range division by multiplication: n / d == (n * magic) >> 20 for all 0 <= n < limit
+static int32_t magic_div(int d, int limit) {
+    const int32_t m = (int32_t)(((1u << 20) + d - 1) / d);
+    for (int n = 0; n < limit; ++n)
+        if ((int)(((int64_t)n * m) >> 20) != n / d || (int64_t)n * m > 0x7fffffffLL)
+            fail(NC_EUNSUPPORTED, "internal: no exact reciprocal for /%d below %d", d, limit);
+    return m;
 }
 
 static conv_kernel_fn lookup_kernel(const TileCfg& c) {
     conv_kernel_fn f = nullptr;
     switch (c.K) {
-        case 1: f = conv_kernel_table_k1(c.TM, c.TN); break;
-        case 2: f = conv_kernel_table_k2(c.TM, c.TN); break;
-        case 3: f = conv_kernel_table_k3(c.TM, c.TN); break;
-        case 4: f = conv_kernel_table_k4(c.TM, c.TN); break;
-        case 6: f = conv_kernel_table_k6(c.TM, c.TN); break;
-        case 7: f = conv_kernel_table_k7(c.TM, c.TN); break;
-        case 8: f = conv_kernel_table_k8(c.TM, c.TN); break;
-        case 10: f = conv_kernel_table_k10(c.TM, c.TN); break;
-        case 16: f = conv_kernel_table_k16(c.TM, c.TN); break;
+#define X(k) case k: f = conv_kernel_table_k##k(c.TM, c.TN); break;
+        NC_K_CASES(X)
+#undef X
     }
     if (!f) fail(NC_EUNSUPPORTED, "no conv kernel for TM=%d TN=%d K=%d", c.TM, c.TN, c.K);
     return f;
@@ -134,6 +160,11 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     const int64_t Tout = L.out_len(io.Tin);
     const int64_t n_cols_all = L.transposed ? io.Tin + L.Ktaps - 1 : Tout;
     c.TN = n_cols_all >= 192 ? 2 : 1;  // 256-column tiles for long clips, 128 for the deep (short) layers
+    {   // the per-lane staging registers bound the window: fall back to 128-column tiles when it does not fit
+        const int sx0 = L.transposed ? 1 : L.stride, ad0 = L.transposed ? 1 : L.dil;
+        const int xw2 = (c.BN() - 1) * sx0 + (L.Ktaps - 1) * ad0 + 1;
+        if (c.TN == 2 && c.CB * ((xw2 + 63) / 64) > 4 * nx_for_k(c.K)) c.TN = 1;
+    }
     const int BM = c.BM(), BN = c.BN(), CB = c.CB, KB = c.KB();
     ConvArgs a{};
     a.x = io.x; a.x_bstride = io.x_bstride; a.x_cstride = io.x_cstride; a.Cin = L.Cin; a.x_len = io.x_len;
@@ -160,12 +191,25 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     const int ad = a.dil < 0 ? -a.dil : a.dil;
     a.xneg = a.dil < 0 ? (L.Ktaps - 1) * ad : 0;
     a.xw = (BN - 1) * sx + (L.Ktaps - 1) * ad + 1;
-    a.xwp = (a.xw + sx - 1) / sx;
-    a.xrow = sx == 1 ? a.xw : sx * a.xwp;
+    a.nchunk = (a.xw + 63) / 64;
+    a.xwp = (a.nchunk * 64 + sx - 1) / sx;   // rows are padded to whole 64-slot chunks: every staging store is in-bounds
+    a.xrow = sx == 1 ? a.nchunk * 64 : sx * a.xwp;
     a.n_co_tiles = (L.Cout + BM - 1) / BM;
     a.n_t_tiles = (a.n_cols + BN - 1) / BN;
     a.n_cb = (L.Cin + CB - 1) / CB;
-    const size_t lds = sizeof(float) * ((size_t)KB * BM + (size_t)CB * a.xrow);
+    a.n_items = CB * a.nchunk;
+    const int nx = nx_for_k(c.K);
+    if (a.n_items > 4 * nx)
+        fail(NC_EUNSUPPORTED, "conv K=%d stride=%d dil=%d: input window of %d words per channel exceeds the staging registers",
+             L.K, L.stride, L.dil, a.xw);
+    a.xbuf = ((4 * nx - 1) / a.nchunk + 1) * a.xrow;   // items past n_items land in pad rows
+    a.chunk_magic = magic_div(a.nchunk, 4 * nx + 4);
+    a.stride_magic = magic_div(sx, a.nchunk * 64 + 64);
+    for (int k = 0; k < 16; ++k) {
+        const int q = k * a.dil + a.xneg;
+        a.tapoff[k] = (k < L.Ktaps) ? (sx == 1 ? q : (q % sx) * a.xwp + q / sx) : 0;
+    }
+    const size_t lds = sizeof(float) * (2 * (size_t)KB * BM + 2 * (size_t)a.xbuf + (io.alpha_in ? (size_t)a.n_cb * CB : 0));
     if (lds > 160 * 1024) fail(NC_EUNSUPPORTED, "conv tile needs %zu B of LDS", lds);
     conv_kernel_fn fn = lookup_kernel(c);
     {

@@ -1,3 +1,4 @@
-// Instantiates the implicit-GEMM convolution for taps-per-phase K=10 (reduction block of 4 input channels).
+// Instantiates the implicit-GEMM convolution for taps-per-phase K=10 (reduction block of 3 input channels,
+// up to 18 prefetched window words per lane).
 #include "nc_conv_kernel.hip.h"
-NC_INSTANTIATE_CONV_K(10, 4)
+NC_INSTANTIATE_CONV_K(10, 3, 18)

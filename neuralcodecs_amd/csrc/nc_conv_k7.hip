@@ -1,3 +1,4 @@
-// Instantiates the implicit-GEMM convolution for taps-per-phase K=7 (reduction block of 8 input channels).
+// Instantiates the implicit-GEMM convolution for taps-per-phase K=7 (reduction block of 8 input channels,
+// up to 10 prefetched window words per lane).
 #include "nc_conv_kernel.hip.h"
-NC_INSTANTIATE_CONV_K(7, 8)
+NC_INSTANTIATE_CONV_K(7, 8, 10)

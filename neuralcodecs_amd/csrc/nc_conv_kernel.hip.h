@@ -5,30 +5,57 @@
 #include "nc_conv.h"
 #include "nc_math.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace nc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int N, class F, int... I>
+__device__ __forceinline__ void nc_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+// f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{}), in order
+template <int N, class F>
+__device__ __forceinline__ void nc_static_for(F&& f) {
+    nc_static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+typedef __attribute__((address_space(1))) const void* nc_gptr;
+typedef __attribute__((address_space(3))) void* nc_lptr;
 
 // Block = 4 waves (256 threads).  Wave w owns all BM = 32*TM output channels of the tile and the
-// 32*TN columns [w*32*TN, (w+1)*32*TN).  Per reduction block of CB input channels the block stages
-//   As[kk][BM]   packed weights (linear copy from the pre-packed global image)
+// 32*TN columns [w*32*TN, (w+1)*32*TN).  The reduction runs over blocks of CB input channels
+// (KB = CB*K flattened kk = ci*K + k, ascending: the canonical chain order).  Per block the
+// workgroup holds in LDS, double-buffered,
+//   As[kk][BM]   packed weights (a linear copy of the pre-packed global image)
 //   Xs[ci][...]  the input window of the tile (Snake applied on the way in), de-interleaved by
 //                stride phase so the 32 lanes of an MFMA B-fragment always read consecutive words
-// and then issues KB/2 steps of v_mfma_f32_32x32x2_f32 per accumulator:
-//   lane l supplies A[row = l&31][kk = 2*kp + (l>>5)] and B[kk][col = l&31].
-template <int TM, int TN, int K, int CB>
+// Software pipeline, one barrier per reduction block: the KB/2 matrix-core steps of block cb are cut
+// into NSEG segments; the global loads of block cb+1 are issued in NSEG-1 groups, group g at the head
+// of segment g, and group g is transformed (Snake) and written to the other LDS buffer at the head of
+// segment g+1 -- so a load has a whole segment of MFMA time to land, only 1/(NSEG-1) of the staging
+// registers are live at once, and the VALU work sits between matrix-core segments.
+//   MFMA step kp: lane l supplies A[row = l&31][kk = 2*kp + (l>>5)] and B[kk][col = l&31].
+template <int TM, int TN, int K, int CB, int NX>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
     constexpr int BM = 32 * TM;
     constexpr int BNW = 32 * TN;
     constexpr int BN = 4 * BNW;
     constexpr int KB = CB * K;
     constexpr int KP = KB / 2;
+    constexpr int A_FLOATS = KB * BM;
+    constexpr int A_VEC = A_FLOATS / 4;            // float4 words in the weight tile
+    constexpr int NA = (A_VEC + 255) / 256;        // float4 copies per thread
+    constexpr int NSEG = KP >= 16 ? 4 : 2;
+    constexpr int NG = NSEG - 1;
+    constexpr int GA = (NA + NG - 1) / NG;         // per-group register footprint
+    constexpr int GX = (NX + NG - 1) / NG;
     static_assert(KB % 2 == 0, "reduction block must hold an even number of kk");
-    static_assert((KB * BM) % 4 == 0, "A tile must be float4-copyable");
+    static_assert(A_FLOATS % 4 == 0, "A tile must be 16-byte granular");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;
-    float* Xs = smem + KB * BM;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -57,18 +84,87 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
     const int s = p.stride;
     const int xs0 = col0 * s - p.pad - p.xneg;  // global x position of window slot 0
 
-    // per-lane LDS offsets of the B fragments: slot of (ci_local, k) for kk = 2*kp + hi
-    int xo[KP];
+    const f32x4* const wbase =
+        reinterpret_cast<const f32x4*>(p.w + (int64_t)phase * p.w_phase_stride + (int64_t)co_tile * p.n_cb * A_FLOATS);
+    const float* const xb = p.x + (int64_t)b * p.x_bstride;
+
+    float* const As0 = smem;
+    float* const Xs0 = smem + 2 * A_FLOATS;
+
+    // kernel arguments used inside the pipeline, pinned in registers
+    const int nchunk = p.nchunk, chunk_magic = p.chunk_magic, stride_magic = p.stride_magic;
+    const int xwp = p.xwp, xrow = p.xrow, xbuf = p.xbuf, Cin = p.Cin, x_len = p.x_len, n_cb = p.n_cb;
+    const unsigned x_cstride = (unsigned)p.x_cstride;
+    const float* const alpha_in = p.alpha_in;
+    int tap[K];  // window slot of tap k (wave-uniform scalars)
 #pragma unroll
-    for (int kp = 0; kp < KP; ++kp) {
-        const int kk = 2 * kp + hi;
-        const int ci = kk / K, k = kk - ci * K;
-        const int q = k * p.dil + p.xneg;
-        int o = ci * p.xrow;
-        if (s == 1) o += q;
-        else o += (q % s) * p.xwp + q / s;
-        xo[kp] = o + wave * BNW + l31;
-    }
+    for (int k = 0; k < K; ++k) tap[k] = p.tapoff[k];
+    // Snake alphas of all input channels, staged once per block behind the tile buffers
+    float* const Al = Xs0 + 2 * xbuf;
+    if (alpha_in != nullptr)
+        for (int i = tid; i < n_cb * CB; i += 256) Al[i] = alpha_in[min(i, Cin - 1)];
+    __syncthreads();
+
+    // ---- staging (branch-free; every address is clamped into the tensor) ------------------------
+    // weights: thread t copies float4 words t + 256*n; input window: wave-level items of 64 consecutive
+    // window slots of one channel, item -> wave item%4; items past n_items land in pad rows.
+    f32x4 ra[GA];
+    float rx[GX];
+    auto issue_group = [&](int cbn, auto gtag) __attribute__((always_inline)) {
+        constexpr int g = decltype(gtag)::value;
+        const f32x4* src = wbase + (size_t)cbn * A_VEC;
+        nc_static_for<GA>([&](auto ut) __attribute__((always_inline)) {
+            constexpr int u = decltype(ut)::value, n = g * GA + u;
+            if constexpr (n < NA) {
+                const unsigned idx = (unsigned)(tid + 256 * n);
+                ra[u] = src[(A_VEC % 256 == 0) ? idx : min(idx, (unsigned)(A_VEC - 1))];
+            }
+        });
+        nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
+            constexpr int u = decltype(ut)::value, i = g * GX + u;
+            if constexpr (i < NX) {
+                const int item = wave + 4 * i;
+                const int c = (item * chunk_magic) >> 20;
+                const int ci = min(cbn * CB + c, Cin - 1);
+                const int gp = xs0 + (item - c * nchunk) * 64 + lane;
+                rx[u] = xb[(unsigned)ci * x_cstride + (unsigned)min(max(gp, 0), x_len - 1)];
+            }
+        });
+    };
+    auto store_group = [&](int cbn, float* Ad, float* Xd, auto gtag, auto snake_tag) __attribute__((always_inline)) {
+        constexpr int g = decltype(gtag)::value;
+        constexpr bool SNAKE = decltype(snake_tag)::value;
+        nc_static_for<GA>([&](auto ut) __attribute__((always_inline)) {
+            constexpr int u = decltype(ut)::value, n = g * GA + u;
+            if constexpr (n < NA) {
+                const int idx = tid + 256 * n;
+                if ((A_VEC % 256 == 0) || idx < A_VEC) reinterpret_cast<f32x4*>(Ad)[idx] = ra[u];
+            }
+        });
+        nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
+            constexpr int u = decltype(ut)::value, i = g * GX + u;
+            if constexpr (i < NX) {
+                const int item = wave + 4 * i;
+                const int c = (item * chunk_magic) >> 20;
+                const int ci = cbn * CB + c;
+                const int j = (item - c * nchunk) * 64 + lane;
+                const int gp = xs0 + j;
+                const bool ok = (ci < Cin) & (gp >= 0) & (gp < x_len);  // slots past xw / items past n_items are never read
+                float v = ok ? rx[u] : 0.0f;
+                if (SNAKE) v = nc_snakef(v, Al[ci]);
+                int off = item * 64 + lane;
+                if (s != 1) {
+                    const int q = (j * stride_magic) >> 20;
+                    off = c * xrow + (j - q * s) * xwp + q;
+                }
+                Xd[off] = v;
+            }
+        });
+    };
+    auto store_group_any = [&](int cbn, float* Ad, float* Xd, auto gtag) __attribute__((always_inline)) {
+        if (alpha_in != nullptr) store_group(cbn, Ad, Xd, gtag, std::true_type{});
+        else store_group(cbn, Ad, Xd, gtag, std::false_type{});
+    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -78,49 +174,56 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const float* wbase = p.w + (int64_t)phase * p.w_phase_stride + (int64_t)co_tile * p.n_cb * (KB * BM);
-    const float* xb = p.x + (int64_t)b * p.x_bstride;
+    // ---- prologue: stage reduction block 0
+    nc_static_for<NG>([&](auto g) __attribute__((always_inline)) {
+        issue_group(0, g);
+        store_group_any(0, As0, Xs0, g);
+    });
+    __syncthreads();
 
-    for (int cb = 0; cb < p.n_cb; ++cb) {
-        __syncthreads();
-        // ---- stage weights (linear, 16 B per lane)
-        {
-            const float4* ag = reinterpret_cast<const float4*>(wbase + (int64_t)cb * (KB * BM));
-            float4* as4 = reinterpret_cast<float4*>(As);
+    const int a_lane = hi * BM + l31;
+    const int x_lane = wave * BNW + l31;
+
+    float fa[2][TM], fb[2][TN];
+    auto load_frag = [&](const float* Ac, const float* Xc, auto kp_tag) __attribute__((always_inline)) {
+        constexpr int kp = decltype(kp_tag)::value;
+        constexpr int c0 = (2 * kp) / K, k0 = (2 * kp) % K, c1 = (2 * kp + 1) / K, k1 = (2 * kp + 1) % K;
+        const int o0 = c0 * xrow + tap[k0], o1 = c1 * xrow + tap[k1];
+        const int o = hi ? o1 : o0;
 #pragma unroll
-            for (int i = tid; i < KB * BM / 4; i += 256) as4[i] = ag[i];
-        }
-        // ---- stage the input window (zero outside the clip, Snake fused)
-#pragma unroll 1
-        for (int c = 0; c < CB; ++c) {
-            const int ci = cb * CB + c;
-            const bool cok = ci < p.Cin;
-            const float* xr = xb + (int64_t)ci * p.x_cstride;
-            const float al = (p.alpha_in != nullptr && cok) ? p.alpha_in[ci] : 0.0f;
-            float* xd = Xs + c * p.xrow;
-            for (int j = tid; j < p.xw; j += 256) {
-                const int gp = xs0 + j;
-                float v = 0.0f;
-                if (cok && gp >= 0 && gp < p.x_len) v = xr[gp];
-                if (p.alpha_in != nullptr) v = nc_snakef(v, al);
-                const int slot = (s == 1) ? j : (j % s) * p.xwp + j / s;
-                xd[slot] = v;
+        for (int i = 0; i < TM; ++i) fa[kp & 1][i] = Ac[2 * kp * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[kp & 1][j] = Xc[o + j * 32];
+    };
+
+    for (int cb = 0; cb < n_cb; ++cb) {
+        const int cur = cb & 1;
+        const float* Ac = As0 + cur * A_FLOATS + a_lane;
+        const float* Xc = Xs0 + cur * xbuf + x_lane;
+        float* const An = As0 + (cur ^ 1) * A_FLOATS;
+        float* const Xn = Xs0 + (cur ^ 1) * xbuf;
+        const bool more = cb + 1 < n_cb;
+        nc_static_for<NSEG>([&](auto seg_tag) __attribute__((always_inline)) {
+            constexpr int seg = decltype(seg_tag)::value;
+            if (more) {
+                if constexpr (seg >= 1) store_group_any(cb + 1, An, Xn, std::integral_constant<int, (seg >= 1 ? seg - 1 : 0)>{});
+                if constexpr (seg < NG) issue_group(cb + 1, seg_tag);
             }
-        }
+            // ---- matrix-core steps of this segment, ascending kk; fragments of step kp+1 are read before
+            //      the MFMAs of step kp are issued (register double buffer fa/fb)
+            constexpr int kp_lo = seg * KP / NSEG, kp_hi = (seg + 1) * KP / NSEG;
+            if constexpr (seg == 0) load_frag(Ac, Xc, std::integral_constant<int, 0>{});
+            nc_static_for<kp_hi - kp_lo>([&](auto d) __attribute__((always_inline)) {
+                constexpr int kp = kp_lo + decltype(d)::value;
+                if constexpr (kp + 1 < KP) load_frag(Ac, Xc, std::integral_constant<int, kp + 1>{});
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp & 1][i], fb[kp & 1][j], acc[i][j], 0, 0, 0);
+            });
+        });
         __syncthreads();
-        // ---- matrix-core steps, ascending kk
-#pragma unroll
-        for (int kp = 0; kp < KP; ++kp) {
-            float a[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[(2 * kp + hi) * BM + i * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = Xs[xo[kp] + j * 32];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[j], acc[i][j], 0, 0, 0);
-        }
     }
 
     // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*hi][col = l31]
@@ -157,27 +260,29 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
 
 typedef void (*conv_kernel_fn)(const ConvArgs);
 
-template <int TM, int TN, int K, int CB>
+template <int TM, int TN, int K, int CB, int NX>
 inline conv_kernel_fn get_conv_kernel() {
-    return &conv_mfma_kernel<TM, TN, K, CB>;
+    return &conv_mfma_kernel<TM, TN, K, CB, NX>;
 }
 
 }  // namespace nc
 
 // Instantiation helper: one translation unit per K registers its 8 (TM,TN) variants.
-#define NC_INSTANTIATE_CONV_K(KVAL, CBVAL)                                                                 \
+#define NC_INSTANTIATE_CONV_K(KVAL, CBVAL, NXVAL)                                                          \
     namespace nc {                                                                                         \
     conv_kernel_fn conv_kernel_table_k##KVAL(int TM, int TN) {                                             \
         switch (TM * 10 + TN) {                                                                            \
-            case 11: return get_conv_kernel<1, 1, KVAL, CBVAL>();                                          \
-            case 12: return get_conv_kernel<1, 2, KVAL, CBVAL>();                                          \
-            case 21: return get_conv_kernel<2, 1, KVAL, CBVAL>();                                          \
-            case 22: return get_conv_kernel<2, 2, KVAL, CBVAL>();                                          \
-            case 31: return get_conv_kernel<3, 1, KVAL, CBVAL>();                                          \
-            case 32: return get_conv_kernel<3, 2, KVAL, CBVAL>();                                          \
-            case 41: return get_conv_kernel<4, 1, KVAL, CBVAL>();                                          \
-            case 42: return get_conv_kernel<4, 2, KVAL, CBVAL>();                                          \
+            case 11: return get_conv_kernel<1, 1, KVAL, CBVAL, NXVAL>();                                   \
+            case 12: return get_conv_kernel<1, 2, KVAL, CBVAL, NXVAL>();                                   \
+            case 21: return get_conv_kernel<2, 1, KVAL, CBVAL, NXVAL>();                                   \
+            case 22: return get_conv_kernel<2, 2, KVAL, CBVAL, NXVAL>();                                   \
+            case 31: return get_conv_kernel<3, 1, KVAL, CBVAL, NXVAL>();                                   \
+            case 32: return get_conv_kernel<3, 2, KVAL, CBVAL, NXVAL>();                                   \
+            case 41: return get_conv_kernel<4, 1, KVAL, CBVAL, NXVAL>();                                   \
+            case 42: return get_conv_kernel<4, 2, KVAL, CBVAL, NXVAL>();                                   \
         }                                                                                                  \
         return nullptr;                                                                                    \
     }                                                                                                      \
+    int conv_kernel_cb_k##KVAL() { return CBVAL; }                                                         \
+    int conv_kernel_nx_k##KVAL() { return NXVAL; }                                                         \
     }

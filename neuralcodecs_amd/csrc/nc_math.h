@@ -74,7 +74,7 @@ NC_HD float nc_tanhf(float x) {
 
 // Snake1d.cs:52  where(alpha == 0, x, addcdiv(x, sin(alpha*x)^2, alpha, 1))
 NC_HD float nc_snakef(float x, float alpha) {
-    if (alpha == 0.0f) return x;
     float s = nc_sinf(alpha * x);
-    return x + (s * s) / alpha;
+    float r = x + (s * s) / alpha;   // alpha == 0: inf/NaN here, discarded by the select (branch-free on the GPU)
+    return alpha == 0.0f ? x : r;
 }
