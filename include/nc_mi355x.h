@@ -151,6 +151,12 @@ NC_API nc_status nc_op_conv1d(int device_index, const nc_conv_desc* d, const flo
 /* Timing hook over the same launch path: runs the convolution `iters` times on device-resident seeded random data
  * (fuse bit0: Snake on input, bit1: Snake on output, bit2: residual add) and returns the HIP-event average per launch. */
 NC_API nc_status nc_op_conv1d_bench(int device_index, const nc_conv_desc* d, int32_t fuse, int32_t iters, double* avg_ms);
+/* One DAC ResidualUnit (ResidualUnit.cs:24-59): y = x + conv1(snake_a2(conv7_dil(snake_a1(x)))) on x [B,C,T].
+ * Dense weights w7 [C,C,7], w1 [C,C,1].  fused != 0 requests the single-launch kernel (NC_EUNSUPPORTED when the shape has
+ * none); iters > 0 additionally times `iters` repetitions with HIP events into *avg_ms (nullable when iters == 0). */
+NC_API nc_status nc_op_res_unit(int device_index, int32_t B, int32_t C, int64_t T, int32_t dil, const float* x, const float* w7,
+                                const float* b7, const float* a1, const float* a2, const float* w1, const float* b1,
+                                int32_t fused, float* y, int32_t iters, double* avg_ms);
 /* one VQ stage on projected latents z_e [B,D,T] against codebook [N,D] -> idx [B,T], st [B,D,T] */
 NC_API nc_status nc_op_vq_argmin(int device_index, const float* z_e, int32_t B, int32_t D, int64_t T, const float* codebook,
                                  int32_t N, int64_t* idx, float* st);

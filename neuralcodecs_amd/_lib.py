@@ -67,6 +67,8 @@ SYMBOLS = [
     ("nc_codec_profile_read", C.c_int, [_P, C.POINTER(NcProfileEntry)]),
     ("nc_op_conv1d", C.c_int, [C.c_int, C.POINTER(NcConvDesc), _P, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_int64)]),
     ("nc_op_conv1d_bench", C.c_int, [C.c_int, C.POINTER(NcConvDesc), C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
+    ("nc_op_res_unit", C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P,
+                                 C.c_int32, C.POINTER(C.c_double)]),
     ("nc_op_vq_argmin", C.c_int, [C.c_int, _P, C.c_int32, C.c_int32, C.c_int64, _P, C.c_int32, _P, _P]),
     ("nc_op_fold_weight_norm", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
 ]

@@ -316,6 +316,60 @@ nc_status nc_op_conv1d_bench(int device_index, const nc_conv_desc* d, int32_t fu
     });
 }
 
+nc_status nc_op_res_unit(int device_index, int32_t B, int32_t C, int64_t T, int32_t dil, const float* x, const float* w7,
+                         const float* b7, const float* a1, const float* a2, const float* w1, const float* b1, int32_t fused,
+                         float* y, int32_t iters, double* avg_ms) {
+    return guard([&] {
+        if (!x || !w7 || !b7 || !a1 || !a2 || !w1 || !b1 || !y) fail(NC_EINVAL, "null argument");
+        if (B <= 0 || C <= 0 || T <= 0 || dil <= 0 || iters < 0 || (iters > 0 && !avg_ms)) fail(NC_EINVAL, "bad arguments");
+        op_set_device(device_index);
+        ConvLayer c7, c1;
+        c7.build(w7, b7, C, C, 7, 1, 3 * dil, dil, 0, false);
+        c1.build(w1, b1, C, C, 1, 1, 0, 1, 0, false);
+        if (fused && !can_fuse_res_unit(c7, c1)) fail(NC_EUNSUPPORTED, "no fused residual-unit kernel for %d channels", C);
+        const size_t n = (size_t)B * C * T * 4;
+        DevBuf dx, dh, dy, d1, d2;
+        dx.reserve(n); dh.reserve(n); dy.reserve(n); d1.reserve(C * 4); d2.reserve(C * 4);
+        NC_HIP(hipMemcpy(dx.p, x, n, hipMemcpyHostToDevice));
+        NC_HIP(hipMemcpy(d1.p, a1, C * 4, hipMemcpyHostToDevice));
+        NC_HIP(hipMemcpy(d2.p, a2, C * 4, hipMemcpyHostToDevice));
+        auto run = [&]() {
+            ConvIO io{};
+            io.x = dx.as<float>(); io.x_bstride = (int64_t)C * T; io.x_cstride = T; io.x_len = (int32_t)T; io.Tin = T;
+            io.alpha_in = d1.as<float>(); io.alpha_out = d2.as<float>();
+            io.y_bstride = (int64_t)C * T; io.y_cstride = T;
+            if (fused) {
+                io.res = dx.as<float>(); io.fuse_k1 = &c1; io.y = dy.as<float>();
+                launch_conv(c7, io, B, nullptr, nullptr);
+            } else {
+                io.y = dh.as<float>();
+                launch_conv(c7, io, B, nullptr, nullptr);
+                ConvIO i2{};
+                i2.x = dh.as<float>(); i2.x_bstride = (int64_t)C * T; i2.x_cstride = T; i2.x_len = (int32_t)T; i2.Tin = T;
+                i2.res = dx.as<float>(); i2.y = dy.as<float>(); i2.y_bstride = (int64_t)C * T; i2.y_cstride = T;
+                launch_conv(c1, i2, B, nullptr, nullptr);
+            }
+        };
+        run();
+        NC_HIP(hipDeviceSynchronize());
+        NC_HIP(hipMemcpy(y, dy.p, n, hipMemcpyDeviceToHost));
+        if (iters > 0) {
+            hipEvent_t e0, e1;
+            NC_HIP(hipEventCreate(&e0)); NC_HIP(hipEventCreate(&e1));
+            NC_HIP(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < iters; ++i) run();
+            NC_HIP(hipEventRecord(e1, nullptr));
+            NC_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            NC_HIP(hipEventElapsedTime(&ms, e0, e1));
+            *avg_ms = (double)ms / iters;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        }
+        dx.release(); dh.release(); dy.release(); d1.release(); d2.release();
+        c7.w.release(); c7.bias.release(); c1.w.release(); c1.bias.release(); c1.w_fused.release();
+    });
+}
+
 nc_status nc_op_vq_argmin(int device_index, const float* z_e, int32_t B, int32_t D, int64_t T, const float* codebook, int32_t N,
                           int64_t* idx, float* st) {
     return guard([&] {

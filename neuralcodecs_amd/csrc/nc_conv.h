@@ -35,6 +35,8 @@ struct ConvArgs {
     int64_t y_bstride, y_cstride;  // elements
     int32_t y_tstride, y_toff;     // t_out = col*y_tstride + y_toff + phase
     int32_t Tout;                  // stores outside [0,Tout) are dropped
+    const float* w2;               // fused residual unit: packed 1x1 weights [row block][ci][32], bias2 [Cout]
+    const float* bias2;
     float* rvq_zq;                 // EPI_RVQ: zq += out ; rvq_res -= out  (same geometry as y)
     float* rvq_res;
     int32_t Cout, n_cols;          // columns (output steps per phase) handled by this launch
@@ -63,6 +65,7 @@ struct ConvLayer {
     TileCfg cfg{};
     int n_phase = 1, Ktaps = 0;  // taps per phase (== K for conv, ceil(K/stride) for conv-transpose)
     DevBuf w, bias;
+    DevBuf w_fused;  // K==1, Cin==Cout<=128: [row block][ci][32 rows] image consumed by the fused residual-unit kernel
     bool has_bias = false;
     int64_t w_phase_stride = 0;
     int kclass = NC_KC_CONV_MISC;
@@ -86,9 +89,12 @@ struct ConvIO {
     float* rvq_zq = nullptr;
     float* rvq_res = nullptr;
     int epi = 0;
+    const struct ConvLayer* fuse_k1 = nullptr;  // fused residual unit: the 1x1 layer applied to snake(alpha_out)(this conv) + res
 };
 
-TileCfg pick_tile(int Cout, int Ktaps);  // TN is chosen per launch from the column count
+TileCfg pick_tile(int Cout, int Ktaps);
+// true when `k7` followed by `k1` can run as one fused residual-unit launch
+bool can_fuse_res_unit(const ConvLayer& k7, const ConvLayer& k1);  // TN is chosen per launch from the column count
 void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream, Profiler* prof);
 
 }  // namespace nc

@@ -38,6 +38,8 @@ int conv_kernel_nx_k16();
 
 #define NC_K_CASES(X) X(1) X(2) X(3) X(4) X(6) X(7) X(8) X(10) X(16)
 
+conv_kernel_fn conv_kernel_table_fused_k7(int, int);
+
 static int cb_for_k(int K) {
     switch (K) {
 #define X(k) case k: return conv_kernel_cb_k##k();
@@ -145,11 +147,26 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
             }
     w.reserve(packed.size() * sizeof(float));
     NC_HIP(hipMemcpy(w.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!transposed && K == 1 && Cin == Cout && Cin % 32 == 0 && Cin <= 128) {
+        // image for the fused residual-unit tail: [row block][ci][32 rows]
+        std::vector<float> f((size_t)Cin * Cout);
+        for (int i2 = 0; i2 < Cout / 32; ++i2)
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int rr = 0; rr < 32; ++rr) f[((size_t)i2 * Cin + ci) * 32 + rr] = dense_w[(size_t)(i2 * 32 + rr) * Cin + ci];
+        w_fused.reserve(f.size() * sizeof(float));
+        NC_HIP(hipMemcpy(w_fused.p, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     has_bias = bias_h != nullptr;
     if (has_bias) {
         bias.reserve(sizeof(float) * Cout);
         NC_HIP(hipMemcpy(bias.p, bias_h, sizeof(float) * Cout, hipMemcpyHostToDevice));
     }
+}
+
+bool can_fuse_res_unit(const ConvLayer& k7, const ConvLayer& k1) {
+    return !k7.transposed && k7.K == 7 && k7.stride == 1 && k7.Cin == k7.Cout && k7.Cout % 32 == 0 && k7.Cout >= 64 && k7.Cout <= 128 &&
+           k7.cfg.BM() == k7.Cout && k1.K == 1 && k1.Cin == k7.Cout && k1.Cout == k7.Cout && k1.w_fused.p != nullptr &&
+           k7.has_bias && k1.has_bias;
 }
 
 static std::mutex g_attr_mu;
@@ -209,9 +226,20 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         const int q = k * a.dil + a.xneg;
         a.tapoff[k] = (k < L.Ktaps) ? (sx == 1 ? q : (q % sx) * a.xwp + q / sx) : 0;
     }
-    const size_t lds = sizeof(float) * (2 * (size_t)KB * BM + 2 * (size_t)a.xbuf + (io.alpha_in ? (size_t)a.n_cb * CB : 0));
+    size_t lds = sizeof(float) * (2 * (size_t)KB * BM + 2 * (size_t)a.xbuf + (io.alpha_in ? (size_t)a.n_cb * CB : 0));
+    conv_kernel_fn fn = nullptr;
+    if (io.fuse_k1) {
+        if (!can_fuse_res_unit(L, *io.fuse_k1) || !io.alpha_out || !io.res || io.epi != 0)
+            fail(NC_ESTATE, "internal: residual unit is not fusable");
+        a.w2 = io.fuse_k1->w_fused.as<float>();
+        a.bias2 = io.fuse_k1->bias.as<float>();
+        lds = std::max(lds, sizeof(float) * (size_t)BM * BM);
+        fn = conv_kernel_table_fused_k7(c.TM, c.TN);
+        if (!fn) fail(NC_EUNSUPPORTED, "no fused residual-unit kernel for TM=%d TN=%d", c.TM, c.TN);
+    } else {
+        fn = lookup_kernel(c);
+    }
     if (lds > 160 * 1024) fail(NC_EUNSUPPORTED, "conv tile needs %zu B of LDS", lds);
-    conv_kernel_fn fn = lookup_kernel(c);
     {
         std::lock_guard<std::mutex> g(g_attr_mu);
         if (!g_attr_done.count((const void*)fn)) {
@@ -223,7 +251,9 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     if (grid <= 0) return;
     if (prof && prof->on) {
         const double bytes = 4.0 * ((double)B * L.Cin * io.Tin + (double)B * L.Cout * Tout + (double)L.Cin * L.Cout * L.K);
-        prof->begin(stream, L.kclass, L.flops(B, io.Tin), bytes);
+        double fl = L.flops(B, io.Tin);
+        if (io.fuse_k1) fl += io.fuse_k1->flops(B, io.Tin);
+        prof->begin(stream, L.kclass, fl, bytes);
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, stream, a);
     NC_HIP(hipGetLastError());

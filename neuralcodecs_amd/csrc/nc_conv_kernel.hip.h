@@ -38,7 +38,7 @@ typedef __attribute__((address_space(3))) void* nc_lptr;
 // segment g+1 -- so a load has a whole segment of MFMA time to land, only 1/(NSEG-1) of the staging
 // registers are live at once, and the VALU work sits between matrix-core segments.
 //   MFMA step kp: lane l supplies A[row = l&31][kk = 2*kp + (l>>5)] and B[kk][col = l&31].
-template <int TM, int TN, int K, int CB, int NX>
+template <int TM, int TN, int K, int CB, int NX, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
     constexpr int BM = 32 * TM;
     constexpr int BNW = 32 * TN;
@@ -228,41 +228,104 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
 
     // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*hi][col = l31]
     const int64_t ybase = (int64_t)b * p.y_bstride;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    // store one 32-row block `ib` of the tile: v[j][r] + bias (+ residual) (Snake) (tanh) -> y / RVQ accumulate
+    auto emit_rows = [&](int ib, const f32x16 (&v)[TN], const float* bias_p, const float* ao_p, const float* res_p) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int row = ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
             const int co = co_tile * BM + row;
             if (co >= p.Cout) continue;
-            const float bias = p.bias ? p.bias[co] : 0.0f;
-            const float ao = p.alpha_out ? p.alpha_out[co] : 0.0f;
+            const float bias = bias_p ? bias_p[co] : 0.0f;
+            const float ao = ao_p ? ao_p[co] : 0.0f;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = col0 + wave * BNW + j * 32 + l31;
                 const int t = col * p.y_tstride + p.y_toff + phase;
                 if (col >= p.n_cols || t < 0 || t >= p.Tout) continue;
                 const int64_t o = ybase + (int64_t)co * p.y_cstride + t;
-                float v = acc[i][j][r] + bias;
-                if (p.res) v = v + p.res[o];
-                if (p.alpha_out) v = nc_snakef(v, ao);
-                if (p.epi & EPI_TANH) v = nc_tanhf(v);
+                float val = v[j][r] + bias;
+                if (res_p) val = val + res_p[o];
+                if (ao_p) val = nc_snakef(val, ao);
+                if (p.epi & EPI_TANH) val = nc_tanhf(val);
                 if (p.epi & EPI_RVQ) {
-                    p.rvq_zq[o] = p.rvq_zq[o] + v;
-                    if (p.rvq_res) p.rvq_res[o] = p.rvq_res[o] - v;
+                    p.rvq_zq[o] = p.rvq_zq[o] + val;
+                    if (p.rvq_res) p.rvq_res[o] = p.rvq_res[o] - val;
                 } else {
-                    p.y[o] = v;
+                    p.y[o] = val;
                 }
             }
         }
+    };
+
+    if constexpr (!FUSE) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) emit_rows(i, acc[i], p.bias, p.alpha_out, p.res);
+    } else {
+        // ---- fused ResidualUnit tail (ResidualUnit.cs:29-34,50-59): this block holds ALL channels of
+        //      h_pre = conv7(snake(x)) for its columns (n_co_tiles == 1, Cin == Cout == BM), so
+        //          y = x + W1 . snake_a2(h_pre + b7) + b1
+        //      is finished here: the activation never leaves the registers.  The 1x1 contraction runs on the
+        //      matrix cores with B fragments taken from the accumulators: v_permlane32_swap turns the pair of
+        //      D registers holding rows (2m, 2m+1) of one lane half into the B operands of k-steps m and m+2.
+        static_assert(!FUSE || K == 7, "the fused tail belongs to the k=7 residual-unit convolution");
+        // 1) h = snake(h_pre + b7, a2), in place
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float bias = p.bias[row], ao = p.alpha_out[row];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j][r] = nc_snakef(acc[i][j][r] + bias, ao);
+            }
+        // 2) accumulator layout -> B-operand layout, in place
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int qe = 0; qe < 8; ++qe) {
+                    const int r0 = 4 * (qe >> 1) + 2 * (qe & 1);
+                    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][r0]), __float_as_uint(acc[i][j][r0 + 1]),
+                                                               false, false);
+                    acc[i][j][r0] = __uint_as_float(sw[0]);      // rows (2m, 2m+1) of the low half : k-step m = 4q+e
+                    acc[i][j][r0 + 1] = __uint_as_float(sw[1]);  // rows of the high half           : k-step m+2
+                }
+        // 3) W1 (packed [row block][ci][32 rows]) -> LDS; the main loop's last barrier freed the tile buffers
+        {
+            const f32x4* w2 = reinterpret_cast<const f32x4*>(p.w2);
+            f32x4* dst = reinterpret_cast<f32x4*>(smem);
+#pragma unroll 4
+            for (int idx = tid; idx < BM * BM / 4; idx += 256) dst[idx] = w2[idx];
+        }
+        __syncthreads();
+        // 4) y = W1 . h + b1 + x, one 32-row block at a time (ascending ci chain, like the stand-alone 1x1 kernel)
+        nc_static_for<TM>([&](auto i2t) __attribute__((always_inline)) {
+            constexpr int i2 = decltype(i2t)::value;
+            f32x16 acc2[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[j][r] = 0.0f;
+            const float* W1s = smem + i2 * BM * 32 + hi * 32 + l31;
+            nc_static_for<BM / 2>([&](auto kpt) __attribute__((always_inline)) {
+                constexpr int kp = decltype(kpt)::value;
+                constexpr int i = kp / 16, m = kp % 16;
+                constexpr int reg = 4 * (m >> 2) + 2 * (m & 1) + ((m >> 1) & 1);
+                const float a = W1s[2 * kp * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[i][j][reg], acc2[j], 0, 0, 0);
+            });
+            emit_rows(i2, acc2, p.bias2, nullptr, p.res);
+        });
     }
 }
 
 typedef void (*conv_kernel_fn)(const ConvArgs);
 
-template <int TM, int TN, int K, int CB, int NX>
+template <int TM, int TN, int K, int CB, int NX, bool FUSE = false>
 inline conv_kernel_fn get_conv_kernel() {
-    return &conv_mfma_kernel<TM, TN, K, CB, NX>;
+    return &conv_mfma_kernel<TM, TN, K, CB, NX, FUSE>;
 }
 
 }  // namespace nc
@@ -285,4 +348,20 @@ inline conv_kernel_fn get_conv_kernel() {
     }                                                                                                      \
     int conv_kernel_cb_k##KVAL() { return CBVAL; }                                                         \
     int conv_kernel_nx_k##KVAL() { return NXVAL; }                                                         \
+    }
+
+// Fused residual-unit variants (k=7 conv + Snake + 1x1 conv + skip in one launch): Cin == Cout == 32*TM.
+#define NC_INSTANTIATE_CONV_FUSED(KVAL, CBVAL, NXVAL)                                                      \
+    namespace nc {                                                                                         \
+    conv_kernel_fn conv_kernel_table_fused_k##KVAL(int TM, int TN) {                                       \
+        switch (TM * 10 + TN) {                                                                            \
+            case 21: return get_conv_kernel<2, 1, KVAL, CBVAL, NXVAL, true>();                             \
+            case 22: return get_conv_kernel<2, 2, KVAL, CBVAL, NXVAL, true>();                             \
+            case 31: return get_conv_kernel<3, 1, KVAL, CBVAL, NXVAL, true>();                             \
+            case 32: return get_conv_kernel<3, 2, KVAL, CBVAL, NXVAL, true>();                             \
+            case 41: return get_conv_kernel<4, 1, KVAL, CBVAL, NXVAL, true>();                             \
+            case 42: return get_conv_kernel<4, 2, KVAL, CBVAL, NXVAL, true>();                             \
+        }                                                                                                  \
+        return nullptr;                                                                                    \
+    }                                                                                                      \
     }

@@ -8,6 +8,8 @@
 //   launch 1: conv k7 dil d   [Snake(a1) on the input tile | bias | Snake(a2) on the store]
 //   launch 2: conv k1         [bias | + x residual]
 // so no activation makes an HBM round trip of its own.
+#include <cstdlib>
+
 #include "nc_model.h"
 
 namespace nc {
@@ -75,6 +77,7 @@ DacModel::DacModel(const nc_dac_config& c) : cfg(c) {
         if (c.decoder_rates[i] <= 0) fail(NC_EINVAL, "decoder rate must be positive");
     if ((c.decoder_dim >> c.n_decoder_rates) <= 0) fail(NC_EINVAL, "decoder_dim too small for the number of decoder blocks");
     latent = c.latent_dim > 0 ? c.latent_dim : c.encoder_dim * (1 << c.n_encoder_rates);  // DAC.cs:64
+    if (const char* e = std::getenv("NC_NO_FUSE")) fuse_res_units = !(e[0] == '1');
     cfg.latent_dim = latent;
 }
 
@@ -167,6 +170,14 @@ float* DacModel::run_res_unit(ResUnit& ru, int dil, float* cur, int C, int64_t L
     ConvIO io{};
     io.x = cur; io.x_bstride = (int64_t)C * L; io.x_cstride = L; io.x_len = (int32_t)L; io.Tin = L;
     io.alpha_in = ru.a1.as<float>(); io.alpha_out = ru.a2.as<float>();
+    if (fuse_res_units && can_fuse_res_unit(ru.c7, ru.c1)) {
+        // one launch: y = x + W1.snake(conv7(snake(x)) + b7) + b1 ; h never reaches HBM
+        io.res = cur; io.fuse_k1 = &ru.c1;
+        io.y = o; io.y_bstride = (int64_t)C * L; io.y_cstride = L;
+        launch_conv(ru.c7, io, B, stream, &prof);
+        cur_idx = o_idx;
+        return o;
+    }
     io.y = h; io.y_bstride = (int64_t)C * L; io.y_cstride = L;
     launch_conv(ru.c7, io, B, stream, &prof);
     ConvIO i2{};

@@ -42,6 +42,7 @@ struct Codec {
 struct DacModel : Codec {
     nc_dac_config cfg{};
     int latent = 0, hop = 1;
+    bool fuse_res_units = true;  // NC_NO_FUSE=1 in the environment selects the two-launch residual units (A/B, tests)
 
     struct ResUnit {
         DevBuf a1, a2;

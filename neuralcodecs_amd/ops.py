@@ -33,6 +33,19 @@ def conv1d(x, weight, bias=None, stride=1, pad=0, dil=1, alpha_in=None, alpha_ou
     return y
 
 
+def res_unit(x, w7, b7, a1, a2, w1, b1, dil=1, fused=True, iters=0, device_index=0):
+    """One DAC ResidualUnit; returns y (and the average ms per repetition when iters > 0)."""
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    x, w7, b7, a1, a2, w1, b1 = map(f, (x, w7, b7, a1, a2, w1, b1))
+    B, Cc, T = x.shape
+    y = np.empty_like(x)
+    ms = C.c_double()
+    _lib.check(_lib.lib().nc_op_res_unit(device_index, B, Cc, T, dil, x.ctypes.data, w7.ctypes.data, b7.ctypes.data, a1.ctypes.data,
+                                         a2.ctypes.data, w1.ctypes.data, b1.ctypes.data, 1 if fused else 0, y.ctypes.data, iters,
+                                         C.byref(ms)))
+    return (y, ms.value) if iters > 0 else y
+
+
 def vq_argmin(z_e, codebook, device_index=0):
     z = np.ascontiguousarray(z_e, np.float32); cb = np.ascontiguousarray(codebook, np.float32)
     B, D, T = z.shape

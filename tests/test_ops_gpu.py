@@ -65,6 +65,22 @@ def test_conv1d_fused_snake_residual_bit_exact():
     assert np.array_equal(y, y_ref)
 
 
+@pytest.mark.parametrize("C,T,d,B", [(64, 700, 1, 2), (96, 523, 3, 1), (128, 300, 9, 2), (64, 40, 9, 1)])
+def test_fused_res_unit_bit_exact(C, T, d, B):
+    """Single-launch ResidualUnit (conv7 + Snake + 1x1 on the accumulators + skip) == oracle == two-launch path."""
+    rng = np.random.default_rng(C + d)
+    x = _rand(rng, B, C, T, scale=1.5)
+    a1, a2 = _alpha(rng, C), _alpha(rng, C)
+    w7 = _rand(rng, C, C, 7, scale=1.0 / np.sqrt(C * 7)); b7 = _rand(rng, C, scale=0.1)
+    w1 = _rand(rng, C, C, 1, scale=1.0 / np.sqrt(C)); b1 = _rand(rng, C, scale=0.1)
+    h_ref = c_oracle.snake(c_oracle.conv1d(c_oracle.snake(x, a1), w7, b7, 1, 3 * d, d), a2)
+    y_ref = c_oracle.conv1d(h_ref, w1, b1, residual=x)
+    y_f = ops.res_unit(x, w7, b7, a1, a2, w1, b1, dil=d, fused=True)
+    y_u = ops.res_unit(x, w7, b7, a1, a2, w1, b1, dil=d, fused=False)
+    assert np.array_equal(y_u, y_ref)
+    assert np.array_equal(y_f, y_ref), f"max abs diff {np.abs(y_f - y_ref).max()}"
+
+
 def test_conv1d_tanh_head_bit_exact():
     rng = np.random.default_rng(6)
     x = _rand(rng, 2, 96, 1000, scale=2.0)
