@@ -219,14 +219,14 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     if (a.n_items > 4 * nx)
         fail(NC_EUNSUPPORTED, "conv K=%d stride=%d dil=%d: input window of %d words per channel exceeds the staging registers",
              L.K, L.stride, L.dil, a.xw);
-    a.xbuf = ((4 * nx - 1) / a.nchunk + 1) * a.xrow;   // items past n_items land in pad rows
+    a.xbuf = (((4 * nx - 1) / a.nchunk + 1) * a.xrow + 3) & ~3;   // items past n_items land in pad rows
     a.chunk_magic = magic_div(a.nchunk, 4 * nx + 4);
     a.stride_magic = magic_div(sx, a.nchunk * 64 + 64);
     for (int k = 0; k < 16; ++k) {
         const int q = k * a.dil + a.xneg;
         a.tapoff[k] = (k < L.Ktaps) ? (sx == 1 ? q : (q % sx) * a.xwp + q / sx) : 0;
     }
-    size_t lds = sizeof(float) * (2 * (size_t)KB * BM + 2 * (size_t)a.xbuf + (io.alpha_in ? (size_t)a.n_cb * CB : 0));
+    size_t lds = sizeof(float) * (2 * (size_t)KB * BM + 2 * (size_t)a.xbuf + (io.alpha_in ? 2 * (size_t)a.n_cb * CB : 0));
     conv_kernel_fn fn = nullptr;
     if (io.fuse_k1) {
         if (!can_fuse_res_unit(L, *io.fuse_k1) || !io.alpha_out || !io.res || io.epi != 0)

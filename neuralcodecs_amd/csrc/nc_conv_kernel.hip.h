@@ -100,9 +100,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
 #pragma unroll
     for (int k = 0; k < K; ++k) tap[k] = p.tapoff[k];
     // Snake alphas of all input channels, staged once per block behind the tile buffers
-    float* const Al = Xs0 + 2 * xbuf;
+    float2* const Al = reinterpret_cast<float2*>(Xs0 + 2 * xbuf);   // (alpha, 1/alpha) per input channel
     if (alpha_in != nullptr)
-        for (int i = tid; i < n_cb * CB; i += 256) Al[i] = alpha_in[min(i, Cin - 1)];
+        for (int i = tid; i < n_cb * CB; i += 256) {
+            const float al = alpha_in[min(i, Cin - 1)];
+            Al[i] = make_float2(al, nc_snake_inv(al));
+        }
     __syncthreads();
 
     // ---- staging (branch-free; every address is clamped into the tensor) ------------------------
@@ -141,6 +144,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
                 if ((A_VEC % 256 == 0) || idx < A_VEC) reinterpret_cast<f32x4*>(Ad)[idx] = ra[u];
             }
         });
+        float2 al[GX];
+        if (SNAKE) {
+            nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
+                constexpr int u = decltype(ut)::value, i = g * GX + u;
+                if constexpr (i < NX) {
+                    const int item = wave + 4 * i;
+                    al[u] = Al[cbn * CB + ((item * chunk_magic) >> 20)];
+                }
+            });
+        }
+        float v[GX];
+        int off[GX];
         nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value, i = g * GX + u;
             if constexpr (i < NX) {
@@ -150,15 +165,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
                 const int j = (item - c * nchunk) * 64 + lane;
                 const int gp = xs0 + j;
                 const bool ok = (ci < Cin) & (gp >= 0) & (gp < x_len);  // slots past xw / items past n_items are never read
-                float v = ok ? rx[u] : 0.0f;
-                if (SNAKE) v = nc_snakef(v, Al[ci]);
-                int off = item * 64 + lane;
+                v[u] = ok ? rx[u] : 0.0f;
+                if (SNAKE) v[u] = nc_snakef(v[u], al[u].x, al[u].y);
+                off[u] = item * 64 + lane;
                 if (s != 1) {
                     const int q = (j * stride_magic) >> 20;
-                    off = c * xrow + (j - q * s) * xwp + q;
+                    off[u] = c * xrow + (j - q * s) * xwp + q;
                 }
-                Xd[off] = v;
             }
+        });
+        nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
+            constexpr int u = decltype(ut)::value, i = g * GX + u;
+            if constexpr (i < NX) Xd[off[u]] = v[u];
         });
     };
     auto store_group_any = [&](int cbn, float* Ad, float* Xd, auto gtag) __attribute__((always_inline)) {
@@ -205,17 +223,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         const bool more = cb + 1 < n_cb;
         nc_static_for<NSEG>([&](auto seg_tag) __attribute__((always_inline)) {
             constexpr int seg = decltype(seg_tag)::value;
+#if !defined(NC_ABL_NOSTAGE)
             if (more) {
                 if constexpr (seg >= 1) store_group_any(cb + 1, An, Xn, std::integral_constant<int, (seg >= 1 ? seg - 1 : 0)>{});
                 if constexpr (seg < NG) issue_group(cb + 1, seg_tag);
             }
+#endif
             // ---- matrix-core steps of this segment, ascending kk; fragments of step kp+1 are read before
             //      the MFMAs of step kp are issued (register double buffer fa/fb)
             constexpr int kp_lo = seg * KP / NSEG, kp_hi = (seg + 1) * KP / NSEG;
             if constexpr (seg == 0) load_frag(Ac, Xc, std::integral_constant<int, 0>{});
             nc_static_for<kp_hi - kp_lo>([&](auto d) __attribute__((always_inline)) {
                 constexpr int kp = kp_lo + decltype(d)::value;
+#if !defined(NC_ABL_NOFRAG)
                 if constexpr (kp + 1 < KP) load_frag(Ac, Xc, std::integral_constant<int, kp + 1>{});
+#endif
+#ifdef NC_EXP_SCHED
+                __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of step kp+1 ahead of the MFMAs of step kp
+#endif
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -223,7 +248,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp & 1][i], fb[kp & 1][j], acc[i][j], 0, 0, 0);
             });
         });
+#if !defined(NC_ABL_NOBAR)
         __syncthreads();
+#endif
     }
 
     // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*hi][col = l31]
@@ -237,6 +264,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
             if (co >= p.Cout) continue;
             const float bias = bias_p ? bias_p[co] : 0.0f;
             const float ao = ao_p ? ao_p[co] : 0.0f;
+            const float ao_inv = nc_snake_inv(ao);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = col0 + wave * BNW + j * 32 + l31;
@@ -245,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
                 const int64_t o = ybase + (int64_t)co * p.y_cstride + t;
                 float val = v[j][r] + bias;
                 if (res_p) val = val + res_p[o];
-                if (ao_p) val = nc_snakef(val, ao);
+                if (ao_p) val = nc_snakef(val, ao, ao_inv);
                 if (p.epi & EPI_TANH) val = nc_tanhf(val);
                 if (p.epi & EPI_RVQ) {
                     p.rvq_zq[o] = p.rvq_zq[o] + val;
@@ -275,8 +303,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
             for (int r = 0; r < 16; ++r) {
                 const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const float bias = p.bias[row], ao = p.alpha_out[row];
+                const float ao_inv = nc_snake_inv(ao);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j][r] = nc_snakef(acc[i][j][r] + bias, ao);
+                for (int j = 0; j < TN; ++j) acc[i][j][r] = nc_snakef(acc[i][j][r] + bias, ao, ao_inv);
             }
         // 2) accumulator layout -> B-operand layout, in place
 #pragma unroll

@@ -72,9 +72,11 @@ NC_HD float nc_tanhf(float x) {
     return __builtin_copysignf(t, x);
 }
 
-// Snake1d.cs:52  where(alpha == 0, x, addcdiv(x, sin(alpha*x)^2, alpha, 1))
-NC_HD float nc_snakef(float x, float alpha) {
+// Snake1d.cs:52  where(alpha == 0, x, addcdiv(x, sin(alpha*x)^2, alpha, 1)), with the division folded into one
+// correctly-rounded reciprocal per channel: inv = nc_snake_inv(alpha) = fl(1/alpha), 0 when alpha == 0 (then the
+// product term is exactly 0 and the result is x).  Branch-free; <= 1 ulp of the quotient away from the true division.
+NC_HD float nc_snake_inv(float alpha) { return alpha == 0.0f ? 0.0f : 1.0f / alpha; }
+NC_HD float nc_snakef(float x, float alpha, float inv) {
     float s = nc_sinf(alpha * x);
-    float r = x + (s * s) / alpha;   // alpha == 0: inf/NaN here, discarded by the select (branch-free on the GPU)
-    return alpha == 0.0f ? x : r;
+    return x + (s * s) * inv;
 }

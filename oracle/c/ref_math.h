@@ -72,10 +72,14 @@ static inline float ref_tanhf(float x) {
 }
 
 /* Snake1d.cs:52  where(alpha == 0, x, addcdiv(x, sin(alpha*x)^2, alpha, 1)) */
+/* Snake1d.cs:52  where(alpha == 0, x, x + sin(alpha*x)^2 / alpha), restated with the division folded into one
+ * correctly-rounded reciprocal per channel (canonical arithmetic): r = fl(1/alpha), or 0 when alpha == 0
+ * (then sin(0*x)^2 * 0 == 0 and the result is x); y = x + fl(fl(s*s) * r).  Differs from the true quotient by <= 1 ulp of
+ * the quotient. */
+static inline float ref_snake_inv(float alpha) { return alpha == 0.0f ? 0.0f : 1.0f / alpha; }
 static inline float ref_snakef(float x, float alpha) {
-    if (alpha == 0.0f) return x;
     float s = ref_sinf(alpha * x);
-    return x + (s * s) / alpha;
+    return x + (s * s) * ref_snake_inv(alpha);
 }
 
 #endif

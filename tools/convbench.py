@@ -67,16 +67,16 @@ def main():
         import numpy as np
         from neuralcodecs_amd import ops
         rng = np.random.default_rng(0)
-        for C, T in ((64, 44544), (128, 22272), (96, 44544)):
+        for Cc, T in ((64, 44544), (128, 22272), (96, 44544)):
             B = 8
-            x = rng.standard_normal((B, C, T)).astype(np.float32)
-            w7 = (rng.standard_normal((C, C, 7)) / np.sqrt(C * 7)).astype(np.float32); b7 = np.zeros(C, np.float32)
-            w1 = (rng.standard_normal((C, C, 1)) / np.sqrt(C)).astype(np.float32); b1 = np.zeros(C, np.float32)
-            al = np.full(C, 1.3, np.float32)
-            fl = 2.0 * C * C * 8 * T * B
+            x = rng.standard_normal((B, Cc, T)).astype(np.float32)
+            w7 = (rng.standard_normal((Cc, Cc, 7)) / np.sqrt(Cc * 7)).astype(np.float32); b7 = np.zeros(Cc, np.float32)
+            w1 = (rng.standard_normal((Cc, Cc, 1)) / np.sqrt(Cc)).astype(np.float32); b1 = np.zeros(Cc, np.float32)
+            al = np.full(Cc, 1.3, np.float32)
+            fl = 2.0 * Cc * Cc * 8 * T * B
             for fused in (False, True):
                 _, ms = ops.res_unit(x, w7, b7, al, al, w1, b1, dil=3, fused=fused, iters=a.iters)
-                print(f"res_unit C{C} B{B} {'fused  ' if fused else '2-launch'} {ms:8.3f} ms {fl/ms/1e9:7.1f} TF/s", flush=True)
+                print(f"res_unit C{Cc} B{B} {'fused  ' if fused else '2-launch'} {ms:8.3f} ms {fl/ms/1e9:7.1f} TF/s", flush=True)
     if tot > 0:
         print(f"sum over one encode+decode step: {tot:.2f} ms, {totf/tot/1e9:.1f} TFLOP/s")
 
