@@ -72,6 +72,8 @@ def main():
     gathered = torch.empty((world * B, cfg.n_codebooks, Tz), dtype=torch.int64, device=dev) if world > 1 else None
     side = torch.cuda.Stream(device=dev) if world > 1 else None
 
+    from neuralcodecs_amd import parallel
+
     def step():
         z, codes, lat, _, _ = model.encode(pcm)
         if world > 1:
@@ -80,7 +82,7 @@ def main():
             ev.record()
             with torch.cuda.stream(side):
                 side.wait_event(ev)
-                dist.all_gather_into_tensor(gathered, codes)
+                parallel.all_gather_codes(codes, world * B, out=gathered)
         audio = model.decode(z)
         if world > 1:
             torch.cuda.current_stream().wait_stream(side)
