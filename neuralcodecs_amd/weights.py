@@ -28,7 +28,7 @@ from typing import Dict, Iterable, List, Tuple
 
 import numpy as np
 
-from .config import DACConfig
+from .config import DACConfig, SNACConfig
 
 MAGIC = b"NCWB0001"
 _DT = {np.dtype(np.float32): 0, np.dtype(np.int64): 1}
@@ -209,6 +209,114 @@ def dac_synthetic_state_dict(cfg: DACConfig, seed: int = 42) -> "OrderedDict[str
     _alpha(sd, seed, f"decoder.model.{n + 1}.alpha", out_dim)
     _wn_pair(sd, seed, f"decoder.model.{n + 2}", (1, out_dim, 7), out_dim * 7, 0.25, bias_len=1)
     return sd
+
+
+def _wn_param(sd, seed, prefix, shape, fan_in, gain, bias_len=None, g_lo=0.8, g_hi=1.2):
+    """SNAC / Encodec flavour: `parametrizations.weight.original0` (g, [d0,1,1]) / `original1` (v) / bias
+    (Modules/SNAC/WNConv1d.cs:66-70)."""
+    tmp: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    _wn_pair(tmp, seed, prefix, shape, fan_in, gain, bias_len=bias_len, g_lo=g_lo, g_hi=g_hi)
+    sd[prefix + ".parametrizations.weight.original0"] = tmp[prefix + ".weight_g"].reshape(shape[0], 1, 1)
+    sd[prefix + ".parametrizations.weight.original1"] = tmp[prefix + ".weight_v"]
+    if bias_len is not None:
+        sd[prefix + ".bias"] = tmp[prefix + ".bias"]
+
+
+def _local_mha(sd, seed, prefix, dim):
+    """LocalMHA parameters (Modules/SNAC/LocalMHA.cs:46-70): LayerNorm, bias-free qkv / out projections, inv_freq buffer."""
+    sd[prefix + ".norm.weight"] = (0.8 + 0.4 * uniform01(seed, prefix + ".norm.weight", dim)).astype(np.float32)
+    sd[prefix + ".norm.bias"] = (approx_normal(seed, prefix + ".norm.bias", dim) * 0.02).astype(np.float32)
+    sd[prefix + ".to_qkv.weight"] = (approx_normal(seed, prefix + ".to_qkv.weight", 3 * dim * dim) / np.sqrt(dim)
+                                     ).astype(np.float32).reshape(3 * dim, dim)
+    sd[prefix + ".to_out.weight"] = (approx_normal(seed, prefix + ".to_out.weight", dim * dim) * (0.5 / np.sqrt(dim))
+                                     ).astype(np.float32).reshape(dim, dim)
+    # SinusoidalEmbedding.cs:44-47: inv_freq = 1 / 10000 ** (arange(0, 64, 2) / 64), float32 arithmetic
+    power = (np.arange(0, 64, 2, dtype=np.float32) / np.float32(64)).astype(np.float32)
+    sd[prefix + ".rel_pos.inv_freq"] = (np.float32(1.0) / np.power(np.float32(10000.0), power, dtype=np.float32)).astype(np.float32)
+
+
+def snac_synthetic_state_dict(cfg: SNACConfig, seed: int = 42) -> "OrderedDict[str, np.ndarray]":
+    """Seeded synthetic SNAC weights under the reference's TorchSharp key names."""
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    G_DW, G_RES1, G_MAIN = 1.0, 0.35, 0.9
+    d = cfg.encoder_dim
+    _wn_param(sd, seed, "encoder.block.0", (d, 1, 7), 7, 1.6, bias_len=d)
+    for bi, s in enumerate(cfg.encoder_rates):
+        cin = d
+        d *= 2
+        p = f"encoder.block.{bi + 1}"
+        for ui in range(3):
+            q = f"{p}.block.{ui}"
+            _alpha(sd, seed, f"{q}.block.0.alpha", cin)
+            if cfg.depthwise:
+                _wn_param(sd, seed, f"{q}.block.1", (cin, 1, 7), 7, G_DW, bias_len=cin)
+            else:
+                _wn_param(sd, seed, f"{q}.block.1", (cin, cin, 7), cin * 7, 0.9, bias_len=cin)
+            _alpha(sd, seed, f"{q}.block.2.alpha", cin)
+            _wn_param(sd, seed, f"{q}.block.3", (cin, cin, 1), cin, G_RES1, bias_len=cin)
+        _alpha(sd, seed, f"{p}.block.3.alpha", cin)
+        _wn_param(sd, seed, f"{p}.block.4", (d, cin, 2 * s), cin * 2 * s, G_MAIN, bias_len=d)
+    n = len(cfg.encoder_rates) + 1
+    if cfg.attn_window_size:
+        _local_mha(sd, seed, f"encoder.block.{n}", d)
+        n += 1
+    if cfg.depthwise:
+        _wn_param(sd, seed, f"encoder.block.{n}", (d, 1, 7), 7, G_DW, bias_len=d)
+    else:
+        _wn_param(sd, seed, f"encoder.block.{n}", (d, d, 7), d * 7, G_MAIN, bias_len=d)
+    latent = cfg.resolved_latent_dim
+    for i in range(len(cfg.vq_strides)):
+        p = f"quantizer.quantizers.{i}"
+        _wn_param(sd, seed, f"{p}.in_proj", (cfg.codebook_dim, latent, 1), latent, 1.0, bias_len=cfg.codebook_dim)
+        _wn_param(sd, seed, f"{p}.out_proj", (latent, cfg.codebook_dim, 1), cfg.codebook_dim, 0.45, bias_len=latent)
+        sd[f"{p}.codebook.weight"] = (approx_normal(seed, f"{p}.codebook.weight", cfg.codebook_size * cfg.codebook_dim)
+                                      * 0.8).astype(np.float32).reshape(cfg.codebook_size, cfg.codebook_dim)
+    ch = cfg.decoder_dim
+    if cfg.depthwise:
+        _wn_param(sd, seed, "decoder.model.0", (latent, 1, 7), 7, G_DW, bias_len=latent)
+        _wn_param(sd, seed, "decoder.model.1", (ch, latent, 1), latent, G_MAIN, bias_len=ch)
+        n = 2
+    else:
+        _wn_param(sd, seed, "decoder.model.0", (ch, latent, 7), latent * 7, G_MAIN, bias_len=ch)
+        n = 1
+    if cfg.attn_window_size:
+        _local_mha(sd, seed, f"decoder.model.{n}", ch)
+        n += 1
+    out_dim = ch
+    for bi, s in enumerate(cfg.decoder_rates):
+        in_dim = ch // (1 << bi)
+        out_dim = ch // (1 << (bi + 1))
+        p = f"decoder.model.{n}"
+        _alpha(sd, seed, f"{p}.block.0.alpha", in_dim)
+        _wn_param(sd, seed, f"{p}.block.1", (in_dim, out_dim, 2 * s), in_dim * 2, G_MAIN, bias_len=out_dim)
+        k = 2
+        if cfg.noise:
+            _wn_param(sd, seed, f"{p}.block.2.linear", (out_dim, out_dim, 1), out_dim, 0.15)
+            k = 3
+        for ui in range(3):
+            q = f"{p}.block.{k + ui}"
+            _alpha(sd, seed, f"{q}.block.0.alpha", out_dim)
+            if cfg.depthwise:
+                _wn_param(sd, seed, f"{q}.block.1", (out_dim, 1, 7), 7, G_DW, bias_len=out_dim)
+            else:
+                _wn_param(sd, seed, f"{q}.block.1", (out_dim, out_dim, 7), out_dim * 7, 0.9, bias_len=out_dim)
+            _alpha(sd, seed, f"{q}.block.2.alpha", out_dim)
+            _wn_param(sd, seed, f"{q}.block.3", (out_dim, out_dim, 1), out_dim, G_RES1, bias_len=out_dim)
+        n += 1
+    _alpha(sd, seed, f"decoder.model.{n}.alpha", out_dim)
+    _wn_param(sd, seed, f"decoder.model.{n + 1}", (1, out_dim, 7), out_dim * 7, 0.25, bias_len=1)
+    return sd
+
+
+def snac_noise(cfg: SNACConfig, batch: int, frames: int, seed: int = 99):
+    """The NoiseBlock inputs of one decode ([B,1,T_i] per decoder block), from the counter-based generator -- the reference
+    draws them with randn at inference (NoiseBlock.cs:41, deviation D8), so parity tests inject them."""
+    out = []
+    T = frames
+    for bi, s in enumerate(cfg.decoder_rates):
+        T = (T - 1) * s - 2 * (-(-s // 2)) + 2 * s + (s % 2)
+        out.append(approx_normal(seed + bi, "snac.noise", batch * T).astype(np.float32).reshape(batch, 1, T))
+    return out
 
 
 def _parabolic_sine(phase_num: np.ndarray, denom: int) -> np.ndarray:

@@ -28,23 +28,10 @@
 #endif
 #include "ref_math.h"
 
-#define REF_API __attribute__((visibility("default")))
 
-/* ------------------------------------------------------------------ weight blob (NCWB0001) */
-typedef struct {
-    char name[176];
-    int dtype, ndim;
-    int64_t dims[6];
-    const void* data;
-    int64_t nbytes;
-} ref_tensor;
+#include "nc_ref_internal.h"
 
-typedef struct {
-    int n;
-    ref_tensor* t;
-} ref_blob;
-
-static int blob_parse(const uint8_t* buf, int64_t len, ref_blob* out) {
+int ref_blob_parse(const uint8_t* buf, int64_t len, ref_blob* out) {
     if (len < 24 || memcmp(buf, "NCWB0001", 8) != 0) return -1;
     uint64_t n, idx_len;
     memcpy(&n, buf + 8, 8);
@@ -69,7 +56,7 @@ static int blob_parse(const uint8_t* buf, int64_t len, ref_blob* out) {
     return 0;
 }
 
-static const ref_tensor* blob_find(const ref_blob* b, const char* name) {
+const ref_tensor* ref_blob_find(const ref_blob* b, const char* name) {
     for (int i = 0; i < b->n; i++)
         if (strcmp(b->t[i].name, name) == 0) return &b->t[i];
     return NULL;
@@ -272,11 +259,11 @@ typedef struct {
 static int load_wn(const ref_blob* bl, const char* prefix, ref_conv_p* p, int transpose) {
     char nm[256];
     snprintf(nm, sizeof nm, "%s.weight_v", prefix);
-    const ref_tensor* v = blob_find(bl, nm);
+    const ref_tensor* v = ref_blob_find(bl, nm);
     snprintf(nm, sizeof nm, "%s.weight_g", prefix);
-    const ref_tensor* g = blob_find(bl, nm);
+    const ref_tensor* g = ref_blob_find(bl, nm);
     snprintf(nm, sizeof nm, "%s.bias", prefix);
-    const ref_tensor* b = blob_find(bl, nm);
+    const ref_tensor* b = ref_blob_find(bl, nm);
     if (!v || !g) { fprintf(stderr, "nc_ref: missing %s\n", prefix); return -1; }
     int64_t d0 = v->dims[0], inner = v->dims[1] * v->dims[2];
     p->w = (float*)malloc(sizeof(float) * d0 * inner);
@@ -289,7 +276,7 @@ static int load_wn(const ref_blob* bl, const char* prefix, ref_conv_p* p, int tr
 }
 
 static const float* load_alpha(const ref_blob* bl, const char* fmt_name) {
-    const ref_tensor* t = blob_find(bl, fmt_name);
+    const ref_tensor* t = ref_blob_find(bl, fmt_name);
     if (!t) { fprintf(stderr, "nc_ref: missing %s\n", fmt_name); return NULL; }
     return (const float*)t->data;
 }
@@ -301,7 +288,7 @@ REF_API ref_dac* ref_dac_create(const ref_dac_config* cfg, const uint8_t* blob, 
     m->cfg = *cfg;
     m->blob_copy = (uint8_t*)malloc(blob_len);
     memcpy(m->blob_copy, blob, blob_len);
-    if (blob_parse(m->blob_copy, blob_len, &m->blob) != 0) { ref_dac_destroy(m); return NULL; }
+    if (ref_blob_parse(m->blob_copy, blob_len, &m->blob) != 0) { ref_dac_destroy(m); return NULL; }
     const ref_blob* bl = &m->blob;
     char nm[256];
     int bad = 0;
@@ -326,7 +313,7 @@ REF_API ref_dac* ref_dac_create(const ref_dac_config* cfg, const uint8_t* blob, 
         snprintf(nm, sizeof nm, "quantizer.quantizers.%d.in_proj", i); bad |= load_wn(bl, nm, &m->in_proj[i], 0);
         snprintf(nm, sizeof nm, "quantizer.quantizers.%d.out_proj", i); bad |= load_wn(bl, nm, &m->out_proj[i], 0);
         snprintf(nm, sizeof nm, "quantizer.quantizers.%d.codebook.weight", i);
-        const ref_tensor* t = blob_find(bl, nm);
+        const ref_tensor* t = ref_blob_find(bl, nm);
         if (!t) bad = 1; else m->codebook[i] = (const float*)t->data;
     }
     bad |= load_wn(bl, "decoder.model.0", &m->dec_in, 0);

@@ -20,10 +20,17 @@ i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 
 
 def build(force: bool = False) -> str:
-    src = [os.path.join(_HERE, "c", f) for f in ("nc_ref.c", "ref_math.h")]
+    src = [os.path.join(_HERE, "c", f) for f in os.listdir(os.path.join(_HERE, "c")) if f.endswith((".c", ".h"))]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
+
+
+class RefSnacConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_int), ("encoder_dim", C.c_int), ("n_enc_rates", C.c_int), ("enc_rates", C.c_int * 8),
+                ("decoder_dim", C.c_int), ("n_dec_rates", C.c_int), ("dec_rates", C.c_int * 8), ("latent_dim", C.c_int),
+                ("attn_window", C.c_int), ("codebook_size", C.c_int), ("codebook_dim", C.c_int), ("n_vq", C.c_int),
+                ("vq_strides", C.c_int * 8), ("noise", C.c_int), ("depthwise", C.c_int)]
 
 
 class RefDacConfig(C.Structure):
@@ -54,6 +61,16 @@ def lib():
         L.ref_fold_wn_dac.argtypes = [f32p, f32p, C.c_int64, C.c_int64, f32p]
         L.ref_vq_argmin.argtypes = [f32p, C.c_int64, C.c_int, C.c_int64, f32p, C.c_int, i64p, f32p, C.c_void_p]
         L.ref_num_threads.restype = C.c_int
+        L.ref_snac_create.restype = C.c_void_p
+        L.ref_snac_create.argtypes = [C.POINTER(RefSnacConfig), C.c_char_p, C.c_int64]
+        L.ref_snac_destroy.argtypes = [C.c_void_p]
+        for f in ("ref_snac_padded_length", "ref_snac_frames", "ref_snac_decoded_length"):
+            getattr(L, f).restype = C.c_int64
+            getattr(L, f).argtypes = [C.c_void_p, C.c_int64]
+        L.ref_snac_encode.argtypes = [C.c_void_p, f32p, C.c_int64, C.c_int64, i64p, C.c_void_p, C.c_void_p]
+        L.ref_snac_from_codes.argtypes = [C.c_void_p, i64p, C.c_int64, C.c_int64, f32p]
+        L.ref_snac_decode.argtypes = [C.c_void_p, f32p, C.c_int64, C.c_int64, C.c_void_p, f32p]
+        L.ref_fold_wn_snac.argtypes = [f32p, f32p, C.c_int64, C.c_int64, f32p]
         _lib = L
     return _lib
 
@@ -168,3 +185,74 @@ class RefDAC:
         z = np.empty((B, self.cfg.resolved_latent_dim, Tz), np.float32)
         lib().ref_dac_from_codes(self._h, codes, B, nq, Tz, z)
         return z
+
+
+class RefSNAC:
+    """C-oracle SNAC (call surface of the reference's SNAC.Encode / Decode; codes are a list of per-level int64 arrays)."""
+
+    def __init__(self, cfg, blob: bytes):
+        rc = RefSnacConfig()
+        rc.sample_rate, rc.encoder_dim, rc.decoder_dim = cfg.sampling_rate, cfg.encoder_dim, cfg.decoder_dim
+        rc.n_enc_rates, rc.n_dec_rates, rc.n_vq = len(cfg.encoder_rates), len(cfg.decoder_rates), len(cfg.vq_strides)
+        for i, r in enumerate(cfg.encoder_rates): rc.enc_rates[i] = r
+        for i, r in enumerate(cfg.decoder_rates): rc.dec_rates[i] = r
+        for i, r in enumerate(cfg.vq_strides): rc.vq_strides[i] = r
+        rc.latent_dim, rc.attn_window = cfg.resolved_latent_dim, cfg.attn_window_size or 0
+        rc.codebook_size, rc.codebook_dim = cfg.codebook_size, cfg.codebook_dim
+        rc.noise, rc.depthwise = int(cfg.noise), int(cfg.depthwise)
+        self.cfg = cfg
+        self._h = lib().ref_snac_create(C.byref(rc), blob, len(blob))
+        if not self._h:
+            raise RuntimeError("ref_snac_create failed")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            try:
+                _lib.ref_snac_destroy(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+    def level_widths(self, Tz):
+        return [Tz // s for s in self.cfg.vq_strides]
+
+    def encode(self, pcm):
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        B, _, T = pcm.shape
+        Tz = lib().ref_snac_frames(self._h, T)
+        widths = self.level_widths(Tz)
+        flat = np.empty((B, sum(widths)), np.int64)
+        ld = self.cfg.resolved_latent_dim
+        zq = np.empty((B, ld, Tz), np.float32); z = np.empty((B, ld, Tz), np.float32)
+        if lib().ref_snac_encode(self._h, pcm, B, T, flat, _opt(zq), _opt(z)) != 0:
+            raise RuntimeError("ref_snac_encode failed (missing tensors?)")
+        codes, o = [], 0
+        for w in widths:
+            codes.append(np.ascontiguousarray(flat[:, o:o + w])); o += w
+        return z, zq, codes
+
+    def from_codes(self, codes):
+        B = codes[0].shape[0]
+        Tz = codes[-1].shape[1] * self.cfg.vq_strides[-1]
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(c, np.int64).reshape(B, -1) for c in codes], axis=1))
+        zq = np.empty((B, self.cfg.resolved_latent_dim, Tz), np.float32)
+        if lib().ref_snac_from_codes(self._h, flat, B, Tz, zq) != 0:
+            raise RuntimeError("ref_snac_from_codes failed")
+        return zq
+
+    def decode_latents(self, zq, noises=None):
+        zq = np.ascontiguousarray(zq, np.float32)
+        B, _, Tz = zq.shape
+        L = lib().ref_snac_decoded_length(self._h, Tz)
+        nz = None
+        if self.cfg.noise:
+            if noises is None:
+                raise ValueError("SNAC decode needs the NoiseBlock inputs (deviation D8)")
+            nz = np.ascontiguousarray(np.concatenate([np.asarray(n, np.float32).reshape(-1) for n in noises]))
+        pcm = np.empty((B, 1, L), np.float32)
+        if lib().ref_snac_decode(self._h, zq, B, Tz, _opt(nz), pcm) != 0:
+            raise RuntimeError("ref_snac_decode failed")
+        return pcm
+
+    def decode(self, codes, noises=None):
+        return self.decode_latents(self.from_codes(codes), noises)

@@ -58,3 +58,30 @@ def audit_code_mismatches(codes, ref_codes, gap, tol):
                 g = float(gap[i, b * T + t])
                 assert g < tol, f"code mismatch at clip {b} stage {i} frame {t} is not a near-tie (gap {g:g})"
     return bad
+
+
+def snac_cfg_from_meta(meta):
+    from neuralcodecs_amd.config import SNACConfig
+    kw = dict(meta["cfg"])
+    for k in ("encoder_rates", "decoder_rates", "vq_strides"):
+        if k in kw:
+            kw[k] = tuple(kw[k])
+    return SNACConfig(**kw)
+
+
+def audit_snac_levels(codes, golden, tol):
+    """Per level: a code that differs from the golden one must be a near-tie of the golden argmin.  SNAC levels run at
+    different rates, so a flip at a coarse level can change finer levels freely: stop auditing a clip at its first flip."""
+    flips = 0
+    B = codes[0].shape[0]
+    for b in range(B):
+        for i, c in enumerate(codes):
+            ref = golden[f"codes{i}"][b]
+            neq = np.nonzero(np.asarray(c[b]) != ref)[0]
+            if neq.size:
+                T = ref.shape[0]
+                g = golden[f"gap{i}"][b * T + int(neq[0])]
+                assert g < tol, f"SNAC code mismatch clip {b} level {i} frame {int(neq[0])} is not a near-tie (gap {g:g})"
+                flips += 1
+                break
+    return flips

@@ -1,0 +1,56 @@
+"""CPU suite: the C oracle's SNAC path against the golden vectors of the PyTorch-CPU restatement (oracle/torch_ref/snac.py)."""
+import numpy as np
+import pytest
+
+from conftest import audit_snac_levels, load_golden, snac_cfg_from_meta
+from neuralcodecs_amd.weights import save_blob, snac_noise, snac_synthetic_state_dict, synthetic_pcm
+from oracle import c_oracle
+
+PCM_TOL, LATENT_TOL, GAP_TOL = 1e-4, 3e-5, 1e-4
+
+
+@pytest.mark.parametrize("name", ["snac_small", "snac_small_attn"])
+def test_c_oracle_snac_small_matches_golden(name):
+    g = load_golden(name)
+    meta = g["meta"]
+    cfg = snac_cfg_from_meta(meta)
+    ref = c_oracle.RefSNAC(cfg, save_blob(snac_synthetic_state_dict(cfg, seed=meta["weight_seed"])))
+    assert np.array_equal(synthetic_pcm(meta["B"], 1, meta["T"], cfg.sampling_rate, seed=meta["pcm_seed"]), g["pcm"])
+    z, zq, codes = ref.encode(g["pcm"])
+    Tz = g["z"].shape[-1]
+    assert [c.shape for c in codes] == [(meta["B"], Tz // s) for s in cfg.vq_strides] and codes[0].dtype == np.int64
+    assert np.abs(z - g["z"]).max() < LATENT_TOL
+    if audit_snac_levels(codes, g, GAP_TOL) == 0:
+        assert np.abs(zq - g["zq"]).max() < LATENT_TOL
+    gold_codes = [g[f"codes{i}"].astype(np.int64) for i in range(len(cfg.vq_strides))]
+    noises = snac_noise(cfg, meta["B"], Tz, seed=meta["noise_seed"])
+    audio = ref.decode(gold_codes, noises)
+    assert audio.shape == g["audio"].shape
+    assert np.abs(audio - g["audio"]).max() < PCM_TOL
+    assert np.abs(ref.from_codes(gold_codes) - g["zq"]).max() < LATENT_TOL
+
+
+def test_c_oracle_snac24k_full_size():
+    """BASELINE config C1: SNAC 24 kHz mono, one 1 s clip -> padded 24576, T'=48, codes 12/24/48."""
+    g = load_golden("snac24k_b1")
+    meta = g["meta"]
+    cfg = snac_cfg_from_meta(meta)
+    ref = c_oracle.RefSNAC(cfg, save_blob(snac_synthetic_state_dict(cfg, seed=meta["weight_seed"])))
+    pcm = synthetic_pcm(1, 1, meta["T"], cfg.sampling_rate, seed=meta["pcm_seed"])
+    z, zq, codes = ref.encode(pcm)
+    assert [c.shape for c in codes] == [(1, 12), (1, 24), (1, 48)]
+    if audit_snac_levels(codes, g, GAP_TOL) == 0:
+        assert np.abs(zq[:, ::16, :] - g["zq_slice"]).max() < LATENT_TOL
+    gold_codes = [g[f"codes{i}"].astype(np.int64) for i in range(3)]
+    audio = ref.decode(gold_codes, snac_noise(cfg, 1, 48, seed=meta["noise_seed"]))
+    assert audio.shape == (1, 1, 24576)
+    assert np.abs(audio[:, :, ::17] - g["audio_slice"]).max() < PCM_TOL
+
+
+def test_snac_pad_rule_and_noise_requirement():
+    cfg = snac_cfg_from_meta(load_golden("snac_small_attn")["meta"])
+    assert cfg.pad_multiple == cfg.hop_length * 8          # lcm(vq_strides[0]=4, window=8)
+    ref = c_oracle.RefSNAC(cfg, save_blob(snac_synthetic_state_dict(cfg, seed=6)))
+    assert c_oracle.lib().ref_snac_padded_length(ref._h, 2500) == 3072
+    with pytest.raises(ValueError):
+        ref.decode_latents(np.zeros((1, cfg.resolved_latent_dim, 8), np.float32))      # D8: noise must be injected

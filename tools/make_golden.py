@@ -15,9 +15,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from neuralcodecs_amd.config import DACConfig  # noqa: E402
-from neuralcodecs_amd.weights import dac_synthetic_state_dict, synthetic_pcm  # noqa: E402
+from neuralcodecs_amd.config import DACConfig, SNACConfig  # noqa: E402
+from neuralcodecs_amd.weights import dac_synthetic_state_dict, snac_noise, snac_synthetic_state_dict, synthetic_pcm  # noqa: E402
 from oracle.torch_ref.dac import TorchDAC  # noqa: E402
+from oracle.torch_ref.snac import TorchSNAC  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 torch.set_num_threads(8)
@@ -57,9 +58,41 @@ def dac_case(name, cfg_kw, B, T, wseed, pseed, full):
     print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k != "meta"})
 
 
+SNAC_SMALL = dict(sampling_rate=16000, encoder_dim=8, encoder_rates=(2, 3, 4, 4), decoder_dim=64, decoder_rates=(4, 4, 3, 2),
+                  attn_window_size=None, codebook_size=256, vq_strides=(4, 2, 1))
+SNAC_SMALL_ATTN = dict(sampling_rate=16000, encoder_dim=16, encoder_rates=(2, 3, 4, 4), decoder_dim=256, decoder_rates=(4, 4, 3, 2),
+                       attn_window_size=8, codebook_size=256, vq_strides=(4, 2, 1))
+
+
+def snac_case(name, cfg_kw, B, T, wseed, pseed, nseed, full):
+    cfg = SNACConfig(**cfg_kw)
+    m = TorchSNAC(cfg, snac_synthetic_state_dict(cfg, seed=wseed))
+    pcm = synthetic_pcm(B, 1, T, cfg.sampling_rate, seed=pseed)
+    z, zq, codes, dists = m.encode(pcm, want_dist=True)
+    noises = snac_noise(cfg, B, z.shape[-1], seed=nseed)
+    audio = m.decode(codes, noises)
+    meta = dict(cfg=cfg_kw, B=B, T=T, weight_seed=wseed, pcm_seed=pseed, noise_seed=nseed)
+    out = dict(meta=json.dumps(meta))
+    for i, (c, d) in enumerate(zip(codes, dists)):
+        out[f"codes{i}"] = c.numpy().astype(np.int16)
+        v, _ = torch.topk(d, 2, dim=1, largest=False)
+        out[f"gap{i}"] = (v[:, 1] - v[:, 0]).numpy().astype(np.float32)
+    if full:
+        out.update(zq_slice=zq.numpy()[:, ::16, :], audio_slice=audio.numpy()[:, :, ::17])
+    else:
+        out.update(pcm=pcm, z=z.numpy(), zq=zq.numpy(), audio=audio.numpy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k != "meta"})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     # reduced width, ragged length (not a hop multiple), odd stride 5 (DAC-16/24 kHz presets use it)
     dac_case("dac_small", SMALL, 2, 2000, 7, 11, False)
     # full-size DAC 44.1 kHz 8 kbps, one 1 s clip (BASELINE config C2 at B=1)
     dac_case("dac44k_b1", dict(), 1, 44100, 42, 1234, True)
+    # SNAC: reduced width without / with local attention (odd stride 3 exercises output_padding), ragged lengths
+    snac_case("snac_small", SNAC_SMALL, 2, 3001, 5, 3, 99, False)
+    snac_case("snac_small_attn", SNAC_SMALL_ATTN, 2, 2500, 6, 4, 98, False)
+    # full-size SNAC 24 kHz, one 1 s clip (BASELINE config C1)
+    snac_case("snac24k_b1", dict(), 1, 24000, 42, 1234, 77, True)
