@@ -81,8 +81,11 @@ NC_API nc_status nc_codec_destroy(nc_codec* h);
 NC_API nc_status nc_codec_load_weights(nc_codec* h, const char* path);
 NC_API nc_status nc_codec_load_weights_mem(nc_codec* h, const void* blob, size_t nbytes);
 
-/* Run the handle's work on a caller-owned hipStream_t (NULL = the handle's own stream). */
+/* Run the handle's work on a caller-owned hipStream_t.  NULL is HIP's legacy default (null) stream -- the stream PyTorch-ROCm
+ * uses by default -- so device buffers produced by the caller's framework are ordered with the engine's kernels.
+ * nc_codec_reset_stream returns to the handle's own (non-blocking) stream. */
 NC_API nc_status nc_codec_set_stream(nc_codec* h, void* hip_stream);
+NC_API nc_status nc_codec_reset_stream(nc_codec* h);
 NC_API nc_status nc_codec_synchronize(nc_codec* h);
 
 /* Shape helper for DAC.Preprocess (Models/DAC.cs:141-154): padded length and frame count T'. */
@@ -109,6 +112,57 @@ NC_API nc_status nc_dac_decode_dev(nc_codec* h, const float* z, int32_t B, int64
 NC_API nc_status nc_dac_from_codes(nc_codec* h, const int64_t* codes, int32_t B, int32_t n_q, int64_t frames, float* z);
 NC_API nc_status nc_dac_from_codes_dev(nc_codec* h, const int64_t* codes, int32_t B, int32_t n_q, int64_t frames, float* z);
 
+/* ----------------------------------------------------------------------------------------- SNAC
+ * replaces: new SNAC(SNACConfig)                   NeuralCodecs.Torch/Models/SNAC.cs:34-63
+ *           fields consumed                        NeuralCodecs.Torch/Config/SNAC/SNACConfig.cs:40-100 */
+typedef struct {
+    int32_t sample_rate;      /* 24000 */
+    int32_t encoder_dim;      /* 48 */
+    int32_t n_encoder_rates;  /* 4 */
+    int32_t encoder_rates[8]; /* 2,4,8,8 */
+    int32_t decoder_dim;      /* 1024 */
+    int32_t n_decoder_rates;
+    int32_t decoder_rates[8]; /* 8,8,4,2 */
+    int32_t latent_dim;       /* 0 => encoder_dim * 2^n_encoder_rates (SNAC.cs:41) */
+    int32_t attn_window_size; /* 0 = no LocalMHA (24 kHz); 32 for the 32/44 kHz presets */
+    int32_t codebook_size;    /* 4096 */
+    int32_t codebook_dim;     /* 8 */
+    int32_t n_vq_strides;
+    int32_t vq_strides[8];    /* 4,2,1 */
+    int32_t noise;            /* NoiseBlock in every decoder block */
+    int32_t depthwise;        /* depthwise k7 convolutions */
+} nc_snac_config;
+
+NC_API nc_status nc_snac_create(const nc_snac_config* cfg, int device_index, nc_codec** out);
+
+/* Shape helper for SNAC.Preprocess (Models/SNAC.cs:70-80): padded length = multiple of hop*lcm(vq_strides[0], window),
+ * frames T' = padded/hop, per-level code widths T'/stride_i (level_widths has room for 8), decoded length. */
+NC_API nc_status nc_snac_query(const nc_codec* h, int64_t T, int64_t* T_padded, int64_t* frames, int32_t* n_levels,
+                               int64_t* level_widths, int64_t* decoded_len);
+
+/* replaces: SNAC.Encode(float[]) / Encode(Tensor)   Models/SNAC.cs:113-150  (always pads: the Tensor overload's missing pad
+ * is reference bug D7; both agree on lengths that are already multiples)
+ *   pcm   [B,1,T] float32
+ *   codes [B, sum_i T'/stride_i] int64: the levels of one clip side by side, coarse first (the reference returns a List of
+ *         [B, T'/stride_i] tensors; nc_snac_query gives the widths)
+ *   z / zq nullable [B, latent, T']: encoder output / quantized latents */
+NC_API nc_status nc_snac_encode(nc_codec* h, const float* pcm, int32_t B, int64_t T, int64_t* codes, float* z, float* zq);
+NC_API nc_status nc_snac_encode_dev(nc_codec* h, const float* pcm, int32_t B, int64_t T, int64_t* codes, float* z, float* zq);
+
+/* replaces: ResidualVectorQuantizer.FromCodes      Modules/SNAC/ResidualVectorQuantizer.cs:100-135 */
+NC_API nc_status nc_snac_from_codes(nc_codec* h, const int64_t* codes, int32_t B, int64_t frames, float* zq);
+NC_API nc_status nc_snac_from_codes_dev(nc_codec* h, const int64_t* codes, int32_t B, int64_t frames, float* zq);
+
+/* replaces: SNAC.Decode(List<Tensor> codes)        Models/SNAC.cs:157-192 -> [B,1,decoded_len]
+ *   noise: the NoiseBlock inputs, one [B,1,T_i] block per decoder stage laid end to end (reference: torch.randn at inference,
+ *          NoiseBlock.cs:41, hence not reproducible); NULL = draw N(0,1) on the device from `seed` (counter-based). */
+NC_API nc_status nc_snac_decode(nc_codec* h, const int64_t* codes, int32_t B, int64_t frames, const float* noise, uint64_t seed,
+                                float* pcm);
+NC_API nc_status nc_snac_decode_dev(nc_codec* h, const int64_t* codes, int32_t B, int64_t frames, const float* noise,
+                                    uint64_t seed, float* pcm);
+/* total number of noise floats nc_snac_decode consumes for (B, frames) */
+NC_API nc_status nc_snac_noise_len(const nc_codec* h, int32_t B, int64_t frames, int64_t* n);
+
 /* ------------------------------------------------------------------------------------ profiling
  * Per-kernel-class timing with HIP events recorded on the handle's stream around every launch
  * (used by bench.py for the roofline object).  Classes are stable small integers. */
@@ -119,7 +173,8 @@ typedef enum {
     NC_KC_CONV_UP = 3,   /* transposed (polyphase) up-sampling convolutions */
     NC_KC_CONV_MISC = 4, /* stem / head / k3 / decoder-input convolutions */
     NC_KC_RVQ = 5,       /* codebook argmin + gather kernels */
-    NC_KC_COUNT = 6
+    NC_KC_ELEM = 6,      /* HBM-bound element-wise kernels: depthwise conv, norms, pooling, attention windows */
+    NC_KC_COUNT = 7
 } nc_kernel_class;
 
 typedef struct {

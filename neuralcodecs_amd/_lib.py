@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnc_mi355x.so")
 
 NC_OK, NC_EINVAL, NC_ENOTFOUND, NC_ESTATE, NC_EDEVICE, NC_ENOMEM, NC_EUNSUPPORTED = range(7)
-NC_KC_NAMES = ("conv_k7", "conv_k1", "conv_down", "conv_up", "conv_misc", "rvq")
+NC_KC_NAMES = ("conv_k7", "conv_k1", "conv_down", "conv_up", "conv_misc", "rvq", "elem")
 
 
 class NcError(RuntimeError):
@@ -29,6 +29,14 @@ class NcDacConfig(C.Structure):
                 ("encoder_rates", C.c_int32 * 8), ("decoder_dim", C.c_int32), ("n_decoder_rates", C.c_int32),
                 ("decoder_rates", C.c_int32 * 8), ("latent_dim", C.c_int32), ("n_codebooks", C.c_int32),
                 ("codebook_size", C.c_int32), ("codebook_dim", C.c_int32)]
+
+
+class NcSnacConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_int32), ("encoder_dim", C.c_int32), ("n_encoder_rates", C.c_int32),
+                ("encoder_rates", C.c_int32 * 8), ("decoder_dim", C.c_int32), ("n_decoder_rates", C.c_int32),
+                ("decoder_rates", C.c_int32 * 8), ("latent_dim", C.c_int32), ("attn_window_size", C.c_int32),
+                ("codebook_size", C.c_int32), ("codebook_dim", C.c_int32), ("n_vq_strides", C.c_int32),
+                ("vq_strides", C.c_int32 * 8), ("noise", C.c_int32), ("depthwise", C.c_int32)]
 
 
 class NcProfileEntry(C.Structure):
@@ -54,6 +62,7 @@ SYMBOLS = [
     ("nc_codec_load_weights", C.c_int, [_P, C.c_char_p]),
     ("nc_codec_load_weights_mem", C.c_int, [_P, _P, C.c_size_t]),
     ("nc_codec_set_stream", C.c_int, [_P, _P]),
+    ("nc_codec_reset_stream", C.c_int, [_P]),
     ("nc_codec_synchronize", C.c_int, [_P]),
     ("nc_dac_query", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("nc_dac_encode", C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P]),
@@ -62,6 +71,16 @@ SYMBOLS = [
     ("nc_dac_decode_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
     ("nc_dac_from_codes", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, _P]),
     ("nc_dac_from_codes_dev", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, _P]),
+    ("nc_snac_create", C.c_int, [C.POINTER(NcSnacConfig), C.c_int, C.POINTER(_P)]),
+    ("nc_snac_query", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("nc_snac_noise_len", C.c_int, [_P, C.c_int32, C.c_int64, C.POINTER(C.c_int64)]),
+    ("nc_snac_encode", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
+    ("nc_snac_encode_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
+    ("nc_snac_from_codes", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
+    ("nc_snac_from_codes_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
+    ("nc_snac_decode", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, C.c_uint64, _P]),
+    ("nc_snac_decode_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, C.c_uint64, _P]),
     ("nc_codec_profile_enable", C.c_int, [_P, C.c_int32]),
     ("nc_codec_profile_reset", C.c_int, [_P]),
     ("nc_codec_profile_read", C.c_int, [_P, C.POINTER(NcProfileEntry)]),

@@ -38,6 +38,12 @@ DacModel& as_dac(nc_codec* h) {
     return static_cast<DacModel&>(*h->impl);
 }
 
+SnacModel& as_snac(nc_codec* h) {
+    if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");
+    if (h->kind != 1) fail(NC_EINVAL, "handle is not a SNAC codec");
+    return static_cast<SnacModel&>(*h->impl);
+}
+
 void h2d(void* d, const void* h, size_t n, hipStream_t s) { NC_HIP(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s)); }
 void d2h(void* h, const void* d, size_t n, hipStream_t s) { NC_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s)); }
 
@@ -107,7 +113,14 @@ nc_status nc_codec_load_weights(nc_codec* h, const char* path) {
 nc_status nc_codec_set_stream(nc_codec* h, void* hip_stream) {
     return guard([&] {
         if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");
-        h->impl->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->impl->own_stream;
+        h->impl->stream = static_cast<hipStream_t>(hip_stream);
+    });
+}
+
+nc_status nc_codec_reset_stream(nc_codec* h) {
+    return guard([&] {
+        if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");
+        h->impl->stream = h->impl->own_stream;
     });
 }
 
@@ -188,6 +201,110 @@ nc_status nc_dac_from_codes(nc_codec* h, const int64_t* codes, int32_t B, int32_
         h2d(m.h_codes.p, codes, n_codes, m.stream);
         m.from_codes_dev(m.h_codes.as<int64_t>(), B, n_q, frames, m.h_aux0.as<float>());
         d2h(z, m.h_aux0.p, n_z, m.stream);
+        NC_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
+// ---- SNAC ------------------------------------------------------------------------------------------
+nc_status nc_snac_create(const nc_snac_config* cfg, int device_index, nc_codec** out) {
+    return guard([&] {
+        if (!cfg || !out) fail(NC_EINVAL, "cfg and out must not be null");
+        *out = nullptr;
+        std::unique_ptr<SnacModel> m(new SnacModel(*cfg));
+        m->init_device(device_index);
+        nc_codec* h = new nc_codec();
+        h->impl = std::move(m);
+        h->kind = 1;
+        *out = h;
+    });
+}
+
+nc_status nc_snac_query(const nc_codec* h, int64_t T, int64_t* T_padded, int64_t* frames, int32_t* n_levels, int64_t* level_widths,
+                        int64_t* decoded_len) {
+    return guard([&] {
+        SnacModel& m = as_snac(const_cast<nc_codec*>(h));
+        if (T <= 0) fail(NC_EINVAL, "T must be positive");
+        const int64_t Tp = m.padded_len(T), Tz = Tp / m.hop;
+        if (T_padded) *T_padded = Tp;
+        if (frames) *frames = Tz;
+        if (n_levels) *n_levels = m.cfg.n_vq_strides;
+        if (level_widths)
+            for (int i = 0; i < m.cfg.n_vq_strides; ++i) level_widths[i] = Tz / m.cfg.vq_strides[i];
+        if (decoded_len) *decoded_len = m.decoded_len(Tz);
+    });
+}
+
+nc_status nc_snac_noise_len(const nc_codec* h, int32_t B, int64_t frames, int64_t* n) {
+    return guard([&] {
+        SnacModel& m = as_snac(const_cast<nc_codec*>(h));
+        if (!n || B <= 0 || frames <= 0) fail(NC_EINVAL, "bad arguments");
+        *n = m.noise_len(B, frames);
+    });
+}
+
+nc_status nc_snac_encode_dev(nc_codec* h, const float* pcm, int32_t B, int64_t T, int64_t* codes, float* z, float* zq) {
+    return guard([&] { as_snac(h).encode_dev(pcm, B, T, codes, z, zq); });
+}
+nc_status nc_snac_from_codes_dev(nc_codec* h, const int64_t* codes, int32_t B, int64_t frames, float* zq) {
+    return guard([&] { as_snac(h).from_codes_dev(codes, B, frames, zq); });
+}
+nc_status nc_snac_decode_dev(nc_codec* h, const int64_t* codes, int32_t B, int64_t frames, const float* noise, uint64_t seed,
+                             float* pcm) {
+    return guard([&] { as_snac(h).decode_dev(codes, B, frames, noise, seed, pcm); });
+}
+
+nc_status nc_snac_encode(nc_codec* h, const float* pcm, int32_t B, int64_t T, int64_t* codes, float* z, float* zq) {
+    return guard([&] {
+        SnacModel& m = as_snac(h);
+        if (!pcm || !codes) fail(NC_EINVAL, "pcm and codes must not be null");
+        if (B <= 0 || T <= 0) fail(NC_EINVAL, "B and T must be positive");
+        m.use_device();
+        const int64_t Tz = m.padded_len(T) / m.hop;
+        const size_t n_in = (size_t)B * T * 4, n_codes = (size_t)B * m.codes_per_clip(Tz) * 8, n_z = (size_t)B * m.latent * Tz * 4;
+        m.h_in.reserve(n_in); m.h_codes.reserve(n_codes); m.h_aux0.reserve(n_z); m.h_aux1.reserve(n_z);
+        h2d(m.h_in.p, pcm, n_in, m.stream);
+        m.encode_dev(m.h_in.as<float>(), B, T, m.h_codes.as<int64_t>(), m.h_aux0.as<float>(), m.h_aux1.as<float>());
+        d2h(codes, m.h_codes.p, n_codes, m.stream);
+        if (z) d2h(z, m.h_aux0.p, n_z, m.stream);
+        if (zq) d2h(zq, m.h_aux1.p, n_z, m.stream);
+        NC_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
+nc_status nc_snac_from_codes(nc_codec* h, const int64_t* codes, int32_t B, int64_t frames, float* zq) {
+    return guard([&] {
+        SnacModel& m = as_snac(h);
+        if (!codes || !zq) fail(NC_EINVAL, "codes and zq must not be null");
+        if (B <= 0 || frames <= 0) fail(NC_EINVAL, "B and frames must be positive");
+        m.use_device();
+        const size_t n_codes = (size_t)B * m.codes_per_clip(frames) * 8, n_z = (size_t)B * m.latent * frames * 4;
+        m.h_codes.reserve(n_codes); m.h_aux0.reserve(n_z);
+        h2d(m.h_codes.p, codes, n_codes, m.stream);
+        m.from_codes_dev(m.h_codes.as<int64_t>(), B, frames, m.h_aux0.as<float>());
+        d2h(zq, m.h_aux0.p, n_z, m.stream);
+        NC_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
+nc_status nc_snac_decode(nc_codec* h, const int64_t* codes, int32_t B, int64_t frames, const float* noise, uint64_t seed,
+                         float* pcm) {
+    return guard([&] {
+        SnacModel& m = as_snac(h);
+        if (!codes || !pcm) fail(NC_EINVAL, "codes and pcm must not be null");   // ArgumentNullException, SNAC.cs:175
+        if (B <= 0 || frames <= 0) fail(NC_EINVAL, "Codes list cannot be empty");   // ArgumentException, SNAC.cs:177-180
+        m.use_device();
+        const size_t n_codes = (size_t)B * m.codes_per_clip(frames) * 8, n_out = (size_t)B * m.decoded_len(frames) * 4;
+        const size_t n_noise = (size_t)m.noise_len(B, frames) * 4;
+        m.h_codes.reserve(n_codes); m.h_out.reserve(n_out);
+        h2d(m.h_codes.p, codes, n_codes, m.stream);
+        const float* nz = nullptr;
+        if (noise && n_noise) {
+            m.h_noise.reserve(n_noise);
+            h2d(m.h_noise.p, noise, n_noise, m.stream);
+            nz = m.h_noise.as<float>();
+        }
+        m.decode_dev(m.h_codes.as<int64_t>(), B, frames, nz, seed, m.h_out.as<float>());
+        d2h(pcm, m.h_out.p, n_out, m.stream);
         NC_HIP(hipStreamSynchronize(m.stream));
     });
 }

@@ -17,7 +17,7 @@
 
 namespace nc {
 
-enum : int { EPI_TANH = 1, EPI_RVQ = 2 };
+enum : int { EPI_TANH = 1, EPI_RVQ = 2, EPI_NOISE = 4 };
 
 struct ConvArgs {
     // input activations [B][Cin][x_len] (row stride x_cstride); positions outside [0,x_len) read as 0
@@ -35,6 +35,8 @@ struct ConvArgs {
     int64_t y_bstride, y_cstride;  // elements
     int32_t y_tstride, y_toff;     // t_out = col*y_tstride + y_toff + phase
     int32_t Tout;                  // stores outside [0,Tout) are dropped
+    const float* noise;            // EPI_NOISE: y = res + noise[b*noise_bstride + t] * conv   (NoiseBlock.cs:38-45)
+    int64_t noise_bstride;
     const float* w2;               // fused residual unit: packed 1x1 weights [row block][ci][32], bias2 [Cout]
     const float* bias2;
     float* rvq_zq;                 // EPI_RVQ: zq += out ; rvq_res -= out  (same geometry as y)
@@ -88,6 +90,7 @@ struct ConvIO {
     int64_t y_bstride = 0, y_cstride = 0;
     float* rvq_zq = nullptr;
     float* rvq_res = nullptr;
+    const float* noise = nullptr;  // EPI_NOISE multiplier [B,1,Tout]
     int epi = 0;
     const struct ConvLayer* fuse_k1 = nullptr;  // fused residual unit: the 1x1 layer applied to snake(alpha_out)(this conv) + res
 };

@@ -191,6 +191,8 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     a.alpha_out = io.alpha_out; a.res = io.res;
     a.y = io.y; a.y_bstride = io.y_bstride; a.y_cstride = io.y_cstride;
     a.rvq_zq = io.rvq_zq; a.rvq_res = io.rvq_res;
+    a.noise = io.noise; a.noise_bstride = L.out_len(io.Tin);
+    if ((io.epi & EPI_NOISE) && (!io.noise || !io.res)) fail(NC_ESTATE, "internal: noise epilogue needs noise and residual");
     a.Cout = L.Cout; a.B = B; a.epi = io.epi;
     a.Tout = (int32_t)Tout;
     int sx;  // x step per output column

@@ -272,7 +272,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
                 if (col >= p.n_cols || t < 0 || t >= p.Tout) continue;
                 const int64_t o = ybase + (int64_t)co * p.y_cstride + t;
                 float val = v[j][r] + bias;
-                if (res_p) val = val + res_p[o];
+                if (p.epi & EPI_NOISE) val = res_p[o] + p.noise[(int64_t)b * p.noise_bstride + t] * val;
+                else if (res_p) val = val + res_p[o];
                 if (ao_p) val = nc_snakef(val, ao, ao_inv);
                 if (p.epi & EPI_TANH) val = nc_tanhf(val);
                 if (p.epi & EPI_RVQ) {

@@ -1,0 +1,233 @@
+// HBM-bound kernels of the codec path that are not dense contractions: depthwise k-tap convolution (SNAC), average pooling and
+// repeat-interleave RVQ update (SNAC multi-rate quantizer), LayerNorm + windowed rotary attention (SNAC LocalMHA), noise source.
+//
+// Reference call sites (under NeuralCodecs.Torch/):
+//   depthwise conv   Modules/SNAC/ResidualUnit.cs:32 (groups == dim), Encoder.cs:55-62, Decoder.cs:45
+//   avg_pool1d       Modules/SNAC/VectorQuantizer.cs:88 ; repeat_interleave  VectorQuantizer.cs:100, ResidualVectorQuantizer.cs:120
+//   LayerNorm / SDPA Modules/SNAC/LocalMHA.cs:85,105 ; rotary  RotaryEmbedding.cs:46-68 ; randn  NoiseBlock.cs:41
+// Arithmetic is the canonical arithmetic of DESIGN.md (same sequences as oracle/c/nc_ref_snac.c).
+#include "nc_elem.h"
+#include "nc_math.h"
+
+namespace nc {
+
+// ---------------------------------------------------------------------------------------------- depthwise conv
+// y[b,c,t] = (chain_k w[c,k] * snake_in(x[b,c,t + k*dil - pad])) + bias[c]  [-> snake_out]
+// One block = one (clip, channel) row segment of DW_TT outputs; the activated input window lives in LDS.
+constexpr int DW_TT = 2048;
+constexpr int DW_MAXK = 7;
+
+__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, const float* __restrict__ alpha_in,
+                                                     const float* __restrict__ alpha_out, float* __restrict__ y, int C, int T,
+                                                     int K, int dil, int pad) {
+    extern __shared__ float win[];
+    const int tile = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+    const int t0 = tile * DW_TT;
+    const int span = DW_TT + (K - 1) * dil;
+    const float* xr = x + ((int64_t)b * C + c) * T;
+    const float ai = alpha_in ? alpha_in[c] : 0.0f;
+    const float ai_inv = nc_snake_inv(ai);
+    for (int j = threadIdx.x; j < span; j += 256) {
+        const int gp = t0 - pad + j;
+        float v = (gp >= 0 && gp < T) ? xr[gp] : 0.0f;
+        if (alpha_in) v = nc_snakef(v, ai, ai_inv);
+        win[j] = v;
+    }
+    __syncthreads();
+    float wk[DW_MAXK];
+#pragma unroll
+    for (int k = 0; k < DW_MAXK; ++k) wk[k] = k < K ? w[c * K + k] : 0.0f;
+    const float bv = bias ? bias[c] : 0.0f;
+    const float ao = alpha_out ? alpha_out[c] : 0.0f;
+    const float ao_inv = nc_snake_inv(ao);
+    float* yr = y + ((int64_t)b * C + c) * T;
+#pragma unroll
+    for (int i = 0; i < DW_TT / 256; ++i) {
+        const int lt = threadIdx.x + 256 * i;
+        const int t = t0 + lt;
+        if (t >= T) break;
+        float a = 0.0f;
+#pragma unroll
+        for (int k = 0; k < DW_MAXK; ++k)
+            if (k < K) a = nc_fma(wk[k], win[lt + k * dil], a);
+        float v = a + bv;
+        if (alpha_out) v = nc_snakef(v, ao, ao_inv);
+        yr[t] = v;
+    }
+}
+
+void launch_dwconv(const DwConvLayer& L, const float* x, const float* alpha_in, const float* alpha_out, float* y, int B, int64_t T,
+                   hipStream_t s, Profiler* prof) {
+    if (L.K > DW_MAXK) fail(NC_EUNSUPPORTED, "depthwise kernel size %d > %d", L.K, DW_MAXK);
+    const size_t lds = sizeof(float) * (DW_TT + (L.K - 1) * L.dil);
+    dim3 grid((unsigned)((T + DW_TT - 1) / DW_TT), (unsigned)L.C, (unsigned)B);
+    if (prof && prof->on) prof->begin(s, NC_KC_ELEM, 2.0 * L.K * L.C * (double)T * B, 8.0 * L.C * (double)T * B);
+    hipLaunchKernelGGL(dwconv_kernel, grid, dim3(256), lds, s, x, L.w.as<float>(), L.has_bias ? L.bias.as<float>() : nullptr,
+                       alpha_in, alpha_out, y, L.C, (int)T, L.K, L.dil, L.pad);
+    NC_HIP(hipGetLastError());
+    if (prof && prof->on) prof->end(s);
+}
+
+void DwConvLayer::build(const float* dense_w, const float* bias_h, int C_, int K_, int pad_, int dil_) {
+    C = C_; K = K_; pad = pad_; dil = dil_;
+    w.reserve(sizeof(float) * C * K);
+    NC_HIP(hipMemcpy(w.p, dense_w, sizeof(float) * C * K, hipMemcpyHostToDevice));
+    has_bias = bias_h != nullptr;
+    if (has_bias) {
+        bias.reserve(sizeof(float) * C);
+        NC_HIP(hipMemcpy(bias.p, bias_h, sizeof(float) * C, hipMemcpyHostToDevice));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- avg_pool1d(s)
+__global__ void avg_pool_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int64_t T, int s) {
+    const int64_t Ts = T / s;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * Ts) return;
+    const int64_t r = i / Ts, t = i - r * Ts;
+    const float* xp = x + r * T + t * s;
+    float a = xp[0];
+    for (int j = 1; j < s; ++j) a = a + xp[j];
+    y[i] = a / (float)s;
+}
+void launch_avg_pool(const float* x, float* y, int64_t rows, int64_t T, int s, hipStream_t st) {
+    const int64_t n = rows * (T / s);
+    hipLaunchKernelGGL(avg_pool_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, rows, T, s);
+    NC_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ zq (+)= repeat_interleave(q, s) ; residual -= ...
+__global__ void rvq_update_kernel(const float* __restrict__ q, float* __restrict__ zq, float* __restrict__ residual, int64_t rows,
+                                  int64_t T, int s, int first) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * T) return;
+    const int64_t r = i / T, t = i - r * T;
+    const float qv = q[r * (T / s) + t / s];
+    zq[i] = first ? qv : zq[i] + qv;
+    if (residual) residual[i] = residual[i] - qv;
+}
+void launch_rvq_update(const float* q, float* zq, float* residual, int64_t rows, int64_t T, int s, bool first, hipStream_t st) {
+    const int64_t n = rows * T;
+    hipLaunchKernelGGL(rvq_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, q, zq, residual, rows, T, s,
+                       first ? 1 : 0);
+    NC_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------- LayerNorm over C
+// x, y in [B,C,T] layout; one thread per (b,t), sequential binary64 sums over c (the canonical order).
+__global__ void layernorm_ct_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    float* __restrict__ y, int B, int C, int64_t T) {
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= (int64_t)B * T) return;
+    const int64_t b = i / T, t = i - b * T;
+    const float* xp = x + b * C * T + t;
+    double s1 = 0.0;
+    for (int c = 0; c < C; ++c) s1 += (double)xp[(int64_t)c * T];
+    const double mu = s1 / C;
+    double s2 = 0.0;
+    for (int c = 0; c < C; ++c) {
+        const double d = (double)xp[(int64_t)c * T] - mu;
+        s2 += d * d;
+    }
+    const float r = (float)(1.0 / sqrt(s2 / C + 1e-5));
+    const float muf = (float)mu;
+    float* yp = y + b * C * T + t;
+    for (int c = 0; c < C; ++c) yp[(int64_t)c * T] = ((xp[(int64_t)c * T] - muf) * r) * gamma[c] + beta[c];
+}
+void launch_layernorm_ct(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int64_t T, hipStream_t st) {
+    const int64_t n = (int64_t)B * T;
+    hipLaunchKernelGGL(layernorm_ct_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, x, gamma, beta, y, B, C, T);
+    NC_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------- windowed rotary attention
+// qkv [B,3C,T] (channel = part*C + head*64 + d) -> out [B,C,T]; one block per (window, head, clip), thread i = query i.
+// cos/sin tables [W][64] come from the host (binary64 libm, rounded once).
+constexpr int ATT_D = 64, ATT_W = 32;
+__global__ __launch_bounds__(64) void local_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ cs,
+                                                        const float* __restrict__ sn, float* __restrict__ out, int C, int64_t T,
+                                                        int W) {
+    __shared__ float ks[ATT_W][ATT_D + 1], vs[ATT_W][ATT_D + 1];
+    const int wdx = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int i = threadIdx.x;
+    const float* base = qkv + (int64_t)b * 3 * C * T;
+    const int64_t t = (int64_t)wdx * W + i;
+    float q[ATT_D];
+    if (i < W) {
+#pragma unroll
+        for (int d = 0; d < ATT_D; ++d) {
+            const int dr = d < 32 ? d + 32 : d - 32;
+            const float qv = base[(int64_t)(h * 64 + d) * T + t], qr = base[(int64_t)(h * 64 + dr) * T + t];
+            const float kv = base[(int64_t)(C + h * 64 + d) * T + t], kr = base[(int64_t)(C + h * 64 + dr) * T + t];
+            const float c = cs[i * 64 + d], s = sn[i * 64 + d];
+            q[d] = (qv * c) + ((d < 32 ? -qr : qr) * s);
+            ks[i][d] = (kv * c) + ((d < 32 ? -kr : kr) * s);
+            vs[i][d] = base[(int64_t)(2 * C + h * 64 + d) * T + t];
+        }
+    }
+    __syncthreads();
+    if (i >= W) return;
+    float s[ATT_W];
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int j = 0; j < ATT_W; ++j) {
+        if (j < W) {
+            float a = 0.0f;
+#pragma unroll
+            for (int d = 0; d < ATT_D; ++d) a = nc_fma(q[d], ks[j][d], a);
+            s[j] = a * 0.125f;
+            if (s[j] > mx) mx = s[j];
+        }
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < ATT_W; ++j)
+        if (j < W) {
+            s[j] = nc_expf(s[j] - mx);
+            sum = sum + s[j];
+        }
+#pragma unroll
+    for (int j = 0; j < ATT_W; ++j)
+        if (j < W) s[j] = s[j] / sum;
+    float* op = out + ((int64_t)b * C + h * 64) * T + t;
+#pragma unroll 4
+    for (int d = 0; d < ATT_D; ++d) {
+        float a = 0.0f;
+#pragma unroll
+        for (int j = 0; j < ATT_W; ++j)
+            if (j < W) a = nc_fma(s[j], vs[j][d], a);
+        op[(int64_t)d * T] = a;
+    }
+}
+void launch_local_attn(const float* qkv, const float* cs, const float* sn, float* out, int B, int C, int64_t T, int W,
+                       hipStream_t st) {
+    if (W > ATT_W || W <= 0 || T % W != 0 || C % 64 != 0) fail(NC_EUNSUPPORTED, "local attention: window %d / dim %d not supported", W, C);
+    hipLaunchKernelGGL(local_attn_kernel, dim3((unsigned)(T / W), (unsigned)(C / 64), (unsigned)B), dim3(64), 0, st, qkv, cs, sn, out,
+                       C, T, W);
+    NC_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------- N(0,1) source (NoiseBlock)
+// The reference draws torch.randn at inference (NoiseBlock.cs:41): not reproducible by construction.  When the caller does not
+// inject the noise we draw it from a counter-based generator (SplitMix64 -> Box-Muller), deterministic in (seed, element index).
+__device__ inline uint64_t nc_splitmix(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void randn_kernel(float* __restrict__ out, int64_t n, uint64_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t r = nc_splitmix(seed * 0xD1342543DE82EF95ull + (uint64_t)i);
+    const float u1 = ((float)((r >> 40) + 1)) * (1.0f / 16777217.0f);  // (0,1]
+    const float u2 = ((float)((r >> 16) & 0xFFFFFF)) * (1.0f / 16777216.0f);
+    out[i] = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+void launch_randn(float* out, int64_t n, uint64_t seed, hipStream_t st) {
+    hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n, seed);
+    NC_HIP(hipGetLastError());
+}
+
+}  // namespace nc

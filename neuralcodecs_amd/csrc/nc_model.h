@@ -4,11 +4,13 @@
 
 #include "nc_common.h"
 #include "nc_conv.h"
+#include "nc_elem.h"
 
 namespace nc {
 
 const char* get_last_error();
 void fold_weight_norm_dac(const float* v, const float* g, int64_t d0, int64_t inner, float* w);
+void fold_weight_norm_snac(const float* v, const float* g, int64_t d0, int64_t inner, float* w);
 
 // ---- RVQ kernels (nc_rvq.hip) ----------------------------------------------------------------
 // Codebook resident on the device in the two layouts the kernels want.
@@ -84,6 +86,68 @@ struct DacModel : Codec {
 
   private:
     float* run_res_unit(ResUnit& ru, int dil, float* cur, int C, int64_t L, int B, int& cur_idx);
+};
+
+struct SnacModel : Codec {
+    nc_snac_config cfg{};
+    int latent = 0, hop = 1;
+    int64_t pad_to = 1;
+
+    struct ResUnit {
+        DevBuf a1, a2;
+        DwConvLayer dw;   // depthwise flavour
+        ConvLayer c7;     // dense flavour (depthwise == 0)
+        ConvLayer c1;
+    };
+    struct Mha {
+        int C = 0;
+        DevBuf gamma, beta, cs, sn;
+        ConvLayer qkv, out;
+    };
+    ConvLayer enc_stem;
+    struct EncBlk {
+        ResUnit ru[3];
+        DevBuf a_down;
+        ConvLayer down;
+    } enc[8];
+    Mha enc_mha, dec_mha;
+    DwConvLayer enc_out_dw, dec_in_dw;
+    ConvLayer enc_out, dec_in;
+
+    std::vector<std::unique_ptr<ConvLayer>> in_proj, out_proj;
+    std::vector<std::unique_ptr<Codebook>> codebooks;
+
+    struct DecBlk {
+        DevBuf a_up;
+        ConvLayer up, noise;
+        ResUnit ru[3];
+    } dec[8];
+    DevBuf dec_alpha_out;
+    ConvLayer dec_out;
+
+    DevBuf act[3], resid, zq, pooled, qbuf, lat, st, qkv_ws, noise_ws, h_in, h_out, h_codes, h_aux0, h_aux1, h_noise;
+
+    explicit SnacModel(const nc_snac_config& c);
+    void load(const Blob& blob) override;
+    int64_t padded_len(int64_t T) const { return (T + pad_to - 1) / pad_to * pad_to; }
+    static int64_t up_len(int64_t L, int s) { return (L - 1) * s - 2 * ((s + 1) / 2) + 2 * s + (s % 2); }
+    int64_t decoded_len(int64_t frames) const;
+    int64_t noise_len(int B, int64_t frames) const;
+    int64_t codes_per_clip(int64_t frames) const {
+        int64_t n = 0;
+        for (int i = 0; i < cfg.n_vq_strides; ++i) n += frames / cfg.vq_strides[i];
+        return n;
+    }
+    void encode_dev(const float* pcm, int B, int64_t T, int64_t* codes, float* z, float* zq);
+    void from_codes_dev(const int64_t* codes, int B, int64_t frames, float* zq);
+    void decode_dev(const int64_t* codes, int B, int64_t frames, const float* noise, uint64_t seed, float* pcm);
+
+  private:
+    void load_res_unit(const Blob& b, const std::string& q, ResUnit& ru, int C, int dil);
+    void load_mha(const Blob& b, const std::string& p, Mha& m, int C);
+    float* run_res_unit(ResUnit& ru, float* cur, int C, int64_t L, int B, int& cur_idx);
+    float* run_mha(Mha& m, float* cur, int C, int64_t L, int B, int& cur_idx);
+    void reserve_act(int B, int64_t Tp);
 };
 
 }  // namespace nc

@@ -1,0 +1,114 @@
+"""GPU suite: SNAC Encode / FromCodes / Decode through the C ABI against the C oracle (bit for bit) and the golden vectors."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from conftest import audit_snac_levels, load_golden, snac_cfg_from_meta  # noqa: E402
+from neuralcodecs_amd import SNAC  # noqa: E402
+from neuralcodecs_amd.weights import save_blob, snac_noise, snac_synthetic_state_dict, synthetic_pcm  # noqa: E402
+from oracle import c_oracle  # noqa: E402
+
+PCM_TOL, LATENT_TOL, GAP_TOL = 1e-4, 3e-5, 1e-4
+
+
+def _setup(name):
+    g = load_golden(name)
+    cfg = snac_cfg_from_meta(g["meta"])
+    blob = save_blob(snac_synthetic_state_dict(cfg, seed=g["meta"]["weight_seed"]))
+    m = SNAC(cfg)
+    m.load_blob(blob)
+    return g, cfg, m, c_oracle.RefSNAC(cfg, blob)
+
+
+@pytest.mark.parametrize("name", ["snac_small", "snac_small_attn"])
+def test_snac_small_vs_golden_and_oracle(name):
+    g, cfg, m, ref = _setup(name)
+    meta = g["meta"]
+    codes, z, zq = m.encode(g["pcm"], return_latents=True)
+    rz, rzq, rcodes = ref.encode(g["pcm"])
+    assert all(c.dtype == np.int64 for c in codes)
+    for a, b in zip(codes, rcodes):
+        assert np.array_equal(a, b)                                   # bit-exact codes vs the C oracle
+    assert np.array_equal(z, rz) and np.array_equal(zq, rzq)
+    assert np.abs(z - g["z"]).max() < LATENT_TOL
+    if audit_snac_levels(codes, g, GAP_TOL) == 0:
+        assert np.abs(zq - g["zq"]).max() < LATENT_TOL
+    Tz = z.shape[-1]
+    noises = snac_noise(cfg, meta["B"], Tz, seed=meta["noise_seed"])
+    gold_codes = [g[f"codes{i}"].astype(np.int64) for i in range(len(cfg.vq_strides))]
+    audio = m.decode(gold_codes, noises)
+    assert np.array_equal(audio, ref.decode(gold_codes, noises))
+    assert np.abs(audio - g["audio"]).max() < PCM_TOL
+    assert np.array_equal(m.from_codes(gold_codes), ref.from_codes(gold_codes))
+    m.dispose()
+
+
+def test_snac24k_full_size_config_c1():
+    """BASELINE config C1 (SNAC 24 kHz mono, 1 s clip) plus a second clip: codes 12/24/48 per clip."""
+    g, cfg, m, ref = _setup("snac24k_b1")
+    meta = g["meta"]
+    pcm = synthetic_pcm(2, 1, meta["T"], cfg.sampling_rate, seed=meta["pcm_seed"])
+    codes, z, zq = m.encode(pcm, return_latents=True)
+    assert [c.shape for c in codes] == [(2, 12), (2, 24), (2, 48)]
+    rz, rzq, rcodes = ref.encode(pcm)
+    for a, b in zip(codes, rcodes):
+        assert np.array_equal(a, b)
+    assert np.array_equal(zq, rzq)
+    if audit_snac_levels([c[:1] for c in codes], g, GAP_TOL) == 0:
+        assert np.abs(zq[:1, ::16, :] - g["zq_slice"]).max() < LATENT_TOL
+    noises = snac_noise(cfg, 2, 48, seed=meta["noise_seed"])
+    audio = m.decode(codes, noises)
+    assert audio.shape == (2, 1, 24576)
+    assert np.array_equal(audio, ref.decode(rcodes, noises))
+    gold_codes = [g[f"codes{i}"].astype(np.int64) for i in range(3)]
+    a1 = m.decode(gold_codes, snac_noise(cfg, 1, 48, seed=meta["noise_seed"]))
+    assert np.abs(a1[:, :, ::17] - g["audio_slice"]).max() < PCM_TOL
+    m.dispose()
+
+
+def test_snac_api_shapes_errors_and_noise_source():
+    g, cfg, m, ref = _setup("snac_small")
+    pcm = g["pcm"]
+    # SNACValidator.ValidateModel contract (Config/SNAC/SNACValidator.cs:95-111): #codebooks, 3-D output, ~input length
+    codes = m.encode(pcm)
+    assert len(codes) == len(cfg.vq_strides)
+    audio, codes2 = m.forward(pcm, seed=5)
+    assert audio.shape == pcm.shape and all(np.array_equal(a, b) for a, b in zip(codes, codes2))
+    # device noise source: deterministic in the seed, different across seeds, and actually used
+    a5 = m.decode(codes, seed=5); a5b = m.decode(codes, seed=5); a6 = m.decode(codes, seed=6)
+    assert np.array_equal(a5, a5b) and not np.array_equal(a5, a6)
+    # float[] overloads
+    fl = m.encode_array(pcm[0, 0])
+    assert all(c.dtype == np.float32 for c in fl) and np.array_equal(fl[2].astype(np.int64), codes[2][0])
+    nz = snac_noise(cfg, 1, codes[-1].shape[-1] * cfg.vq_strides[-1], seed=1)
+    assert np.array_equal(m.decode_array(fl, nz), m.decode([c[:1] for c in codes], nz).reshape(-1))
+    with pytest.raises(ValueError):
+        m.decode(codes[:2])                                            # ArgumentException: wrong number of codebooks
+    with pytest.raises(ValueError):
+        m.decode_array([])
+    with pytest.raises(ValueError):
+        m.encode(None)
+    fresh = SNAC(cfg)
+    with pytest.raises(RuntimeError):
+        fresh.encode(pcm)
+    fresh.dispose()
+    out = m.process_audio(pcm[0, 0], cfg.sampling_rate // 2, seed=3)      # resample x2 then forward
+    assert out.shape[0] == 2 * pcm.shape[-1]
+    m.dispose()
+
+
+def test_snac_device_tensor_api_and_batch_invariance():
+    import torch
+    g, cfg, m, ref = _setup("snac_small_attn")
+    pcm = synthetic_pcm(3, 1, 2100, cfg.sampling_rate, seed=21)
+    codes = m.encode(pcm)
+    one = m.encode(pcm[1:2])
+    assert all(np.array_equal(a[1:2], b) for a, b in zip(codes, one))
+    dc = m.encode(torch.from_numpy(pcm).cuda())
+    nz = snac_noise(cfg, 3, codes[-1].shape[-1], seed=2)
+    da = m.decode(dc, [torch.from_numpy(n).cuda() for n in nz])
+    torch.cuda.synchronize()
+    assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(dc, codes))
+    assert np.array_equal(da.cpu().numpy(), m.decode(codes, nz))
+    m.dispose()
