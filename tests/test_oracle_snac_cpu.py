@@ -54,3 +54,20 @@ def test_snac_pad_rule_and_noise_requirement():
     assert c_oracle.lib().ref_snac_padded_length(ref._h, 2500) == 3072
     with pytest.raises(ValueError):
         ref.decode_latents(np.zeros((1, cfg.resolved_latent_dim, 8), np.float32))      # D8: noise must be injected
+
+
+def test_c_oracle_snac44k_with_local_attention():
+    """Full-width SNAC 44.1 kHz (54.5 M parameters, LocalMHA dim 1024 / 1536, stride-3 stage with output_padding) on a short
+    clip: 20000 samples -> padded 24576 (= 2 * 12288), T' = 64 = two attention windows, codes 8/16/32/64."""
+    g = load_golden("snac44k_short")
+    meta = g["meta"]
+    cfg = snac_cfg_from_meta(meta)
+    ref = c_oracle.RefSNAC(cfg, save_blob(snac_synthetic_state_dict(cfg, seed=meta["weight_seed"])))
+    pcm = synthetic_pcm(1, 1, meta["T"], cfg.sampling_rate, seed=meta["pcm_seed"])
+    z, zq, codes = ref.encode(pcm)
+    assert [c.shape for c in codes] == [(1, 8), (1, 16), (1, 32), (1, 64)]
+    if audit_snac_levels(codes, g, GAP_TOL) == 0:
+        assert np.abs(zq[:, ::16, :] - g["zq_slice"]).max() < LATENT_TOL
+    gold_codes = [g[f"codes{i}"].astype(np.int64) for i in range(4)]
+    audio = ref.decode(gold_codes, snac_noise(cfg, 1, 64, seed=meta["noise_seed"]))
+    assert np.abs(audio[:, :, ::17] - g["audio_slice"]).max() < PCM_TOL

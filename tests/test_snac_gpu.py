@@ -112,3 +112,34 @@ def test_snac_device_tensor_api_and_batch_invariance():
     assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(dc, codes))
     assert np.array_equal(da.cpu().numpy(), m.decode(codes, nz))
     m.dispose()
+
+
+def test_snac44k_attention_full_width_config_c5_shape():
+    """BASELINE config C5 model (SNAC 44.1 kHz, LocalMHA window 32): golden short clip + one full 5 s clip vs the C oracle."""
+    g, cfg, m, ref = _setup("snac44k_short")
+    meta = g["meta"]
+    pcm = synthetic_pcm(2, 1, meta["T"], cfg.sampling_rate, seed=meta["pcm_seed"])
+    codes, z, zq = m.encode(pcm, return_latents=True)
+    rz, rzq, rcodes = ref.encode(pcm)
+    assert [c.shape for c in codes] == [(2, 8), (2, 16), (2, 32), (2, 64)]
+    for a, b in zip(codes, rcodes):
+        assert np.array_equal(a, b)
+    assert np.array_equal(z, rz) and np.array_equal(zq, rzq)
+    if audit_snac_levels([c[:1] for c in codes], g, GAP_TOL) == 0:
+        assert np.abs(zq[:1, ::16, :] - g["zq_slice"]).max() < LATENT_TOL
+    nz = snac_noise(cfg, 2, 64, seed=meta["noise_seed"])
+    audio = m.decode(codes, nz)
+    assert np.array_equal(audio, ref.decode(rcodes, nz))
+    gold_codes = [g[f"codes{i}"].astype(np.int64) for i in range(4)]
+    a1 = m.decode(gold_codes, snac_noise(cfg, 1, 64, seed=meta["noise_seed"]))
+    assert np.abs(a1[:, :, ::17] - g["audio_slice"]).max() < PCM_TOL
+    # one 5 s clip: 220500 -> padded 221184 = 18 * 12288, T' = 576 (18 windows), codes 72/144/288/576
+    pcm5 = synthetic_pcm(1, 1, 220500, cfg.sampling_rate, seed=8)
+    c5 = m.encode(pcm5)
+    assert [c.shape for c in c5] == [(1, 72), (1, 144), (1, 288), (1, 576)]
+    _, _, r5 = ref.encode(pcm5)
+    for a, b in zip(c5, r5):
+        assert np.array_equal(a, b)
+    nz5 = snac_noise(cfg, 1, 576, seed=9)
+    assert np.array_equal(m.decode(c5, nz5), ref.decode(r5, nz5))
+    m.dispose()
