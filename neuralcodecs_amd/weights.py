@@ -28,7 +28,7 @@ from typing import Dict, Iterable, List, Tuple
 
 import numpy as np
 
-from .config import DACConfig, SNACConfig
+from .config import DACConfig, EncodecConfig, SNACConfig
 
 MAGIC = b"NCWB0001"
 _DT = {np.dtype(np.float32): 0, np.dtype(np.int64): 1}
@@ -317,6 +317,75 @@ def snac_noise(cfg: SNACConfig, batch: int, frames: int, seed: int = 99):
         T = (T - 1) * s - 2 * (-(-s // 2)) + 2 * s + (s % 2)
         out.append(approx_normal(seed + bi, "snac.noise", batch * T).astype(np.float32).reshape(batch, 1, T))
     return out
+
+
+def _enc_conv(sd, seed, cfg, prefix, shape, fan_in, gain, n_out):
+    """One SConv1d / SConvTranspose1d parameter set (Modules/Encodec/SConv1d.cs:110-128): plain conv + GroupNorm affine for
+    norm == time_group_norm, weight_v / weight_g for weight_norm."""
+    if cfg.norm == "time_group_norm":
+        n = int(np.prod(shape))
+        sd[prefix + ".conv.weight"] = (approx_normal(seed, prefix + ".conv.weight", n) * (gain / np.sqrt(fan_in))
+                                       ).astype(np.float32).reshape(shape)
+        sd[prefix + ".conv.bias"] = ((uniform01(seed, prefix + ".conv.bias", n_out) * 2.0 - 1.0) * (0.5 / np.sqrt(fan_in))
+                                     ).astype(np.float32)
+        sd[prefix + ".norm.weight"] = (0.8 + 0.4 * uniform01(seed, prefix + ".norm.weight", n_out)).astype(np.float32)
+        sd[prefix + ".norm.bias"] = (approx_normal(seed, prefix + ".norm.bias", n_out) * 0.05).astype(np.float32)
+    else:
+        tmp: "OrderedDict[str, np.ndarray]" = OrderedDict()
+        _wn_pair(tmp, seed, prefix + ".conv", shape, fan_in, gain, bias_len=n_out)
+        sd[prefix + ".conv.weight_v"] = tmp[prefix + ".conv.weight_v"]
+        sd[prefix + ".conv.weight_g"] = tmp[prefix + ".conv.weight_g"].reshape(shape[0], 1, 1)
+        sd[prefix + ".conv.bias"] = tmp[prefix + ".conv.bias"]
+
+
+def encodec_synthetic_state_dict(cfg: EncodecConfig, seed: int = 42) -> "OrderedDict[str, np.ndarray]":
+    """Seeded synthetic Encodec weights under the reference's TorchSharp key names (SEANetEncoder.cs:37-148,
+    SEANetDecoder.cs:40-153, SLSTM.cs:31, EuclideanCodebook.cs:60-66)."""
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    nf, dim = cfg.n_filters, cfg.dimension
+    rk = cfg.residual_kernel_size
+
+    def resblock(p, d):
+        h = d // cfg.compress
+        _enc_conv(sd, seed, cfg, p + ".block.1", (h, d, rk), d * rk, 1.0, h)
+        _enc_conv(sd, seed, cfg, p + ".block.3", (d, h, 1), h, 0.6, d)
+        _enc_conv(sd, seed, cfg, p + ".shortcut", (d, d, 1), d, 0.8, d)
+
+    def lstm(p, d):
+        bound = 1.0 / np.sqrt(d)
+        for l in range(cfg.lstm_layers):
+            for nm, shape in (("weight_ih", (4 * d, d)), ("weight_hh", (4 * d, d)), ("bias_ih", (4 * d,)), ("bias_hh", (4 * d,))):
+                k = f"{p}.lstm.{nm}_l{l}"
+                sd[k] = ((uniform01(seed, k, int(np.prod(shape))) * 2.0 - 1.0) * bound).astype(np.float32).reshape(shape)
+
+    _enc_conv(sd, seed, cfg, "encoder.layers.0", (nf, cfg.channels, cfg.kernel_size), cfg.channels * cfg.kernel_size, 1.5, nf)
+    n, mult = 1, 1
+    for r in reversed(cfg.ratios):
+        d = mult * nf
+        resblock(f"encoder.layers.{n}", d)
+        _enc_conv(sd, seed, cfg, f"encoder.layers.{n + 2}", (2 * d, d, 2 * r), d * 2 * r, 1.0, 2 * d)
+        n += 3
+        mult *= 2
+    lstm(f"encoder.layers.{n}", mult * nf)
+    _enc_conv(sd, seed, cfg, f"encoder.layers.{n + 2}", (dim, mult * nf, cfg.last_kernel_size), mult * nf * cfg.last_kernel_size, 1.0, dim)
+    import math
+    n_q = int(1000 * max(cfg.target_bandwidths) / (math.ceil(cfg.sampling_rate / cfg.hop_length) * 10))
+    for i in range(n_q):
+        k = f"quantizer.layers.{i}.codebook.embed"
+        sd[k] = (approx_normal(seed, k, cfg.codebook_size * dim) * (0.9 * 0.75 ** i)).astype(np.float32).reshape(cfg.codebook_size, dim)
+    _enc_conv(sd, seed, cfg, "decoder.layers.0", (mult * nf, dim, cfg.kernel_size), dim * cfg.kernel_size, 1.0, mult * nf)
+    lstm("decoder.layers.1", mult * nf)
+    n = 2
+    for r in cfg.ratios:
+        d = mult * nf
+        # conv-transpose weight [Cin, Cout, K]; each output sample sees K/stride = 2 taps per input channel
+        _enc_conv(sd, seed, cfg, f"decoder.layers.{n + 1}", (d, d // 2, 2 * r), d * 2, 1.0, d // 2)
+        resblock(f"decoder.layers.{n + 2}", d // 2)
+        n += 3
+        mult //= 2
+    _enc_conv(sd, seed, cfg, f"decoder.layers.{n + 1}", (cfg.channels, nf, cfg.last_kernel_size), nf * cfg.last_kernel_size, 0.5,
+              cfg.channels)
+    return sd
 
 
 def _parabolic_sine(phase_num: np.ndarray, denom: int) -> np.ndarray:

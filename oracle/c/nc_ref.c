@@ -197,7 +197,7 @@ REF_API void ref_vq_argmin(const float* z_e, int64_t B, int D, int64_t T, const 
 #pragma omp parallel for collapse(2) schedule(static)
     for (int64_t b = 0; b < B; b++)
         for (int64_t t = 0; t < T; t++) {
-            float e[64];
+            float e[256];
             float e2 = 0.0f;
             for (int d = 0; d < D; d++) { e[d] = z_e[((int64_t)b * D + d) * T + t]; e2 = fmaf(e[d], e[d], e2); }
             float best = INFINITY;

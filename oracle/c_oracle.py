@@ -33,6 +33,13 @@ class RefSnacConfig(C.Structure):
                 ("vq_strides", C.c_int * 8), ("noise", C.c_int), ("depthwise", C.c_int)]
 
 
+class RefEncodecConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_int), ("channels", C.c_int), ("dimension", C.c_int), ("n_filters", C.c_int), ("n_ratios", C.c_int),
+                ("ratios", C.c_int * 8), ("lstm_layers", C.c_int), ("compress", C.c_int), ("kernel_size", C.c_int),
+                ("last_kernel_size", C.c_int), ("residual_kernel_size", C.c_int), ("group_norm", C.c_int), ("causal", C.c_int),
+                ("normalize", C.c_int), ("codebook_size", C.c_int), ("n_q_total", C.c_int)]
+
+
 class RefDacConfig(C.Structure):
     _fields_ = [("sample_rate", C.c_int), ("encoder_dim", C.c_int), ("n_enc_rates", C.c_int), ("enc_rates", C.c_int * 8),
                 ("decoder_dim", C.c_int), ("n_dec_rates", C.c_int), ("dec_rates", C.c_int * 8), ("latent_dim", C.c_int),
@@ -71,6 +78,16 @@ def lib():
         L.ref_snac_from_codes.argtypes = [C.c_void_p, i64p, C.c_int64, C.c_int64, f32p]
         L.ref_snac_decode.argtypes = [C.c_void_p, f32p, C.c_int64, C.c_int64, C.c_void_p, f32p]
         L.ref_fold_wn_snac.argtypes = [f32p, f32p, C.c_int64, C.c_int64, f32p]
+        L.ref_encodec_create.restype = C.c_void_p
+        L.ref_encodec_create.argtypes = [C.POINTER(RefEncodecConfig), C.c_char_p, C.c_int64]
+        L.ref_encodec_destroy.argtypes = [C.c_void_p]
+        for f in ("ref_encodec_frames", "ref_encodec_decoded_length"):
+            getattr(L, f).restype = C.c_int64
+            getattr(L, f).argtypes = [C.c_void_p, C.c_int64]
+        L.ref_encodec_encode_frame.argtypes = [C.c_void_p, f32p, C.c_int64, C.c_int64, C.c_int, i64p, C.c_void_p, C.c_void_p]
+        L.ref_encodec_decode_frame.argtypes = [C.c_void_p, i64p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, f32p, C.c_void_p]
+        L.ref_linear_overlap_add.argtypes = [f32p, i64p, i64p, C.c_int, C.c_int64, C.c_int64, f32p, C.c_int64]
+        L.ref_group_norm1.argtypes = [f32p, C.c_int64, C.c_int, C.c_int64, f32p, f32p, f32p]
         _lib = L
     return _lib
 
@@ -256,3 +273,102 @@ class RefSNAC:
 
     def decode(self, codes, noises=None):
         return self.decode_latents(self.from_codes(codes), noises)
+
+
+class RefEncodec:
+    """C-oracle Encodec (call surface of the reference's Encodec.Encode / Decode: a list of (codes, scale) frames)."""
+
+    def __init__(self, cfg, blob: bytes):
+        import math
+        rc = RefEncodecConfig()
+        rc.sample_rate, rc.channels, rc.dimension, rc.n_filters = cfg.sampling_rate, cfg.channels, cfg.dimension, cfg.n_filters
+        rc.n_ratios = len(cfg.ratios)
+        for i, r in enumerate(cfg.ratios): rc.ratios[i] = r
+        rc.lstm_layers, rc.compress, rc.kernel_size = cfg.lstm_layers, cfg.compress, cfg.kernel_size
+        rc.last_kernel_size, rc.residual_kernel_size = cfg.last_kernel_size, cfg.residual_kernel_size
+        rc.group_norm, rc.causal, rc.normalize = int(cfg.norm == "time_group_norm"), int(cfg.causal), int(cfg.normalize)
+        rc.codebook_size = cfg.codebook_size
+        self.frame_rate = int(math.ceil(cfg.sampling_rate / float(cfg.hop_length)))
+        self.n_q_total = int(1000 * max(cfg.target_bandwidths) / (math.ceil(cfg.sampling_rate / cfg.hop_length) * 10))
+        rc.n_q_total = self.n_q_total
+        self.cfg = cfg
+        self.bandwidth = cfg.bandwidth
+        self._h = lib().ref_encodec_create(C.byref(rc), blob, len(blob))
+        if not self._h:
+            raise RuntimeError("ref_encodec_create failed")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            try:
+                _lib.ref_encodec_destroy(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+    @property
+    def segment_length(self):
+        return None if self.cfg.segment_seconds is None else int(self.cfg.segment_seconds * self.cfg.sampling_rate)
+
+    @property
+    def segment_stride(self):
+        sl = self.segment_length
+        return None if sl is None else max(1, int((1 - self.cfg.overlap) * sl))
+
+    def n_q(self):
+        import math
+        bw_per_q = int(math.log2(self.cfg.codebook_size)) * self.frame_rate
+        if self.bandwidth and self.bandwidth > 0:
+            return int(max(1, math.floor(self.bandwidth * 1000 / bw_per_q)))
+        return self.n_q_total
+
+    def encode_frame(self, x, want_emb=False):
+        x = np.ascontiguousarray(x, np.float32)
+        B, _, L = x.shape
+        Tz = lib().ref_encodec_frames(self._h, L)
+        nq = self.n_q()
+        codes = np.empty((B, nq, Tz), np.int64)
+        scale = np.empty((B,), np.float32) if self.cfg.normalize else None
+        emb = np.empty((B, self.cfg.dimension, Tz), np.float32) if want_emb else None
+        if lib().ref_encodec_encode_frame(self._h, x, B, L, nq, codes, _opt(scale), _opt(emb)) < 0:
+            raise RuntimeError("ref_encodec_encode_frame failed (missing tensors?)")
+        sc = None if scale is None else scale.reshape(B, 1)
+        return (codes, sc, emb) if want_emb else (codes, sc)
+
+    def encode(self, pcm, want_emb=False):
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        length = pcm.shape[2]
+        seg = self.segment_length or length
+        stride = self.segment_stride or length
+        return [self.encode_frame(pcm[:, :, off:min(off + seg, length)], want_emb) for off in range(0, length, stride)]
+
+    def decode_frame(self, codes, scale):
+        codes = np.ascontiguousarray(codes, np.int64)
+        B, nq, Tz = codes.shape
+        L = lib().ref_encodec_decoded_length(self._h, Tz)
+        out = np.empty((B, self.cfg.channels, L), np.float32)
+        sc = None if scale is None else np.ascontiguousarray(scale, np.float32).reshape(-1)
+        if lib().ref_encodec_decode_frame(self._h, codes, B, nq, Tz, _opt(sc), out, None) < 0:
+            raise RuntimeError("ref_encodec_decode_frame failed")
+        return out
+
+    def decode(self, frames):
+        if len(frames) == 0:
+            raise ValueError("No frames provided to decode")
+        if self.segment_length is None:
+            if len(frames) != 1:
+                raise ValueError("Expected single frame when no segmentation is used")
+            return self.decode_frame(frames[0][0], frames[0][1])
+        outs = [self.decode_frame(f[0], f[1]) for f in frames]
+        return linear_overlap_add(outs, self.segment_stride)
+
+
+def linear_overlap_add(frames, stride):
+    B, Cc = frames[0].shape[:2]
+    lens = np.array([f.shape[-1] for f in frames], np.int64)
+    flat = np.ascontiguousarray(np.concatenate([np.ascontiguousarray(f, np.float32).reshape(-1) for f in frames]))
+    offs = np.zeros(len(frames), np.int64)
+    offs[1:] = np.cumsum(lens[:-1] * B * Cc)
+    total = int(stride * (len(frames) - 1) + lens[-1])
+    out = np.empty((B, Cc, total), np.float32)
+    lib().ref_linear_overlap_add(flat, offs, lens, len(frames), B * Cc, stride, out, total)
+    return out

@@ -85,3 +85,12 @@ def audit_snac_levels(codes, golden, tol):
                 flips += 1
                 break
     return flips
+
+
+def encodec_cfg_from_meta(meta):
+    from neuralcodecs_amd.config import EncodecConfig
+    kw = dict(meta["cfg"])
+    for k in ("ratios", "target_bandwidths"):
+        if k in kw:
+            kw[k] = tuple(kw[k])
+    return EncodecConfig(**kw)

@@ -15,9 +15,11 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from neuralcodecs_amd.config import DACConfig, SNACConfig  # noqa: E402
-from neuralcodecs_amd.weights import dac_synthetic_state_dict, snac_noise, snac_synthetic_state_dict, synthetic_pcm  # noqa: E402
+from neuralcodecs_amd.config import DACConfig, EncodecConfig, SNACConfig  # noqa: E402
+from neuralcodecs_amd.weights import (dac_synthetic_state_dict, encodec_synthetic_state_dict, snac_noise,  # noqa: E402
+                                      snac_synthetic_state_dict, synthetic_pcm)
 from oracle.torch_ref.dac import TorchDAC  # noqa: E402
+from oracle.torch_ref.encodec import TorchEncodec  # noqa: E402
 from oracle.torch_ref.snac import TorchSNAC  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -85,6 +87,35 @@ def snac_case(name, cfg_kw, B, T, wseed, pseed, nseed, full):
     print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k != "meta"})
 
 
+ENC_SMALL48 = dict(sampling_rate=16000, channels=2, dimension=32, norm="time_group_norm", causal=False, normalize=True,
+                   segment_seconds=0.25, target_bandwidths=(3.0, 6.0, 12.0), bandwidth=6.0, codebook_size=64, n_filters=4,
+                   ratios=(4, 3, 2, 2))
+ENC_SMALL24 = dict(sampling_rate=16000, channels=1, dimension=32, norm="weight_norm", causal=True, normalize=False,
+                   target_bandwidths=(1.5, 3.0, 6.0), bandwidth=3.0, codebook_size=64, n_filters=4, ratios=(4, 3, 2, 2))
+
+
+def encodec_case(name, cfg_kw, B, T, wseed, pseed, full):
+    cfg = EncodecConfig(**cfg_kw)
+    m = TorchEncodec(cfg, encodec_synthetic_state_dict(cfg, seed=wseed))
+    pcm = synthetic_pcm(B, cfg.channels, T, cfg.sampling_rate, seed=pseed)
+    frames = m.encode(pcm, want_dist=True)
+    audio = m.decode(frames)
+    meta = dict(cfg=cfg_kw, B=B, T=T, weight_seed=wseed, pcm_seed=pseed, n_frames=len(frames), n_q=m.n_q())
+    out = dict(meta=json.dumps(meta))
+    for i, (codes, scale, emb, dists) in enumerate(frames):
+        out[f"codes{i}"] = codes.numpy().astype(np.int16)
+        out[f"gap{i}"] = top2_gap(dists).astype(np.float32)                      # [n_q, B*T']
+        if scale is not None:
+            out[f"scale{i}"] = scale.numpy()
+        out[f"emb{i}"] = emb.numpy()[:, ::8, :] if full else emb.numpy()
+    if full:
+        out.update(audio_slice=audio.numpy()[:, :, ::23])
+    else:
+        out.update(pcm=pcm, audio=audio.numpy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k != "meta"})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     # reduced width, ragged length (not a hop multiple), odd stride 5 (DAC-16/24 kHz presets use it)
@@ -96,3 +127,12 @@ if __name__ == "__main__":
     snac_case("snac_small_attn", SNAC_SMALL_ATTN, 2, 2500, 6, 4, 98, False)
     # full-size SNAC 24 kHz, one 1 s clip (BASELINE config C1)
     snac_case("snac24k_b1", dict(), 1, 24000, 42, 1234, 77, True)
+    snac_case("snac44k_short", dict(sampling_rate=44100, encoder_dim=64, encoder_rates=(2, 3, 8, 8), decoder_dim=1536,
+                                    decoder_rates=(8, 8, 3, 2), attn_window_size=32, vq_strides=(8, 4, 2, 1)), 1, 20000, 42, 1234, 55, True)
+    # Encodec: reduced width, stereo + GroupNorm + segments with a short tail (small-input reflect path, D9) / causal weight-norm mono
+    encodec_case("encodec_small48", ENC_SMALL48, 2, 8100, 7, 3, False)
+    encodec_case("encodec_small24", ENC_SMALL24, 2, 3001, 8, 4, False)
+    # full size: Encodec 48 kHz stereo 12 kbps, one 2 s clip (BASELINE config C3 at B=1) and Encodec 24 kHz mono 6 kbps, 1 s
+    encodec_case("encodec48k_b1", dict(sampling_rate=48000, channels=2, norm="time_group_norm", causal=False, normalize=True,
+                                       segment_seconds=1.0, target_bandwidths=(3.0, 6.0, 12.0, 24.0), bandwidth=12.0), 1, 96000, 42, 1234, True)
+    encodec_case("encodec24k_b1", dict(), 1, 24000, 42, 1234, True)
