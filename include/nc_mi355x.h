@@ -163,6 +163,56 @@ NC_API nc_status nc_snac_decode_dev(nc_codec* h, const int64_t* codes, int32_t B
 /* total number of noise floats nc_snac_decode consumes for (B, frames) */
 NC_API nc_status nc_snac_noise_len(const nc_codec* h, int32_t B, int64_t frames, int64_t* n);
 
+/* -------------------------------------------------------------------------------------- Encodec
+ * replaces: new Encodec(EncodecConfig)             NeuralCodecs.Torch/Models/Encodec.cs:46-90
+ * Only channels / dimension / norm / causal reach SEANet in the reference (Encodec.cs:57-68, deviation D11); the other SEANet
+ * fields are its hard defaults (SEANetEncoder.cs:37-56) and are carried here so reduced-width test models can be built. */
+typedef struct {
+    int32_t sample_rate;        /* 24000 | 48000 */
+    int32_t channels;           /* 1 | 2 */
+    int32_t dimension;          /* 128 (HiddenSize == CodebookDim) */
+    int32_t n_filters;          /* 32 */
+    int32_t n_ratios;           /* 4 */
+    int32_t ratios[8];          /* 8,5,4,2 (decoder order; the encoder runs them reversed) */
+    int32_t lstm_layers;        /* 2 */
+    int32_t compress;           /* 2 */
+    int32_t kernel_size;        /* 7 */
+    int32_t last_kernel_size;   /* 7 */
+    int32_t residual_kernel_size; /* 3 */
+    int32_t time_group_norm;    /* 0: weight_norm (24 kHz), 1: GroupNorm(1,C) after every conv (48 kHz) */
+    int32_t causal;             /* 24 kHz: 1 */
+    int32_t normalize;          /* 48 kHz: 1 (per-frame RMS scale) */
+    int32_t segment_length;     /* samples; 0 = no segmentation (24 kHz); 48 kHz: 48000 */
+    int32_t segment_stride;     /* samples; 48 kHz: 47520 (1 % overlap) */
+    int32_t codebook_size;      /* 1024 */
+    int32_t n_codebooks;        /* quantizer layers built: 1000*max(bandwidths)/(frame_rate*10) (Encodec.cs:70-71): 32 | 16 */
+    int32_t frame_rate;         /* ceil(sample_rate / hop) */
+    float bandwidth;            /* target kbps -> n_q = max(1, floor(bandwidth*1000 / (log2(codebook_size)*frame_rate))) */
+} nc_encodec_config;
+
+NC_API nc_status nc_encodec_create(const nc_encodec_config* cfg, int device_index, nc_codec** out);
+/* replaces: Encodec.SetTargetBandwidth(float)      Models/Encodec.cs:409-419 (the caller validates membership in TargetBandwidths) */
+NC_API nc_status nc_encodec_set_bandwidth(nc_codec* h, float bandwidth_kbps);
+
+/* Frame layout of Encodec.Encode for clips of T samples: number of EncodedFrames (segments), codebooks in use n_q, frames T'_f of
+ * every segment (frame_lens has room for `cap` entries), decoded length of Decode (before forward()'s trim to T). */
+NC_API nc_status nc_encodec_query(const nc_codec* h, int64_t T, int32_t* n_frames, int32_t* n_q, int64_t* frame_lens, int32_t cap,
+                                  int64_t* decoded_len);
+
+/* replaces: Encodec.Encode(Tensor x[B,C,T]) -> List<EncodedFrame>     Models/Encodec.cs:259-285, EncodeFrame :457-489
+ *   codes  int64: the EncodedFrame.Codes tensors [B,n_q,T'_f] laid end to end in segment order
+ *   scales float32 [n_frames,B] (EncodedFrame.Scale; written only when normalize) -- nullable otherwise
+ *   emb    nullable: encoder outputs [B,dimension,T'_f] end to end (test hook) */
+NC_API nc_status nc_encodec_encode(nc_codec* h, const float* pcm, int32_t B, int64_t T, int64_t* codes, float* scales, float* emb);
+NC_API nc_status nc_encodec_encode_dev(nc_codec* h, const float* pcm, int32_t B, int64_t T, int64_t* codes, float* scales, float* emb);
+
+/* replaces: Encodec.Decode(List<EncodedFrame>) -> [B,C,decoded_len]    Models/Encodec.cs:213-235, DecodeFrame :436-455,
+ * DSP.LinearOverlapAdd AudioTools/AudioTensorDSP.cs:161-261.  T is the clip length the frames were encoded from (it fixes the
+ * segment layout); n_q the number of codebooks present in `codes`. */
+NC_API nc_status nc_encodec_decode(nc_codec* h, const int64_t* codes, const float* scales, int32_t B, int64_t T, int32_t n_q, float* pcm);
+NC_API nc_status nc_encodec_decode_dev(nc_codec* h, const int64_t* codes, const float* scales, int32_t B, int64_t T, int32_t n_q,
+                                       float* pcm);
+
 /* ------------------------------------------------------------------------------------ profiling
  * Per-kernel-class timing with HIP events recorded on the handle's stream around every launch
  * (used by bench.py for the roofline object).  Classes are stable small integers. */

@@ -7,5 +7,6 @@ classes (NeuralCodecs.Torch/Models/{DAC,SNAC,Encodec}.cs).
 from .config import DACConfig, EncodecConfig, SNACConfig  # noqa: F401
 from .dac import DAC  # noqa: F401
 from .snac import SNAC  # noqa: F401
+from .encodec import EncodedFrame, Encodec  # noqa: F401
 
-__all__ = ["DAC", "SNAC", "DACConfig", "SNACConfig", "EncodecConfig"]
+__all__ = ["DAC", "SNAC", "Encodec", "EncodedFrame", "DACConfig", "SNACConfig", "EncodecConfig"]

@@ -39,6 +39,15 @@ class NcSnacConfig(C.Structure):
                 ("vq_strides", C.c_int32 * 8), ("noise", C.c_int32), ("depthwise", C.c_int32)]
 
 
+class NcEncodecConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_int32), ("channels", C.c_int32), ("dimension", C.c_int32), ("n_filters", C.c_int32),
+                ("n_ratios", C.c_int32), ("ratios", C.c_int32 * 8), ("lstm_layers", C.c_int32), ("compress", C.c_int32),
+                ("kernel_size", C.c_int32), ("last_kernel_size", C.c_int32), ("residual_kernel_size", C.c_int32),
+                ("time_group_norm", C.c_int32), ("causal", C.c_int32), ("normalize", C.c_int32), ("segment_length", C.c_int32),
+                ("segment_stride", C.c_int32), ("codebook_size", C.c_int32), ("n_codebooks", C.c_int32), ("frame_rate", C.c_int32),
+                ("bandwidth", C.c_float)]
+
+
 class NcProfileEntry(C.Structure):
     _fields_ = [("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
@@ -81,6 +90,14 @@ SYMBOLS = [
     ("nc_snac_from_codes_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
     ("nc_snac_decode", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, C.c_uint64, _P]),
     ("nc_snac_decode_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, C.c_uint64, _P]),
+    ("nc_encodec_create", C.c_int, [C.POINTER(NcEncodecConfig), C.c_int, C.POINTER(_P)]),
+    ("nc_encodec_set_bandwidth", C.c_int, [_P, C.c_float]),
+    ("nc_encodec_query", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_int32,
+                                   C.POINTER(C.c_int64)]),
+    ("nc_encodec_encode", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
+    ("nc_encodec_encode_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
+    ("nc_encodec_decode", C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
+    ("nc_encodec_decode_dev", C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
     ("nc_codec_profile_enable", C.c_int, [_P, C.c_int32]),
     ("nc_codec_profile_reset", C.c_int, [_P]),
     ("nc_codec_profile_read", C.c_int, [_P, C.POINTER(NcProfileEntry)]),

@@ -44,6 +44,12 @@ SnacModel& as_snac(nc_codec* h) {
     return static_cast<SnacModel&>(*h->impl);
 }
 
+EncodecModel& as_encodec(nc_codec* h) {
+    if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");
+    if (h->kind != 2) fail(NC_EINVAL, "handle is not an Encodec codec");
+    return static_cast<EncodecModel&>(*h->impl);
+}
+
 void h2d(void* d, const void* h, size_t n, hipStream_t s) { NC_HIP(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s)); }
 void d2h(void* h, const void* d, size_t n, hipStream_t s) { NC_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s)); }
 
@@ -304,6 +310,91 @@ nc_status nc_snac_decode(nc_codec* h, const int64_t* codes, int32_t B, int64_t f
             nz = m.h_noise.as<float>();
         }
         m.decode_dev(m.h_codes.as<int64_t>(), B, frames, nz, seed, m.h_out.as<float>());
+        d2h(pcm, m.h_out.p, n_out, m.stream);
+        NC_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
+// ---- Encodec ---------------------------------------------------------------------------------------
+nc_status nc_encodec_create(const nc_encodec_config* cfg, int device_index, nc_codec** out) {
+    return guard([&] {
+        if (!cfg || !out) fail(NC_EINVAL, "cfg and out must not be null");
+        *out = nullptr;
+        std::unique_ptr<EncodecModel> m(new EncodecModel(*cfg));
+        m->init_device(device_index);
+        nc_codec* h = new nc_codec();
+        h->impl = std::move(m);
+        h->kind = 2;
+        *out = h;
+    });
+}
+
+nc_status nc_encodec_set_bandwidth(nc_codec* h, float bw) {
+    return guard([&] { as_encodec(h).set_bandwidth(bw); });
+}
+
+nc_status nc_encodec_query(const nc_codec* h, int64_t T, int32_t* n_frames, int32_t* n_q, int64_t* frame_lens, int32_t cap,
+                           int64_t* decoded_len) {
+    return guard([&] {
+        EncodecModel& m = as_encodec(const_cast<nc_codec*>(h));
+        if (T <= 0) fail(NC_EINVAL, "T must be positive");
+        const auto segs = m.segments(T);
+        if (n_frames) *n_frames = (int32_t)segs.size();
+        if (n_q) *n_q = m.n_q;
+        if (frame_lens)
+            for (size_t i = 0; i < segs.size() && (int32_t)i < cap; ++i) frame_lens[i] = segs[i].frames;
+        if (decoded_len) {
+            if (m.cfg.segment_length <= 0) *decoded_len = m.decoded_for(segs[0].frames);
+            else *decoded_len = (int64_t)m.cfg.segment_stride * ((int64_t)segs.size() - 1) + m.decoded_for(segs.back().frames);
+        }
+    });
+}
+
+nc_status nc_encodec_encode_dev(nc_codec* h, const float* pcm, int32_t B, int64_t T, int64_t* codes, float* scales, float* emb) {
+    return guard([&] { as_encodec(h).encode_dev(pcm, B, T, codes, scales, emb); });
+}
+nc_status nc_encodec_decode_dev(nc_codec* h, const int64_t* codes, const float* scales, int32_t B, int64_t T, int32_t n_q, float* pcm) {
+    return guard([&] { as_encodec(h).decode_dev(codes, scales, B, T, n_q, pcm); });
+}
+
+nc_status nc_encodec_encode(nc_codec* h, const float* pcm, int32_t B, int64_t T, int64_t* codes, float* scales, float* emb) {
+    return guard([&] {
+        EncodecModel& m = as_encodec(h);
+        if (!pcm || !codes) fail(NC_EINVAL, "pcm and codes must not be null");                  // ArgumentNullException, Encodec.cs:245
+        if (B <= 0 || T <= 0) fail(NC_EINVAL, "B and T must be positive");
+        m.use_device();
+        const auto segs = m.segments(T);
+        int64_t fr = 0;
+        for (auto& s : segs) fr += s.frames;
+        const size_t n_in = (size_t)B * m.cfg.channels * T * 4, n_codes = (size_t)B * m.n_q * fr * 8, n_sc = segs.size() * (size_t)B * 4,
+                     n_emb = (size_t)B * m.cfg.dimension * fr * 4;
+        m.h_in.reserve(n_in); m.h_codes.reserve(n_codes); m.h_scales.reserve(n_sc); m.h_emb.reserve(n_emb);
+        h2d(m.h_in.p, pcm, n_in, m.stream);
+        m.encode_dev(m.h_in.as<float>(), B, T, m.h_codes.as<int64_t>(), m.h_scales.as<float>(), emb ? m.h_emb.as<float>() : nullptr);
+        d2h(codes, m.h_codes.p, n_codes, m.stream);
+        if (scales && m.cfg.normalize) d2h(scales, m.h_scales.p, n_sc, m.stream);
+        if (emb) d2h(emb, m.h_emb.p, n_emb, m.stream);
+        NC_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
+nc_status nc_encodec_decode(nc_codec* h, const int64_t* codes, const float* scales, int32_t B, int64_t T, int32_t n_q, float* pcm) {
+    return guard([&] {
+        EncodecModel& m = as_encodec(h);
+        if (!codes || !pcm) fail(NC_EINVAL, "Invalid frame codes in Encodec Decode");              // Encodec.cs:438-442
+        if (B <= 0 || T <= 0 || n_q <= 0) fail(NC_EINVAL, "No frames provided to decode");
+        if (m.cfg.normalize && !scales) fail(NC_EINVAL, "this model normalises frames: scales must be given");
+        m.use_device();
+        const auto segs = m.segments(T);
+        int64_t fr = 0;
+        for (auto& s : segs) fr += s.frames;
+        const int64_t Lout = m.cfg.segment_length <= 0 ? m.decoded_for(segs[0].frames)
+                                                       : (int64_t)m.cfg.segment_stride * ((int64_t)segs.size() - 1) + m.decoded_for(segs.back().frames);
+        const size_t n_codes = (size_t)B * n_q * fr * 8, n_sc = segs.size() * (size_t)B * 4, n_out = (size_t)B * m.cfg.channels * Lout * 4;
+        m.h_codes.reserve(n_codes); m.h_scales.reserve(n_sc); m.h_out.reserve(n_out);
+        h2d(m.h_codes.p, codes, n_codes, m.stream);
+        if (scales) h2d(m.h_scales.p, scales, n_sc, m.stream);
+        m.decode_dev(m.h_codes.as<int64_t>(), scales ? m.h_scales.as<float>() : nullptr, B, T, n_q, m.h_out.as<float>());
         d2h(pcm, m.h_out.p, n_out, m.stream);
         NC_HIP(hipStreamSynchronize(m.stream));
     });

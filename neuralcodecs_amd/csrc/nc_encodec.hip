@@ -1,0 +1,758 @@
+// Encodec on the engine: SEANet encoder / decoder, LSTM, Euclidean RVQ, RMS scale and overlap-add.
+//
+// Reference call stacks restated as kernel launches:
+//   Encodec.Encode  Models/Encodec.cs:259-285 -> EncodeFrame :457-489 -> SEANetEncoder.cs:37-148 -> ResidualVectorQuantizer.cs:133-157
+//   Encodec.Decode  Models/Encodec.cs:213-235 -> DecodeFrame :436-455 -> SEANetDecoder.cs:40-153 -> DSP.LinearOverlapAdd
+// Every SConv1d (SConv1d.cs:144-173) is  [pad_act kernel: GroupNorm-apply of the producer + ELU + asymmetric reflect pad, incl. the
+// small-input path D9]  ->  [implicit-GEMM conv kernel on the padded tensor]  ->  [GroupNorm statistics kernels]; the normalisation of
+// a conv output is applied by its consumer, so each activation is written once raw and once padded.  Dense contractions (convs,
+// LSTM input projections) run on the matrix-core conv template; the recurrent part of the LSTM is one launch per time step.
+// Arithmetic is the canonical arithmetic of DESIGN.md (same sequences as oracle/c/nc_ref_encodec.c).
+#include <cmath>
+
+#include "nc_math.h"
+#include "nc_model.h"
+
+namespace nc {
+
+constexpr int GN_CHUNK = 256;
+
+// ---------------------------------------------------------------------------------------------- kernels
+struct ActView {          // [B,C,L] view of a raw conv output with its pending GroupNorm (applied by the consumer)
+    const float* p;
+    int64_t rs, off;      // row stride (elements), offset of logical sample 0 in a row (conv-transpose trim)
+    const float* stats;   // [B][2] = (mean, rstd); null: no normalisation
+    const float* gamma;
+    const float* beta;
+};
+
+__device__ __forceinline__ float nc_eluf(float x) { return x > 0.0f ? x : nc_expf(x) - 1.0f; }
+__device__ __forceinline__ float nc_sigmoidf(float x) { return 1.0f / (1.0f + nc_expf(-x)); }
+
+__device__ __forceinline__ float act_value(const ActView& v, int64_t b, int c, int C, int64_t q) {
+    float x = v.p[(b * C + c) * v.rs + v.off + q];
+    if (v.stats) x = ((x - v.stats[2 * b]) * v.stats[2 * b + 1]) * v.gamma[c] + v.beta[c];
+    return x;
+}
+
+// dst[b,c,j] = pad(elu?(GN(a) [+ GN(b2)]))[j],  j in [0,Lp): reflect over the zero-extended row of length Lz (SConv1d.cs:258-274)
+__global__ void pad_act_kernel(ActView a, ActView b2, int has_b, int elu, float* __restrict__ dst, int B, int C, int64_t L, int64_t Lz,
+                               int64_t left, int64_t Lp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * C * Lp) return;
+    const int64_t j = i % Lp, r = i / Lp;
+    const int c = (int)(r % C);
+    const int64_t b = r / C;
+    int64_t q = j - left;
+    if (q < 0) q = -q;
+    if (q >= Lz) q = 2 * (Lz - 1) - q;
+    float v = 0.0f;
+    if (q < L) {
+        v = act_value(a, b, c, C, q);
+        if (has_b) v = v + act_value(b2, b, c, C, q);
+        if (elu) v = nc_eluf(v);
+    }
+    dst[i] = v;
+}
+
+// per 256-sample chunk of one row: binary64 sum and sum of squares, ascending t
+__global__ void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int64_t rows, int64_t T, int nchunk) {
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= rows * nchunk) return;
+    const int64_t r = i / nchunk, ch = i - r * nchunk;
+    const int64_t t0 = ch * GN_CHUNK, t1 = t0 + GN_CHUNK < T ? t0 + GN_CHUNK : T;
+    const float* xp = x + r * T;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t t = t0; t < t1; ++t) {
+        const double v = (double)xp[t];
+        s1 += v;
+        s2 += v * v;
+    }
+    part[2 * i] = s1;
+    part[2 * i + 1] = s2;
+}
+// one block per sample: row totals (chunks ascending) in parallel, then rows ascending by one thread -> (mean, rstd)
+__global__ __launch_bounds__(256) void gn_final_kernel(const double* __restrict__ part, float* __restrict__ stats, int C, int64_t T,
+                                                       int nchunk) {
+    extern __shared__ double rsum[];   // [2*C]
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const double* p = part + 2 * ((int64_t)(b * C + c) * nchunk);
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < nchunk; ++k) {
+            s1 += p[2 * k];
+            s2 += p[2 * k + 1];
+        }
+        rsum[2 * c] = s1;
+        rsum[2 * c + 1] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S1 = 0.0, S2 = 0.0;
+        for (int c = 0; c < C; ++c) {
+            S1 += rsum[2 * c];
+            S2 += rsum[2 * c + 1];
+        }
+        const double N = (double)C * (double)T;
+        const double mu = S1 / N;
+        double var = S2 / N - mu * mu;
+        if (var < 0.0) var = 0.0;
+        stats[2 * b] = (float)mu;
+        stats[2 * b + 1] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+}
+
+// RMS scale (Encodec.cs:469-480): chunk sums of fl32(mono^2), then scale = sqrtf((float)(S/L)) + 1e-8f
+__global__ void rms_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int B, int C, int64_t L, int nchunk) {
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= (int64_t)B * nchunk) return;
+    const int64_t b = i / nchunk, ch = i - b * nchunk;
+    const int64_t t0 = ch * GN_CHUNK, t1 = t0 + GN_CHUNK < L ? t0 + GN_CHUNK : L;
+    double s = 0.0;
+    for (int64_t t = t0; t < t1; ++t) {
+        float a = x[(b * C) * L + t];
+        for (int c = 1; c < C; ++c) a = a + x[(b * C + c) * L + t];
+        const float m = a / (float)C;
+        s += (double)(m * m);
+    }
+    part[i] = s;
+}
+__global__ void rms_final_kernel(const double* __restrict__ part, float* __restrict__ scale, int B, int64_t L, int nchunk) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    double s = 0.0;
+    for (int k = 0; k < nchunk; ++k) s += part[(int64_t)b * nchunk + k];
+    scale[b] = sqrtf((float)(s / (double)L)) + 1e-8f;
+}
+// y = x / scale[b]  (mode 0)   |   y = GN(x) * scale[b] (mode 1, scale nullable -> plain GN materialisation)
+__global__ void scale_kernel(ActView a, const float* __restrict__ scale, int mode, float* __restrict__ y, int B, int C, int64_t L) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * C * L) return;
+    const int64_t t = i % L, r = i / L;
+    const int c = (int)(r % C);
+    const int64_t b = r / C;
+    float v = act_value(a, b, c, C, t);
+    if (scale) v = mode == 0 ? v / scale[b] : v * scale[b];
+    y[i] = v;
+}
+
+// One LSTM time step of one layer (SLSTM.cs:31,40-57; gate order i,f,g,o).  Block j = hidden unit, thread = clip.
+//   gi   [B,4C,T]  input projection incl. b_ih (matrix-core 1x1 conv)         hprev/hnext, cst  [C][B] (unit-major)
+//   out  [B,C,T]   h_t (+ skip[b,j,t] for the last layer: output.add(permuted), SLSTM.cs:50-53)
+__global__ __launch_bounds__(64) void lstm_step_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
+                                                       const float* __restrict__ bhh, const float* __restrict__ hprev,
+                                                       float* __restrict__ hnext, float* __restrict__ cst, const float* __restrict__ skip,
+                                                       float* __restrict__ out, int B, int C, int64_t T, int64_t t) {
+    extern __shared__ float wrow[];   // [4][C]
+    const int j = blockIdx.x;
+    for (int i = threadIdx.x; i < 4 * C; i += 64) wrow[i] = whh[(int64_t)((i / C) * C + j) * C + (i % C)];
+    __syncthreads();
+    const int b = blockIdx.y * 64 + threadIdx.x;
+    if (b >= B) return;
+    float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, r3 = 0.0f;
+    for (int k = 0; k < C; ++k) {
+        const float h = hprev[(int64_t)k * B + b];
+        r0 = nc_fma(wrow[k], h, r0);
+        r1 = nc_fma(wrow[C + k], h, r1);
+        r2 = nc_fma(wrow[2 * C + k], h, r2);
+        r3 = nc_fma(wrow[3 * C + k], h, r3);
+    }
+    const float* g = gi + ((int64_t)b * 4 * C) * T + t;
+    const float pi = g[(int64_t)j * T] + (r0 + bhh[j]);
+    const float pf = g[(int64_t)(C + j) * T] + (r1 + bhh[C + j]);
+    const float pg = g[(int64_t)(2 * C + j) * T] + (r2 + bhh[2 * C + j]);
+    const float po = g[(int64_t)(3 * C + j) * T] + (r3 + bhh[3 * C + j]);
+    const float ig = nc_sigmoidf(pi), fg = nc_sigmoidf(pf), gg = nc_tanhf(pg), og = nc_sigmoidf(po);
+    const float cn = (fg * cst[(int64_t)j * B + b]) + (ig * gg);
+    cst[(int64_t)j * B + b] = cn;
+    const float h = og * nc_tanhf(cn);
+    hnext[(int64_t)j * B + b] = h;
+    const int64_t o = ((int64_t)b * C + j) * T + t;
+    out[o] = skip ? h + skip[o] : h;
+}
+
+// Euclidean codebook search, D <= 128 (EuclideanCodebook.cs:155-182): per frame dist_n = (|x|^2 + |e_n|^2) - 2*(x.e_n) with fma
+// chains over d ascending, argmin with lowest-index ties; then residual -= embed[idx] (ResidualVectorQuantizer.cs:150-152).
+// Block = EQ_F frames x 256 threads; thread n scans codes n, n+256, ...; codebook transposed [D][N] streams from L2.
+constexpr int EQ_F = 8, EQ_MAXD = 128, EQ_NPT = 4;
+__global__ __launch_bounds__(256) void euclid_vq_kernel(float* __restrict__ residual, const float* __restrict__ cbT,
+                                                        const float* __restrict__ cb, const float* __restrict__ c2, int N, int D, int B,
+                                                        int64_t T, int64_t* __restrict__ codes, int64_t codes_bstride) {
+    __shared__ float es[EQ_F][EQ_MAXD];
+    __shared__ float e2s[EQ_F];
+    __shared__ float bd[EQ_F][4];
+    __shared__ int bi[EQ_F][4];
+    __shared__ int win[EQ_F];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t f0 = (int64_t)blockIdx.x * EQ_F, total = (int64_t)B * T;
+    for (int i = tid; i < EQ_F * D; i += 256) {
+        const int f = i / D, d = i - f * D;
+        const int64_t fr = f0 + f;
+        float v = 0.0f;
+        if (fr < total) { const int64_t b = fr / T, t = fr - b * T; v = residual[(b * D + d) * T + t]; }
+        es[f][d] = v;
+    }
+    __syncthreads();
+    if (tid < EQ_F) {
+        float a = 0.0f;
+        for (int d = 0; d < D; ++d) a = nc_fma(es[tid][d], es[tid][d], a);
+        e2s[tid] = a;
+    }
+    __syncthreads();
+    float best[EQ_F];
+    int besti[EQ_F];
+#pragma unroll
+    for (int f = 0; f < EQ_F; ++f) { best[f] = __builtin_inff(); besti[f] = 0x7fffffff; }
+    for (int n0 = 0; n0 < N; n0 += 256 * EQ_NPT) {
+        float cr[EQ_NPT][EQ_F];
+#pragma unroll
+        for (int u = 0; u < EQ_NPT; ++u)
+#pragma unroll
+            for (int f = 0; f < EQ_F; ++f) cr[u][f] = 0.0f;
+        for (int d = 0; d < D; ++d) {
+            float cv[EQ_NPT];
+#pragma unroll
+            for (int u = 0; u < EQ_NPT; ++u) {
+                const int n = n0 + u * 256 + tid;
+                cv[u] = n < N ? cbT[(int64_t)d * N + n] : 0.0f;
+            }
+#pragma unroll
+            for (int f = 0; f < EQ_F; ++f) {
+                const float ev = es[f][d];
+#pragma unroll
+                for (int u = 0; u < EQ_NPT; ++u) cr[u][f] = nc_fma(ev, cv[u], cr[u][f]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < EQ_NPT; ++u) {
+            const int n = n0 + u * 256 + tid;
+            if (n < N) {
+                const float cc = c2[n];
+#pragma unroll
+                for (int f = 0; f < EQ_F; ++f) {
+                    const float dist = (e2s[f] + cc) - 2.0f * cr[u][f];
+                    if (dist < best[f]) { best[f] = dist; besti[f] = n; }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < EQ_F; ++f) {
+        float d0 = best[f];
+        int i0 = besti[f];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float od = __shfl_xor(d0, off, 64);
+            const int oi = __shfl_xor(i0, off, 64);
+            if (od < d0 || (od == d0 && oi < i0)) { d0 = od; i0 = oi; }
+        }
+        if (lane == 0) { bd[f][wave] = d0; bi[f][wave] = i0; }
+    }
+    __syncthreads();
+    if (tid < EQ_F) {
+        float d0 = bd[tid][0];
+        int i0 = bi[tid][0];
+        for (int w = 1; w < 4; ++w)
+            if (bd[tid][w] < d0 || (bd[tid][w] == d0 && bi[tid][w] < i0)) { d0 = bd[tid][w]; i0 = bi[tid][w]; }
+        if (i0 == 0x7fffffff) i0 = 0;
+        win[tid] = i0;
+        const int64_t fr = f0 + tid;
+        if (fr < total) { const int64_t b = fr / T, t = fr - b * T; codes[b * codes_bstride + t] = (int64_t)i0; }
+    }
+    __syncthreads();
+    for (int i = tid; i < EQ_F * D; i += 256) {
+        const int f = i / D, d = i - f * D;
+        const int64_t fr = f0 + f;
+        if (fr < total) {
+            const int64_t b = fr / T, t = fr - b * T;
+            residual[(b * D + d) * T + t] = es[f][d] - cb[(int64_t)win[f] * D + d];
+        }
+    }
+}
+
+// ResidualVectorQuantizer.Decode (:107-124): emb = ((0 + e_0[idx_0]) + e_1[idx_1]) + ...
+__global__ void emb_sum_kernel(const int64_t* __restrict__ codes, const float* const* __restrict__ cbs, int n_q, int N, int D, int B,
+                               int64_t T, float* __restrict__ emb) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * D * T) return;
+    const int64_t t = i % T, r = i / T;
+    const int d = (int)(r % D);
+    const int64_t b = r / D;
+    float a = 0.0f;
+    for (int q = 0; q < n_q; ++q) {
+        int64_t c = codes[(b * n_q + q) * T + t];
+        if (c < 0) c = 0;
+        if (c >= N) c = N - 1;
+        a = a + cbs[q][c * D + d];
+    }
+    emb[i] = a;
+}
+
+// DSP.LinearOverlapAdd (AudioTensorDSP.cs:161-261): out[r,i] = (sum_f frame_f[r, i - f*stride] * w[i - f*stride]) / sw[i]
+struct OlaFrames {
+    const float* p[16];
+    int64_t len[16];
+    int n;
+};
+__global__ void overlap_add_kernel(OlaFrames fr, const float* __restrict__ w, const float* __restrict__ sw, int64_t rows, int64_t stride,
+                                   int64_t total, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * total) return;
+    const int64_t r = i / total, t = i - r * total;
+    float a = 0.0f;
+    for (int f = 0; f < fr.n; ++f) {
+        const int64_t q = t - (int64_t)f * stride;
+        if (q >= 0 && q < fr.len[f]) a = a + fr.p[f][r * fr.len[f] + q] * w[q];
+    }
+    out[i] = a / sw[t];
+}
+
+// ---------------------------------------------------------------------------------------------- model
+EncodecModel::EncodecModel(const nc_encodec_config& c) : cfg(c) {
+    if (c.n_ratios <= 0 || c.n_ratios > 8) fail(NC_EINVAL, "ratios must hold 1..8 entries");
+    if (c.channels <= 0 || c.channels > 2) fail(NC_EINVAL, "Invalid number of channels: %d", c.channels);          // Encodec.cs:267-270
+    if (c.dimension <= 0 || c.dimension > EQ_MAXD || c.n_filters <= 0 || c.sample_rate <= 0 || c.codebook_size <= 0 || c.n_codebooks <= 0 ||
+        c.n_codebooks > 64 || c.frame_rate <= 0 || c.lstm_layers < 0 || c.lstm_layers > 4 || c.compress <= 0)
+        fail(NC_EINVAL, "Encodec config fields out of range");
+    if (c.kernel_size != 7 || c.last_kernel_size != 7 || c.residual_kernel_size != 3)
+        fail(NC_EUNSUPPORTED, "SEANet kernel sizes other than 7/7/3 are not instantiated");
+    if (c.time_group_norm && c.causal) fail(NC_EINVAL, "GroupNorm doesn't support causal evaluation");               // NormConv1d.cs:143-147
+    if ((c.segment_length > 0) != (c.segment_stride > 0)) fail(NC_EINVAL, "segment_length and segment_stride go together");
+    hop = 1;
+    for (int i = 0; i < c.n_ratios; ++i) {
+        if (c.ratios[i] <= 0) fail(NC_EINVAL, "ratios must be positive");
+        hop *= c.ratios[i];
+    }
+    set_bandwidth(c.bandwidth);
+}
+
+void EncodecModel::set_bandwidth(float bw) {
+    // ResidualVectorQuantizer.Encode (:139-147): nQ = max(1, floor(bw*1000 / (log2(bins)*frameRate)))
+    const double bw_per_q = std::log2((double)cfg.codebook_size) * cfg.frame_rate;
+    int n = cfg.n_codebooks;
+    if (bw > 0) n = (int)std::max(1.0, std::floor((double)bw * 1000.0 / bw_per_q));
+    if (n > cfg.n_codebooks) fail(NC_EINVAL, "This model doesn't support the bandwidth %g kbps", (double)bw);          // Encodec.cs:411-416
+    n_q = n;
+    cfg.bandwidth = bw;
+}
+
+EncodecModel::Plan EncodecModel::plan_sconv(int64_t L, int k, int stride, int dil) const {
+    Plan p;
+    const int64_t eff = (int64_t)(k - 1) * dil + 1, pt = eff - stride;
+    const float nf = (float)(L - eff + pt) / (float)stride + 1.0f;                      // SConv1d.cs:245-250 (float division)
+    const int64_t ideal = ((int64_t)std::ceil(nf) - 1) * stride + (eff - pt);
+    const int64_t extra = ideal - L;
+    if (cfg.causal) { p.left = pt; p.right = extra; }
+    else { const int64_t r = pt / 2; p.left = pt - r; p.right = r + extra; }
+    const int64_t mx = std::max(p.left, p.right);
+    p.Lz = L <= mx ? L + (mx - L + 1) : L;                                                 // SConv1d.cs:258-274 (D9)
+    p.Lp = p.Lz + p.left + p.right;
+    p.Lout = (p.Lp - eff) / stride + 1;
+    return p;
+}
+
+int64_t EncodecModel::frames_for(int64_t L) const {
+    L = plan_sconv(L, cfg.kernel_size, 1, 1).Lout;
+    for (int i = cfg.n_ratios - 1; i >= 0; --i) {
+        L = plan_sconv(L, cfg.residual_kernel_size, 1, 1).Lout;
+        L = plan_sconv(L, 2 * cfg.ratios[i], cfg.ratios[i], 1).Lout;
+    }
+    return plan_sconv(L, cfg.last_kernel_size, 1, 1).Lout;
+}
+int64_t EncodecModel::decoded_for(int64_t Tz) const {
+    int64_t L = plan_sconv(Tz, cfg.kernel_size, 1, 1).Lout;
+    for (int i = 0; i < cfg.n_ratios; ++i) {
+        L = L * cfg.ratios[i];
+        L = plan_sconv(L, cfg.residual_kernel_size, 1, 1).Lout;
+    }
+    return plan_sconv(L, cfg.last_kernel_size, 1, 1).Lout;
+}
+
+std::vector<EncodecModel::Seg> EncodecModel::segments(int64_t T) const {
+    std::vector<Seg> v;
+    const int64_t seg = cfg.segment_length > 0 ? cfg.segment_length : T, stride = cfg.segment_stride > 0 ? cfg.segment_stride : T;
+    for (int64_t off = 0; off < T; off += stride) {                                         // Encodec.cs:278-282
+        Seg s;
+        s.off = off;
+        s.len = std::min(off + seg, T) - off;
+        s.frames = frames_for(s.len);
+        v.push_back(s);
+    }
+    return v;
+}
+
+static void upload(DevBuf& d, const float* h, size_t n) {
+    d.reserve(n * sizeof(float));
+    NC_HIP(hipMemcpy(d.p, h, n * sizeof(float), hipMemcpyHostToDevice));
+}
+
+void EncodecModel::load_sconv(const Blob& b, const std::string& key, SConv& L, int Cin, int Cout, int K, int stride, bool transposed) {
+    const BlobTensor* w = b.find(key + ".conv.weight");
+    const BlobTensor* bias = b.find(key + ".conv.bias");
+    const int64_t d0 = transposed ? Cin : Cout, d1 = transposed ? Cout : Cin;
+    std::vector<float> folded;
+    const float* dense;
+    if (w) {
+        if (w->dims.size() != 3 || w->dims[0] != d0 || w->dims[1] != d1 || w->dims[2] != K) fail(NC_EINVAL, "%s.conv.weight has the wrong shape", key.c_str());
+        dense = static_cast<const float*>(w->data);
+    } else {
+        const BlobTensor& v = b.get(key + ".conv.weight_v");
+        const BlobTensor& g = b.get(key + ".conv.weight_g");
+        if (v.dims.size() != 3 || v.dims[0] != d0 || v.dims[1] != d1 || v.dims[2] != K || g.numel() != d0)
+            fail(NC_EINVAL, "%s.conv.weight_v/g have the wrong shape", key.c_str());
+        folded.resize((size_t)v.numel());
+        fold_weight_norm_snac(static_cast<const float*>(v.data), static_cast<const float*>(g.data), d0, d1 * K, folded.data());   // D3
+        dense = folded.data();
+    }
+    if (bias && bias->numel() != Cout) fail(NC_EINVAL, "%s.conv.bias has the wrong length", key.c_str());
+    L.K = K; L.stride = stride; L.Cin = Cin; L.Cout = Cout; L.transposed = transposed;
+    L.conv.kclass = transposed ? NC_KC_CONV_UP : (stride > 1 ? NC_KC_CONV_DOWN : (K == 1 ? NC_KC_CONV_K1 : NC_KC_CONV_MISC));
+    L.conv.build(dense, bias ? static_cast<const float*>(bias->data) : nullptr, Cin, Cout, K, stride, 0, 1, 0, transposed);
+    if (cfg.time_group_norm) {
+        const BlobTensor& gw = b.get(key + ".norm.weight");
+        const BlobTensor& gb = b.get(key + ".norm.bias");
+        if (gw.numel() != Cout || gb.numel() != Cout) fail(NC_EINVAL, "%s.norm has the wrong shape", key.c_str());
+        upload(L.gamma, static_cast<const float*>(gw.data), Cout);
+        upload(L.beta, static_cast<const float*>(gb.data), Cout);
+    }
+}
+
+void EncodecModel::load_resblock(const Blob& b, const std::string& key, ResBlock& r, int dim) {
+    const int h = dim / cfg.compress;
+    load_sconv(b, key + ".block.1", r.c1, dim, h, cfg.residual_kernel_size, 1, false);
+    load_sconv(b, key + ".block.3", r.c2, h, dim, 1, 1, false);
+    load_sconv(b, key + ".shortcut", r.sc, dim, dim, 1, 1, false);
+}
+
+void EncodecModel::load_lstm(const Blob& b, const std::string& key, Lstm& l, int C) {
+    l.C = C;
+    l.layers.clear();
+    for (int i = 0; i < cfg.lstm_layers; ++i) {
+        l.layers.emplace_back(new LstmLayer());
+        LstmLayer& y = *l.layers.back();
+        char sfx[32];
+        snprintf(sfx, sizeof sfx, "_l%d", i);
+        const BlobTensor& wih = b.get(key + ".lstm.weight_ih" + sfx);
+        const BlobTensor& whh = b.get(key + ".lstm.weight_hh" + sfx);
+        const BlobTensor& bih = b.get(key + ".lstm.bias_ih" + sfx);
+        const BlobTensor& bhh = b.get(key + ".lstm.bias_hh" + sfx);
+        if (wih.numel() != (int64_t)4 * C * C || whh.numel() != (int64_t)4 * C * C || bih.numel() != 4 * C || bhh.numel() != 4 * C)
+            fail(NC_EINVAL, "%s: LSTM tensors have the wrong shape", key.c_str());
+        y.ih.kclass = NC_KC_CONV_K1;
+        y.ih.build(static_cast<const float*>(wih.data), static_cast<const float*>(bih.data), C, 4 * C, 1, 1, 0, 1, 0, false);
+        upload(y.whh, static_cast<const float*>(whh.data), (size_t)4 * C * C);
+        upload(y.bhh, static_cast<const float*>(bhh.data), (size_t)4 * C);
+    }
+}
+
+void EncodecModel::load(const Blob& b) {
+    use_device();
+    char nm[128];
+    const int nf = cfg.n_filters;
+    load_sconv(b, "encoder.layers.0", enc_in, cfg.channels, nf, cfg.kernel_size, 1, false);
+    int n = 1, mult = 1;
+    for (int i = 0; i < cfg.n_ratios; ++i) {
+        const int r = cfg.ratios[cfg.n_ratios - 1 - i], d = mult * nf;
+        snprintf(nm, sizeof nm, "encoder.layers.%d", n);
+        load_resblock(b, nm, enc_res[i], d);
+        snprintf(nm, sizeof nm, "encoder.layers.%d", n + 2);
+        load_sconv(b, nm, enc_down[i], d, 2 * d, 2 * r, r, false);
+        n += 3;
+        mult *= 2;
+    }
+    snprintf(nm, sizeof nm, "encoder.layers.%d", n);
+    load_lstm(b, nm, enc_lstm, mult * nf);
+    snprintf(nm, sizeof nm, "encoder.layers.%d", n + 2);
+    load_sconv(b, nm, enc_out, mult * nf, cfg.dimension, cfg.last_kernel_size, 1, false);
+    books.clear();
+    std::vector<const float*> ptrs;
+    for (int i = 0; i < cfg.n_codebooks; ++i) {
+        snprintf(nm, sizeof nm, "quantizer.layers.%d.codebook.embed", i);
+        const BlobTensor& e = b.get(nm);
+        if (e.dims.size() != 2 || e.dims[0] != cfg.codebook_size || e.dims[1] != cfg.dimension) fail(NC_EINVAL, "%s has the wrong shape", nm);
+        books.emplace_back(new Codebook());
+        books.back()->build(static_cast<const float*>(e.data), cfg.codebook_size, cfg.dimension);
+        ptrs.push_back(books.back()->cb.as<float>());
+    }
+    book_ptrs.reserve(ptrs.size() * sizeof(float*));
+    NC_HIP(hipMemcpy(book_ptrs.p, ptrs.data(), ptrs.size() * sizeof(float*), hipMemcpyHostToDevice));
+    load_sconv(b, "decoder.layers.0", dec_in, cfg.dimension, mult * nf, cfg.kernel_size, 1, false);
+    load_lstm(b, "decoder.layers.1", dec_lstm, mult * nf);
+    n = 2;
+    for (int i = 0; i < cfg.n_ratios; ++i) {
+        const int r = cfg.ratios[i], d = mult * nf;
+        snprintf(nm, sizeof nm, "decoder.layers.%d", n + 1);
+        load_sconv(b, nm, dec_up[i], d, d / 2, 2 * r, r, true);
+        snprintf(nm, sizeof nm, "decoder.layers.%d", n + 2);
+        load_resblock(b, nm, dec_res[i], d / 2);
+        n += 3;
+        mult /= 2;
+    }
+    snprintf(nm, sizeof nm, "decoder.layers.%d", n + 1);
+    load_sconv(b, nm, dec_out, nf, cfg.channels, cfg.last_kernel_size, 1, false);
+    NC_HIP(hipDeviceSynchronize());
+    loaded = true;
+}
+
+// ---- launch helpers --------------------------------------------------------------------------------
+float* EncodecModel::alloc(size_t n_floats) {
+    if (pool_i == pool.size()) pool.emplace_back(new DevBuf());
+    pool[pool_i]->reserve(n_floats * sizeof(float));
+    return pool[pool_i++]->as<float>();
+}
+
+static ActView view_of(const EncodecModel::Act& a) {
+    ActView v;
+    v.p = a.p; v.rs = a.rs; v.off = a.off; v.stats = a.stats; v.gamma = a.gamma; v.beta = a.beta;
+    return v;
+}
+
+float* EncodecModel::pad_act(const Act& a, const Act* b2, bool elu, int N, const Plan& pl) {
+    float* dst = alloc((size_t)N * a.C * pl.Lp);
+    const int64_t n = (int64_t)N * a.C * pl.Lp;
+    ActView vb = b2 ? view_of(*b2) : view_of(a);
+    hipLaunchKernelGGL(pad_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, view_of(a), vb, b2 ? 1 : 0, elu ? 1 : 0, dst, N,
+                       a.C, a.L, pl.Lz, pl.left, pl.Lp);
+    NC_HIP(hipGetLastError());
+    return dst;
+}
+
+const float* EncodecModel::gn_stats(const float* raw, int N, int C, int64_t L) {
+    if (!cfg.time_group_norm) return nullptr;
+    const int nchunk = (int)((L + GN_CHUNK - 1) / GN_CHUNK);
+    const int64_t nparts = (int64_t)N * C * nchunk;
+    double* part = reinterpret_cast<double*>(alloc((size_t)nparts * 4));
+    float* stats = alloc((size_t)N * 2);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3((unsigned)((nparts + 63) / 64)), dim3(64), 0, stream, raw, part, (int64_t)N * C, L, nchunk);
+    hipLaunchKernelGGL(gn_final_kernel, dim3((unsigned)N), dim3(256), (size_t)2 * C * sizeof(double), stream, part, stats, C, L, nchunk);
+    NC_HIP(hipGetLastError());
+    return stats;
+}
+
+// SConv1d.forward on an activated view: returns the raw conv output with its pending GroupNorm
+EncodecModel::Act EncodecModel::sconv(SConv& L, const Act& a, const Act* b2, bool elu, int N) {
+    const Plan pl = plan_sconv(a.L, L.K, L.stride, 1);
+    const float* xin;
+    const bool passthrough = !b2 && !elu && !a.stats && pl.left == 0 && pl.Lp == a.L && a.off == 0 && a.rs == a.L;
+    xin = passthrough ? a.p : pad_act(a, b2, elu, N, pl);
+    float* y = alloc((size_t)N * L.Cout * pl.Lout);
+    ConvIO io{};
+    io.x = xin; io.x_bstride = (int64_t)L.Cin * pl.Lp; io.x_cstride = pl.Lp; io.x_len = (int32_t)pl.Lp; io.Tin = pl.Lp;
+    io.y = y; io.y_bstride = (int64_t)L.Cout * pl.Lout; io.y_cstride = pl.Lout;
+    launch_conv(L.conv, io, N, stream, &prof);
+    Act o;
+    o.p = y; o.C = L.Cout; o.L = pl.Lout; o.rs = pl.Lout; o.off = 0;
+    o.stats = gn_stats(y, N, L.Cout, pl.Lout);
+    o.gamma = o.stats ? L.gamma.as<float>() : nullptr;
+    o.beta = o.stats ? L.beta.as<float>() : nullptr;
+    return o;
+}
+
+// SConvTranspose1d.forward (SConvTranspose1d.cs:116-139): conv-transpose, GroupNorm over the UNTRIMMED output, then the trim
+EncodecModel::Act EncodecModel::sconvT(SConv& L, const Act& a, const Act* b2, bool elu, int N) {
+    Plan pl; pl.left = 0; pl.right = 0; pl.Lz = a.L; pl.Lp = a.L; pl.Lout = a.L;
+    const float* xin = pad_act(a, b2, elu, N, pl);
+    const int64_t Lfull = (a.L - 1) * L.stride + L.K;
+    float* y = alloc((size_t)N * L.Cout * Lfull);
+    ConvIO io{};
+    io.x = xin; io.x_bstride = (int64_t)L.Cin * a.L; io.x_cstride = a.L; io.x_len = (int32_t)a.L; io.Tin = a.L;
+    io.y = y; io.y_bstride = (int64_t)L.Cout * Lfull; io.y_cstride = Lfull;
+    launch_conv(L.conv, io, N, stream, &prof);
+    const int64_t pt = L.K - L.stride;
+    int64_t right, left;
+    if (cfg.causal) { right = pt; left = 0; }                                               // trimRightRatio = 1
+    else { right = pt / 2; left = pt - right; }
+    Act o;
+    o.p = y; o.C = L.Cout; o.L = Lfull - left - right; o.rs = Lfull; o.off = left;
+    o.stats = gn_stats(y, N, L.Cout, Lfull);
+    o.gamma = o.stats ? L.gamma.as<float>() : nullptr;
+    o.beta = o.stats ? L.beta.as<float>() : nullptr;
+    return o;
+}
+
+// SEANetResnetBlock.forward (:72-85): shortcut(x) + conv1(elu(conv3(elu(x)))) -> the two pending views (s, y)
+void EncodecModel::resblock(ResBlock& r, const Act& x, int N, Act& s, Act& y) {
+    s = sconv(r.sc, x, nullptr, false, N);
+    Act h = sconv(r.c1, x, nullptr, true, N);
+    y = sconv(r.c2, h, nullptr, true, N);
+    // A row shorter than the k=3 pad takes SConv1d's small-input path (zero-extend, never trimmed: D9), so the block branch comes
+    // out LONGER than the 1x1 shortcut and the reference's add() would broadcast.  Such degenerate segments are rejected.
+    if (y.L != s.L) fail(NC_EINVAL, "segment too short: a residual block sees %lld samples", (long long)x.L);
+}
+
+// GroupNorm-apply of a view into a dense tensor (optionally x scale[b] / divided by scale[b])
+float* EncodecModel::materialize(const Act& a, int N, const float* scale, int mode) {
+    float* y = alloc((size_t)N * a.C * a.L);
+    const int64_t n = (int64_t)N * a.C * a.L;
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, view_of(a), scale, mode, y, N, a.C, a.L);
+    NC_HIP(hipGetLastError());
+    return y;
+}
+
+// SLSTM.forward (SLSTM.cs:40-57) on a dense x [N,C,T]; returns lstm(x) + x
+float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
+    const int C = l.C;
+    if (l.layers.empty()) return const_cast<float*>(x);
+    const float* in = x;
+    float* out = nullptr;
+    for (size_t li = 0; li < l.layers.size(); ++li) {
+        LstmLayer& y = *l.layers[li];
+        float* gi = alloc((size_t)N * 4 * C * T);
+        ConvIO io{};
+        io.x = in; io.x_bstride = (int64_t)C * T; io.x_cstride = T; io.x_len = (int32_t)T; io.Tin = T;
+        io.y = gi; io.y_bstride = (int64_t)4 * C * T; io.y_cstride = T;
+        launch_conv(y.ih, io, N, stream, &prof);
+        float* h0 = alloc((size_t)C * N);
+        float* h1 = alloc((size_t)C * N);
+        float* cs = alloc((size_t)C * N);
+        NC_HIP(hipMemsetAsync(h0, 0, (size_t)C * N * 4, stream));
+        NC_HIP(hipMemsetAsync(cs, 0, (size_t)C * N * 4, stream));
+        out = alloc((size_t)N * C * T);
+        const bool last = li + 1 == l.layers.size();
+        if (prof.on) prof.begin(stream, NC_KC_ELEM, 2.0 * 4 * C * C * (double)N * T, 0.0);
+        for (int64_t t = 0; t < T; ++t) {
+            hipLaunchKernelGGL(lstm_step_kernel, dim3((unsigned)C, (unsigned)((N + 63) / 64)), dim3(64), (size_t)4 * C * sizeof(float), stream, gi,
+                               y.whh.as<float>(), y.bhh.as<float>(), (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, cs, last ? x : nullptr, out, N, C, T, t);
+        }
+        NC_HIP(hipGetLastError());
+        if (prof.on) prof.end(stream);
+        in = out;
+    }
+    return out;
+}
+
+// EncodeFrame on N = clips of one segment length: x [N,channels,L] dense -> codes [N,n_q,T'] (+ scale [N], emb)
+void EncodecModel::encode_batch(const float* x, int N, int64_t L, int64_t Tz, int64_t* codes, float* scale_out, float* emb_out) {
+    Act cur;
+    cur.p = x; cur.C = cfg.channels; cur.L = L; cur.rs = L; cur.off = 0; cur.stats = nullptr; cur.gamma = cur.beta = nullptr;
+    if (cfg.normalize) {
+        const int nchunk = (int)((L + GN_CHUNK - 1) / GN_CHUNK);
+        double* part = reinterpret_cast<double*>(alloc((size_t)N * nchunk * 2));
+        float* sc = scale_out ? scale_out : alloc((size_t)N);
+        hipLaunchKernelGGL(rms_partial_kernel, dim3((unsigned)(((int64_t)N * nchunk + 63) / 64)), dim3(64), 0, stream, x, part, N, cfg.channels, L, nchunk);
+        hipLaunchKernelGGL(rms_final_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, stream, part, sc, N, L, nchunk);
+        cur.p = materialize(cur, N, sc, 0);
+    }
+    cur = sconv(enc_in, cur, nullptr, false, N);
+    for (int i = 0; i < cfg.n_ratios; ++i) {
+        Act s, y;
+        resblock(enc_res[i], cur, N, s, y);
+        cur = sconv(enc_down[i], s, &y, true, N);
+    }
+    const float* xl = materialize(cur, N, nullptr, 0);
+    Act a;
+    a.p = run_lstm(enc_lstm, xl, N, cur.L); a.C = cur.C; a.L = cur.L; a.rs = cur.L; a.off = 0; a.stats = nullptr; a.gamma = a.beta = nullptr;
+    Act e = sconv(enc_out, a, nullptr, true, N);
+    if (e.L != Tz) fail(NC_ESTATE, "internal: encoder produced %lld frames, expected %lld", (long long)e.L, (long long)Tz);
+    float* residual = materialize(e, N, nullptr, 0);
+    const int D = cfg.dimension;
+    if (emb_out) NC_HIP(hipMemcpyAsync(emb_out, residual, (size_t)N * D * Tz * 4, hipMemcpyDeviceToDevice, stream));
+    const int64_t total = (int64_t)N * Tz;
+    if (prof.on) prof.begin(stream, NC_KC_RVQ, 3.0 * 2.0 * D * cfg.codebook_size * (double)total * n_q, 0.0);
+    for (int q = 0; q < n_q; ++q) {
+        Codebook& cb = *books[q];
+        hipLaunchKernelGGL(euclid_vq_kernel, dim3((unsigned)((total + EQ_F - 1) / EQ_F)), dim3(256), 0, stream, residual, cb.cbT.as<float>(),
+                           cb.cb.as<float>(), cb.c2.as<float>(), cb.N, D, N, Tz, codes + (int64_t)q * Tz, (int64_t)n_q * Tz);
+    }
+    NC_HIP(hipGetLastError());
+    if (prof.on) prof.end(stream);
+}
+
+// DecodeFrame on N clips: codes [N,n_q,T'] -> out [N,channels,Lout] dense (x scale[n] when given)
+float* EncodecModel::decode_batch(const int64_t* codes, int N, int nq, int64_t Tz, const float* scale, int64_t* Lout) {
+    const int D = cfg.dimension;
+    float* emb = alloc((size_t)N * D * Tz);
+    {
+        const int64_t n = (int64_t)N * D * Tz;
+        hipLaunchKernelGGL(emb_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, codes, book_ptrs.as<const float*>(), nq,
+                           cfg.codebook_size, D, N, Tz, emb);
+        NC_HIP(hipGetLastError());
+    }
+    Act cur;
+    cur.p = emb; cur.C = D; cur.L = Tz; cur.rs = Tz; cur.off = 0; cur.stats = nullptr; cur.gamma = cur.beta = nullptr;
+    cur = sconv(dec_in, cur, nullptr, false, N);
+    const float* xl = materialize(cur, N, nullptr, 0);
+    Act a;
+    a.p = run_lstm(dec_lstm, xl, N, cur.L); a.C = cur.C; a.L = cur.L; a.rs = cur.L; a.off = 0; a.stats = nullptr; a.gamma = a.beta = nullptr;
+    Act s = a, y;
+    bool dual = false;
+    for (int i = 0; i < cfg.n_ratios; ++i) {
+        Act u = sconvT(dec_up[i], s, dual ? &y : nullptr, true, N);
+        resblock(dec_res[i], u, N, s, y);
+        dual = true;
+    }
+    Act o = sconv(dec_out, s, dual ? &y : nullptr, true, N);
+    *Lout = o.L;
+    return materialize(o, N, scale, 1);
+}
+
+void EncodecModel::encode_dev(const float* pcm, int B, int64_t T, int64_t* codes, float* scales, float* emb) {
+    if (!loaded) fail(NC_ESTATE, "weights not loaded (call nc_codec_load_weights first)");
+    if (!pcm || !codes) fail(NC_EINVAL, "pcm and codes must not be null");
+    if (B <= 0 || T <= 0 || T > ((int64_t)1 << 30)) fail(NC_EINVAL, "B and T must be positive");
+    use_device();
+    pool_i = 0;
+    const std::vector<Seg> segs = segments(T);
+    const int C = cfg.channels, D = cfg.dimension;
+    int64_t code_off = 0, emb_off = 0;
+    for (size_t f = 0; f < segs.size(); ++f) {
+        const Seg& s = segs[f];
+        // slice the segment out of [B,C,T] into a dense [B,C,len] tensor
+        float* x = alloc((size_t)B * C * s.len);
+        NC_HIP(hipMemcpy2DAsync(x, (size_t)s.len * 4, pcm + s.off, (size_t)T * 4, (size_t)s.len * 4, (size_t)B * C, hipMemcpyDeviceToDevice, stream));
+        float* sc = (cfg.normalize && scales) ? scales + (int64_t)f * B : nullptr;
+        encode_batch(x, B, s.len, s.frames, codes + code_off, sc, emb ? emb + emb_off : nullptr);
+        code_off += (int64_t)B * n_q * s.frames;
+        emb_off += (int64_t)B * D * s.frames;
+    }
+}
+
+void EncodecModel::decode_dev(const int64_t* codes, const float* scales, int B, int64_t T, int nq, float* pcm) {
+    if (!loaded) fail(NC_ESTATE, "weights not loaded (call nc_codec_load_weights first)");
+    if (!codes || !pcm) fail(NC_EINVAL, "codes and pcm must not be null");
+    if (B <= 0 || T <= 0) fail(NC_EINVAL, "No frames provided to decode");                    // Encodec.cs:215-218
+    if (nq <= 0 || nq > cfg.n_codebooks) fail(NC_EINVAL, "codes carry %d codebooks; the model has %d", nq, cfg.n_codebooks);
+    if (cfg.normalize && !scales) fail(NC_EINVAL, "this model normalises frames: scales must be given");
+    use_device();
+    pool_i = 0;
+    const std::vector<Seg> segs = segments(T);
+    if (segs.size() > 16) fail(NC_EUNSUPPORTED, "more than 16 segments per call");
+    const int C = cfg.channels;
+    OlaFrames fr{};
+    fr.n = (int)segs.size();
+    int64_t code_off = 0;
+    for (size_t f = 0; f < segs.size(); ++f) {
+        int64_t Lo = 0;
+        fr.p[f] = decode_batch(codes + code_off, B, nq, segs[f].frames, cfg.normalize ? scales + (int64_t)f * B : nullptr, &Lo);
+        fr.len[f] = Lo;
+        code_off += (int64_t)B * nq * segs[f].frames;
+    }
+    if (cfg.segment_length <= 0) {                                                           // single frame: DecodeFrame output as is
+        NC_HIP(hipMemcpyAsync(pcm, fr.p[0], (size_t)B * C * fr.len[0] * 4, hipMemcpyDeviceToDevice, stream));
+        return;
+    }
+    // triangular window + weight sum on the host (geometry only), AudioTensorDSP.cs:176-252
+    const int64_t stride = cfg.segment_stride, total = stride * (fr.n - 1) + fr.len[fr.n - 1], L0 = fr.len[0];
+    for (int f = 0; f < fr.n; ++f)
+        if (fr.len[f] > L0) fail(NC_EINVAL, "a later frame is longer than the first one");
+    std::vector<float> w((size_t)L0), sw((size_t)total, 0.0f);
+    for (int64_t i = 0; i < L0; ++i) {
+        const float t = (float)((double)(i + 1) / (double)(L0 + 1));
+        w[(size_t)i] = 0.5f - std::fabs(t - 0.5f);
+    }
+    for (int f = 0; f < fr.n; ++f)
+        for (int64_t i = 0; i < fr.len[f]; ++i) sw[(size_t)(f * stride + i)] = sw[(size_t)(f * stride + i)] + w[(size_t)i];
+    float mn = INFINITY;
+    for (float v : sw) mn = std::min(mn, v);
+    if (mn <= 1e-10f) for (float& v : sw) v = v + 1e-10f;
+    float* dw = alloc((size_t)L0);
+    float* dsw = alloc((size_t)total);
+    NC_HIP(hipMemcpyAsync(dw, w.data(), (size_t)L0 * 4, hipMemcpyHostToDevice, stream));
+    NC_HIP(hipMemcpyAsync(dsw, sw.data(), (size_t)total * 4, hipMemcpyHostToDevice, stream));
+    NC_HIP(hipStreamSynchronize(stream));   // w / sw are stack-owned host vectors
+    const int64_t n = (int64_t)B * C * total;
+    hipLaunchKernelGGL(overlap_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, fr, dw, dsw, (int64_t)B * C, stride, total, pcm);
+    NC_HIP(hipGetLastError());
+}
+
+}  // namespace nc

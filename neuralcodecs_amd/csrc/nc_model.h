@@ -150,4 +150,64 @@ struct SnacModel : Codec {
     void reserve_act(int B, int64_t Tp);
 };
 
+struct EncodecModel : Codec {
+    nc_encodec_config cfg{};
+    int hop = 1, n_q = 1;
+
+    struct SConv {                 // SConv1d / SConvTranspose1d: conv (+ GroupNorm affine when time_group_norm)
+        int K = 0, stride = 1, Cin = 0, Cout = 0;
+        bool transposed = false;
+        ConvLayer conv;
+        DevBuf gamma, beta;
+    };
+    struct ResBlock { SConv c1, c2, sc; };
+    struct LstmLayer { ConvLayer ih; DevBuf whh, bhh; };
+    struct Lstm { int C = 0; std::vector<std::unique_ptr<LstmLayer>> layers; };
+    struct Plan { int64_t left = 0, right = 0, Lz = 0, Lp = 0, Lout = 0; };
+    struct Seg { int64_t off = 0, len = 0, frames = 0; };
+    struct Act {                   // [N,C,L] view of a raw conv output + its pending GroupNorm
+        const float* p = nullptr;
+        int C = 0;
+        int64_t L = 0, rs = 0, off = 0;
+        const float* stats = nullptr;
+        const float* gamma = nullptr;
+        const float* beta = nullptr;
+    };
+
+    SConv enc_in, enc_down[8], enc_out, dec_in, dec_up[8], dec_out;
+    ResBlock enc_res[8], dec_res[8];
+    Lstm enc_lstm, dec_lstm;
+    std::vector<std::unique_ptr<Codebook>> books;
+    DevBuf book_ptrs;
+
+    std::vector<std::unique_ptr<DevBuf>> pool;   // per-call intermediates, same allocation order every call (grow-only)
+    size_t pool_i = 0;
+    DevBuf h_in, h_out, h_codes, h_scales, h_emb;
+
+    explicit EncodecModel(const nc_encodec_config& c);
+    void load(const Blob& blob) override;
+    void set_bandwidth(float bw);
+    Plan plan_sconv(int64_t L, int k, int stride, int dil) const;
+    int64_t frames_for(int64_t L) const;
+    int64_t decoded_for(int64_t Tz) const;
+    std::vector<Seg> segments(int64_t T) const;
+    void encode_dev(const float* pcm, int B, int64_t T, int64_t* codes, float* scales, float* emb);
+    void decode_dev(const int64_t* codes, const float* scales, int B, int64_t T, int nq, float* pcm);
+
+  private:
+    void load_sconv(const Blob& b, const std::string& key, SConv& L, int Cin, int Cout, int K, int stride, bool transposed);
+    void load_resblock(const Blob& b, const std::string& key, ResBlock& r, int dim);
+    void load_lstm(const Blob& b, const std::string& key, Lstm& l, int C);
+    float* alloc(size_t n_floats);
+    float* pad_act(const Act& a, const Act* b2, bool elu, int N, const Plan& pl);
+    const float* gn_stats(const float* raw, int N, int C, int64_t L);
+    Act sconv(SConv& L, const Act& a, const Act* b2, bool elu, int N);
+    Act sconvT(SConv& L, const Act& a, const Act* b2, bool elu, int N);
+    void resblock(ResBlock& r, const Act& x, int N, Act& s, Act& y);
+    float* materialize(const Act& a, int N, const float* scale, int mode);
+    float* run_lstm(Lstm& l, const float* x, int N, int64_t T);
+    void encode_batch(const float* x, int N, int64_t L, int64_t Tz, int64_t* codes, float* scale_out, float* emb_out);
+    float* decode_batch(const int64_t* codes, int N, int nq, int64_t Tz, const float* scale, int64_t* Lout);
+};
+
 }  // namespace nc

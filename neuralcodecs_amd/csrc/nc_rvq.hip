@@ -95,7 +95,6 @@ __global__ __launch_bounds__(256) void vq_gather_kernel(const float* __restrict_
 void Codebook::build(const float* h, int N_, int D_) {
     N = N_;
     D = D_;
-    if (D > VQ_MAX_D) fail(NC_EUNSUPPORTED, "codebook_dim %d > %d", D, VQ_MAX_D);
     std::vector<float> t((size_t)N * D), n2(N);
     for (int n = 0; n < N; ++n) {
         float a = 0.0f;
@@ -117,6 +116,7 @@ static bool g_vq_attr = false;
 
 void launch_vq_argmin(const Codebook& cb, const float* z_e, int64_t ze_bstride, int B, int64_t T, int64_t* codes,
                       int64_t codes_bstride, float* st, hipStream_t s, Profiler* prof) {
+    if (cb.D > VQ_MAX_D) fail(NC_EUNSUPPORTED, "codebook_dim %d > %d", cb.D, VQ_MAX_D);
     const size_t lds = sizeof(float) * ((size_t)cb.D * cb.N + cb.N);
     if (lds > 160 * 1024) fail(NC_EUNSUPPORTED, "codebook of %d x %d does not fit LDS", cb.N, cb.D);
     if (!g_vq_attr) {

@@ -224,6 +224,7 @@ static float* resblock(ref_encodec* m, const char* key, float* x, int64_t B, int
     snprintf(nm, sizeof nm, "%s.block.3", key);
     float* y = sconv(m, nm, a, B, Ch, Lh, 1, 1, 1, &Co, &Lo);
     free(a);
+    if (Lo != L || Co != C) { m->bad = 1; free(s); free(x); return y; }   /* degenerate: block branch longer than the shortcut (D9) */
     for (int64_t i = 0; i < B * C * L; i++) y[i] = s[i] + y[i];
     free(s); free(x);
     return y;
