@@ -54,8 +54,11 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # NC_BENCH_FORCE_DIST=1 exercises the RCCL path (process group, side-stream all-gather, barrier) with a single rank
+    use_dist = world > 1 or os.environ.get("NC_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = DACConfig.dac_44khz()
@@ -69,14 +72,14 @@ def main():
     pcm_h = synthetic_pcm(B, 1, T, cfg.sample_rate, seed=1234 + rank * B)
     pcm = torch.from_numpy(pcm_h).to(dev)
     Tz = model.frames(T)
-    gathered = torch.empty((world * B, cfg.n_codebooks, Tz), dtype=torch.int64, device=dev) if world > 1 else None
-    side = torch.cuda.Stream(device=dev) if world > 1 else None
+    gathered = torch.empty((world * B, cfg.n_codebooks, Tz), dtype=torch.int64, device=dev) if use_dist else None
+    side = torch.cuda.Stream(device=dev) if use_dist else None
 
     from neuralcodecs_amd import parallel
 
     def step():
         z, codes, lat, _, _ = model.encode(pcm)
-        if world > 1:
+        if use_dist:
             # all-gather the emitted codes on a side stream; the local decode only needs local z
             ev = torch.cuda.Event()
             ev.record()
@@ -84,12 +87,12 @@ def main():
                 side.wait_event(ev)
                 parallel.all_gather_codes(codes, world * B, out=gathered)
         audio = model.decode(z)
-        if world > 1:
+        if use_dist:
             torch.cuda.current_stream().wait_stream(side)
         return codes, z, audio
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -105,7 +108,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = model.profile_read()
     model.profile_enable(False)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -120,10 +123,18 @@ def main():
         ach_tflops = (k7["flops"] / (k7["ms"] * 1e-3)) / 1e12 if k7["ms"] > 0 else 0.0
         total_kernel_ms = sum(v["ms"] for v in prof.values())
         total_flops = sum(v["flops"] for v in prof.values())
+        # HBM bytes per launch of the same kernel class from the PMC counters (separate rocprofv3 --pmc passes of this command,
+        # FETCH_SIZE doubled per MI355X_MICROARCH.md; summary committed under profiles/): a measured constant of the build
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_conv_k7.json")
+        if os.path.exists(tpath) and B == 32 and abs(args.seconds - 1.0) < 1e-9:
+            traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
         roofline = {
             "kernel": "conv_mfma_kernel<K=7> (dilated k=7 residual-unit conv, fp32 MFMA implicit GEMM)",
             "bound": "mfma", "achieved": round(ach_tflops, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach_tflops / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(ach_tflops / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_dac_b32.hbm_traffic_pmc.txt)",
+            "algorithmic_bytes_per_launch": round(k7["bytes"] / max(k7["launches"], 1)),
             "launches_per_step": k7["launches"] / max(args.steps, 1),
             "avg_launch_ms": k7["ms"] / max(k7["launches"], 1),
             "flops_per_launch": k7["flops"] / max(k7["launches"], 1),
@@ -156,12 +167,14 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DAC 44.1kHz 8kbps encode+decode, batch=%d x %.0f s clips per GPU (BASELINE configs[1])" % (B, args.seconds),
                        "clips_per_gpu": B, "clip_seconds": args.seconds, "global_batch": world * B,
-                       "collective": "RCCL all_gather of int64 codes [B,9,87] per rank" if world > 1 else "none"},
+                       "collective": "RCCL all_gather of int64 codes [B,9,87] per rank" if use_dist else "none"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
+    if use_dist and rank == 0 and args.check:
+        assert torch.equal(gathered[:B], codes), "gathered codes differ from the local codes"
     model.dispose()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

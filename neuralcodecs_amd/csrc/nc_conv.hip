@@ -1,5 +1,6 @@
 // Host side of the implicit-GEMM convolution: tile selection, weight packing, launch.
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <set>
 
@@ -176,7 +177,8 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     TileCfg c = L.cfg;
     const int64_t Tout = L.out_len(io.Tin);
     const int64_t n_cols_all = L.transposed ? io.Tin + L.Ktaps - 1 : Tout;
-    c.TN = n_cols_all >= 192 ? 2 : 1;  // 256-column tiles for long clips, 128 for the deep (short) layers
+    static const int tn_thresh = std::getenv("NC_TN_THRESH") ? atoi(std::getenv("NC_TN_THRESH")) : 192;
+    c.TN = n_cols_all >= tn_thresh ? 2 : 1;  // 256-column tiles for long clips, 128 for the deep (short) layers
     {   // the per-lane staging registers bound the window: fall back to 128-column tiles when it does not fit
         const int sx0 = L.transposed ? 1 : L.stride, ad0 = L.transposed ? 1 : L.dil;
         const int xw2 = (c.BN() - 1) * sx0 + (L.Ktaps - 1) * ad0 + 1;
