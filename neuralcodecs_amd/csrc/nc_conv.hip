@@ -40,6 +40,7 @@ int conv_kernel_nx_k16();
 #define NC_K_CASES(X) X(1) X(2) X(3) X(4) X(6) X(7) X(8) X(10) X(16)
 
 conv_kernel_fn conv_kernel_table_fused_k7(int, int);
+conv_kernel_fn conv1x1_kernel_table(int);
 
 static int cb_for_k(int K) {
     switch (K) {
@@ -173,7 +174,42 @@ bool can_fuse_res_unit(const ConvLayer& k7, const ConvLayer& k1) {
 static std::mutex g_attr_mu;
 static std::set<const void*> g_attr_done;
 
+// Pointwise fast path (nc_conv1x1.hip): B fragments straight from global memory, 2-wide vector loads/stores.
+static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream, Profiler* prof) {
+    static const bool off = std::getenv("NC_NO_CONV1X1") && std::getenv("NC_NO_CONV1X1")[0] == '1';
+    const int64_t T = io.Tin;
+    if (off || L.transposed || L.K != 1 || L.stride != 1 || L.pad != 0 || L.cfg.CB != 16 || io.fuse_k1) return false;
+    if (io.alpha_in || io.alpha_out || (io.epi & ~EPI_NOISE) || T < 2 || (T & 1) || io.x_len != T) return false;
+    if ((io.x_cstride & 1) || (io.x_bstride & 1) || (io.y_cstride & 1) || (io.y_bstride & 1)) return false;
+    auto al8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; };
+    if (!al8(io.x) || !al8(io.y) || (io.res && !al8(io.res)) || (io.noise && !al8(io.noise))) return false;
+    if ((io.epi & EPI_NOISE) && (!io.noise || !io.res)) return false;
+    conv_kernel_fn fn = conv1x1_kernel_table(L.cfg.TM);
+    if (!fn) return false;
+    ConvArgs a{};
+    a.x = io.x; a.x_bstride = io.x_bstride; a.x_cstride = io.x_cstride; a.Cin = L.Cin; a.x_len = io.x_len;
+    a.w = L.w.as<float>();
+    a.bias = L.has_bias ? L.bias.as<float>() : nullptr;
+    a.res = io.res; a.noise = io.noise; a.noise_bstride = T; a.epi = io.epi;
+    a.y = io.y; a.y_bstride = io.y_bstride; a.y_cstride = io.y_cstride;
+    a.Cout = L.Cout; a.B = B; a.Tout = (int32_t)T;
+    const int BM = L.cfg.BM();
+    a.n_co_tiles = (L.Cout + BM - 1) / BM;
+    a.n_t_tiles = (int32_t)((T + 255) / 256);
+    a.n_cb = (L.Cin + 15) / 16;
+    const int64_t grid = (int64_t)a.n_co_tiles * B * a.n_t_tiles;
+    if (prof && prof->on) {
+        const double bytes = 4.0 * ((double)B * L.Cin * T + (double)B * L.Cout * T * (io.res ? 2 : 1) + (double)L.Cin * L.Cout);
+        prof->begin(stream, L.kclass, L.flops(B, T), bytes);
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    NC_HIP(hipGetLastError());
+    if (prof && prof->on) prof->end(stream);
+    return true;
+}
+
 void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream, Profiler* prof) {
+    if (launch_conv1x1(L, io, B, stream, prof)) return;
     TileCfg c = L.cfg;
     const int64_t Tout = L.out_len(io.Tin);
     const int64_t n_cols_all = L.transposed ? io.Tin + L.Ktaps - 1 : Tout;

@@ -1,0 +1,170 @@
+// Pointwise (k=1) convolution on the fp32 matrix cores with register-fed B fragments.
+//
+// A 1x1 conv is the plain GEMM  Y[Cout, T] = W[Cout, Cin] . X[Cin, T]  per clip (ResidualUnit.cs:33 / Modules/SNAC/ResidualUnit.cs:33
+// second conv, NoiseBlock.cs:38, LocalMHA.cs:92,112 projections, SLSTM input projections).  Unlike the k>1 convolutions there is no tap
+// reuse and no halo, and each wavefront's columns are private to it, so staging X through LDS buys nothing: the B fragment of MFMA step kp
+// (lane l: X[ci = 2*kp + (l>>5)][col(l&31, j)]) is loaded straight from global memory, TN consecutive columns per lane in one
+// 4*TN-byte load, through a rolling register pipeline PF steps deep.  Only the weight tile (shared by the 4 waves) goes through LDS,
+// double-buffered, one barrier per CB input channels.  Column permutation: column of (lane, j) = col0 + wave*32*TN + TN*lane + j, so
+// loads and stores are TN-wide vectors.  Accumulation order per output = ci ascending from +0, then + bias, then + residual: the
+// canonical chain of DESIGN.md, bit-identical to the generic conv template and the oracle.
+#include <algorithm>
+#include <mutex>
+#include <set>
+
+#include "nc_conv.h"
+#include "nc_math.h"
+
+namespace nc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int TM, int CB>
+__global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvArgs p) {
+    constexpr int TN = 2;
+    constexpr int BM = 32 * TM;
+    constexpr int BNW = 32 * TN;
+    constexpr int BN = 4 * BNW;
+    constexpr int KP = CB / 2;
+    constexpr int A_FLOATS = CB * BM;
+    constexpr int A_VEC = A_FLOATS / 4;
+    constexpr int NA = (A_VEC + 255) / 256;
+    constexpr int PF = 4;                       // B prefetch distance in MFMA steps (divides KP)
+    static_assert(KP % PF == 0, "prefetch ring must divide the reduction block");
+
+    __shared__ __attribute__((aligned(16))) float As[2][A_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hi = lane >> 5;
+
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    int lin;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int t_tile = lin % p.n_t_tiles;
+    lin /= p.n_t_tiles;
+    const int b = lin % p.B;
+    const int co_tile = lin / p.B;
+
+    const int T = p.Tout;
+    const int n_cb = p.n_cb, Cin = p.Cin;
+    const unsigned x_cstride = (unsigned)p.x_cstride;
+    const int col = t_tile * BN + wave * BNW + TN * l31;          // first of this lane's TN columns
+    const int colc = min(col, T - TN);                             // clamped (T % TN == 0, T >= TN): loads stay inside the row
+    const float* const xb = p.x + (int64_t)b * p.x_bstride + colc;
+    const f32x4* const wbase = reinterpret_cast<const f32x4*>(p.w + (int64_t)co_tile * n_cb * A_FLOATS);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // B ring: step g (global MFMA step index) uses channel ci = 2g + hi
+    f32x2 bq[PF];
+    auto load_b = [&](int g) __attribute__((always_inline)) {
+        const int ci = min(2 * g + hi, Cin - 1);                  // channels past Cin meet zero weights
+        return *reinterpret_cast<const f32x2*>(xb + (unsigned)ci * x_cstride);
+    };
+    const int n_steps = n_cb * KP;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) bq[u] = load_b(u);
+
+    // A tile 0
+    f32x4 ra[NA];
+#pragma unroll
+    for (int n = 0; n < NA; ++n) {
+        const int idx = tid + 256 * n;
+        if ((A_VEC % 256 == 0) || idx < A_VEC) reinterpret_cast<f32x4*>(As[0])[idx] = wbase[idx];
+    }
+    __syncthreads();
+
+    const int a_lane = hi * BM + l31;
+    for (int cb = 0; cb < n_cb; ++cb) {
+        const int cur = cb & 1;
+        const bool more = cb + 1 < n_cb;
+        if (more) {
+            const f32x4* src = wbase + (size_t)(cb + 1) * A_VEC;
+#pragma unroll
+            for (int n = 0; n < NA; ++n) {
+                const unsigned idx = (unsigned)(tid + 256 * n);
+                ra[n] = src[(A_VEC % 256 == 0) ? idx : min(idx, (unsigned)(A_VEC - 1))];
+            }
+        }
+        const float* Ac = As[cur] + a_lane;
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+            float a[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = Ac[2 * kp * BM + i * 32];
+            const f32x2 bv = bq[kp % PF];
+            const int g = cb * KP + kp + PF;
+            if (g < n_steps) bq[kp % PF] = load_b(g);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[0], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[1], acc[i][1], 0, 0, 0);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int n = 0; n < NA; ++n) {
+                const int idx = tid + 256 * n;
+                if ((A_VEC % 256 == 0) || idx < A_VEC) reinterpret_cast<f32x4*>(As[cur ^ 1])[idx] = ra[n];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*hi] for this lane's TN consecutive columns
+    if (col >= T) return;
+    const int64_t ybase = (int64_t)b * p.y_bstride + col;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int co = co_tile * BM + row;
+            if (co >= p.Cout) continue;
+            const float bias = p.bias ? p.bias[co] : 0.0f;
+            const int64_t o = ybase + (int64_t)co * p.y_cstride;
+            f32x2 v;
+            v[0] = acc[i][0][r] + bias;
+            v[1] = acc[i][1][r] + bias;
+            if (p.epi & EPI_NOISE) {
+                const f32x2 rs = *reinterpret_cast<const f32x2*>(p.res + o);
+                const f32x2 nz = *reinterpret_cast<const f32x2*>(p.noise + (int64_t)b * p.noise_bstride + col);
+                v[0] = rs[0] + nz[0] * v[0];
+                v[1] = rs[1] + nz[1] * v[1];
+            } else if (p.res) {
+                const f32x2 rs = *reinterpret_cast<const f32x2*>(p.res + o);
+                v[0] = v[0] + rs[0];
+                v[1] = v[1] + rs[1];
+            }
+            *reinterpret_cast<f32x2*>(p.y + o) = v;
+        }
+}
+
+typedef void (*conv_kernel_fn)(const ConvArgs);
+
+conv_kernel_fn conv1x1_kernel_table(int TM) {
+    switch (TM) {
+        case 1: return &conv1x1_kernel<1, 16>;
+        case 2: return &conv1x1_kernel<2, 16>;
+        case 3: return &conv1x1_kernel<3, 16>;
+        case 4: return &conv1x1_kernel<4, 16>;
+    }
+    return nullptr;
+}
+
+}  // namespace nc
