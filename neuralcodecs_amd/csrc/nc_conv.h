@@ -39,6 +39,7 @@ struct ConvArgs {
     int64_t noise_bstride;
     const float* w2;               // fused residual unit: packed 1x1 weights [row block][ci][32], bias2 [Cout]
     const float* bias2;
+    const float* alpha_out2;       // fused residual unit: Snake of the layer consuming y (nullable)
     float* rvq_zq;                 // EPI_RVQ: zq += out ; rvq_res -= out  (same geometry as y)
     float* rvq_res;
     int32_t Cout, n_cols;          // columns (output steps per phase) handled by this launch
@@ -92,6 +93,7 @@ struct ConvIO {
     float* rvq_res = nullptr;
     const float* noise = nullptr;  // EPI_NOISE multiplier [B,1,Tout]
     int epi = 0;
+    const float* alpha_out2 = nullptr;          // with fuse_k1: Snake applied to the unit's output y (consumer's activation)
     const struct ConvLayer* fuse_k1 = nullptr;  // fused residual unit: the 1x1 layer applied to snake(alpha_out)(this conv) + res
 };
 

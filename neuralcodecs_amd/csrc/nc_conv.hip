@@ -179,7 +179,8 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
     static const bool off = std::getenv("NC_NO_CONV1X1") && std::getenv("NC_NO_CONV1X1")[0] == '1';
     const int64_t T = io.Tin;
     if (off || L.transposed || L.K != 1 || L.stride != 1 || L.pad != 0 || L.cfg.CB != 16 || io.fuse_k1) return false;
-    if (io.alpha_in || io.alpha_out || (io.epi & ~EPI_NOISE) || T < 2 || (T & 1) || io.x_len != T) return false;
+    if (io.alpha_in || (io.epi & ~EPI_NOISE) || T < 2 || (T & 1) || io.x_len != T) return false;
+    if (io.alpha_out && (io.epi & EPI_NOISE)) return false;
     if ((io.x_cstride & 1) || (io.x_bstride & 1) || (io.y_cstride & 1) || (io.y_bstride & 1)) return false;
     auto al8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; };
     if (!al8(io.x) || !al8(io.y) || (io.res && !al8(io.res)) || (io.noise && !al8(io.noise))) return false;
@@ -190,7 +191,7 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
     a.x = io.x; a.x_bstride = io.x_bstride; a.x_cstride = io.x_cstride; a.Cin = L.Cin; a.x_len = io.x_len;
     a.w = L.w.as<float>();
     a.bias = L.has_bias ? L.bias.as<float>() : nullptr;
-    a.res = io.res; a.noise = io.noise; a.noise_bstride = T; a.epi = io.epi;
+    a.res = io.res; a.noise = io.noise; a.noise_bstride = T; a.epi = io.epi; a.alpha_out = io.alpha_out;
     a.y = io.y; a.y_bstride = io.y_bstride; a.y_cstride = io.y_cstride;
     a.Cout = L.Cout; a.B = B; a.Tout = (int32_t)T;
     const int BM = L.cfg.BM();
@@ -273,6 +274,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
             fail(NC_ESTATE, "internal: residual unit is not fusable");
         a.w2 = io.fuse_k1->w_fused.as<float>();
         a.bias2 = io.fuse_k1->bias.as<float>();
+        a.alpha_out2 = io.alpha_out2;
         lds = std::max(lds, sizeof(float) * (size_t)BM * BM);
         fn = conv_kernel_table_fused_k7(c.TM, c.TN);
         if (!fn) fail(NC_EUNSUPPORTED, "no fused residual-unit kernel for TM=%d TN=%d", c.TM, c.TN);

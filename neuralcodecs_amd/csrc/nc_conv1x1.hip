@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvArgs p) {
     constexpr int A_FLOATS = CB * BM;
     constexpr int A_VEC = A_FLOATS / 4;
     constexpr int NA = (A_VEC + 255) / 256;
-    constexpr int PF = 4;                       // B prefetch distance in MFMA steps (divides KP)
+    constexpr int PF = 4;                       // B prefetch distance in MFMA steps (divides KP); deeper rings measured slower
     static_assert(KP % PF == 0, "prefetch ring must divide the reduction block");
 
     __shared__ __attribute__((aligned(16))) float As[2][A_FLOATS];
@@ -137,6 +137,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvArgs p) {
             const int co = co_tile * BM + row;
             if (co >= p.Cout) continue;
             const float bias = p.bias ? p.bias[co] : 0.0f;
+            const float ao = p.alpha_out ? p.alpha_out[co] : 0.0f;
+            const float ao_inv = nc_snake_inv(ao);
             const int64_t o = ybase + (int64_t)co * p.y_cstride;
             f32x2 v;
             v[0] = acc[i][0][r] + bias;
@@ -150,6 +152,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvArgs p) {
                 const f32x2 rs = *reinterpret_cast<const f32x2*>(p.res + o);
                 v[0] = v[0] + rs[0];
                 v[1] = v[1] + rs[1];
+            }
+            if (p.alpha_out) {   // Snake of the consuming layer, fused into the store
+                v[0] = nc_snakef(v[0], ao, ao_inv);
+                v[1] = nc_snakef(v[1], ao, ao_inv);
             }
             *reinterpret_cast<f32x2*>(p.y + o) = v;
         }

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[i][j][reg], acc2[j], 0, 0, 0);
             });
-            emit_rows(i2, acc2, p.bias2, nullptr, p.res);
+            emit_rows(i2, acc2, p.bias2, p.alpha_out2, p.res);
         });
     }
 }

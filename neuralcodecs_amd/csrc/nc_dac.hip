@@ -162,7 +162,7 @@ int64_t DacModel::decoded_len(int64_t fr) const {
 }
 
 // x + conv1(snake(conv7(snake(x))));  buffers rotate through act[0..2]
-float* DacModel::run_res_unit(ResUnit& ru, int dil, float* cur, int C, int64_t L, int B, int& cur_idx) {
+float* DacModel::run_res_unit(ResUnit& ru, int dil, float* cur, int C, int64_t L, int B, int& cur_idx, const float* alpha_next) {
     (void)dil;
     const int h_idx = (cur_idx + 1) % 3, o_idx = (cur_idx + 2) % 3;
     float* h = act[h_idx].as<float>();
@@ -172,7 +172,7 @@ float* DacModel::run_res_unit(ResUnit& ru, int dil, float* cur, int C, int64_t L
     io.alpha_in = ru.a1.as<float>(); io.alpha_out = ru.a2.as<float>();
     if (fuse_res_units && can_fuse_res_unit(ru.c7, ru.c1)) {
         // one launch: y = x + W1.snake(conv7(snake(x)) + b7) + b1 ; h never reaches HBM
-        io.res = cur; io.fuse_k1 = &ru.c1;
+        io.res = cur; io.fuse_k1 = &ru.c1; io.alpha_out2 = alpha_next;
         io.y = o; io.y_bstride = (int64_t)C * L; io.y_cstride = L;
         launch_conv(ru.c7, io, B, stream, &prof);
         cur_idx = o_idx;
@@ -182,7 +182,7 @@ float* DacModel::run_res_unit(ResUnit& ru, int dil, float* cur, int C, int64_t L
     launch_conv(ru.c7, io, B, stream, &prof);
     ConvIO i2{};
     i2.x = h; i2.x_bstride = (int64_t)C * L; i2.x_cstride = L; i2.x_len = (int32_t)L; i2.Tin = L;
-    i2.res = cur;
+    i2.res = cur; i2.alpha_out = alpha_next;
     i2.y = o; i2.y_bstride = (int64_t)C * L; i2.y_cstride = L;
     launch_conv(ru.c1, i2, B, stream, &prof);
     cur_idx = o_idx;
@@ -229,14 +229,16 @@ void DacModel::encode_dev(const float* pcm, int B, int64_t T, int sample_rate, i
         launch_conv(enc_stem, io, B, stream, &prof);
     }
     for (int bi = 0; bi < cfg.n_encoder_rates; ++bi) {
-        for (int u = 0; u < 3; ++u) cur = run_res_unit(enc[bi].ru[u], kDil[u], cur, C, L, B, cur_idx);
+        // the block output is consumed only through Snake(a_down) (EncoderBlock.cs:26): fuse it into the last unit's store
+        for (int u = 0; u < 3; ++u)
+            cur = run_res_unit(enc[bi].ru[u], kDil[u], cur, C, L, B, cur_idx, u == 2 ? enc[bi].a_down.as<float>() : nullptr);
         const int s = cfg.encoder_rates[bi];
         const int64_t Lo = enc[bi].down.out_len(L);
         const int o_idx = (cur_idx + 1) % 3;
         float* o = act[o_idx].as<float>();
         ConvIO io{};
         io.x = cur; io.x_bstride = (int64_t)C * L; io.x_cstride = L; io.x_len = (int32_t)L; io.Tin = L;
-        io.alpha_in = enc[bi].a_down.as<float>();
+        if (bi + 1 == cfg.n_encoder_rates) io.alpha_out = enc_alpha_out.as<float>();   // Encoder.cs:44 Snake, consumed by the k3 conv only
         io.y = o; io.y_bstride = (int64_t)2 * C * Lo; io.y_cstride = Lo;
         launch_conv(enc[bi].down, io, B, stream, &prof);
         (void)s;
@@ -247,7 +249,6 @@ void DacModel::encode_dev(const float* pcm, int B, int64_t T, int sample_rate, i
     {  // Snake -> conv k3 -> z, written straight into the RVQ residual buffer (residual = z.clone())
         ConvIO io{};
         io.x = cur; io.x_bstride = (int64_t)C * L; io.x_cstride = L; io.x_len = (int32_t)L; io.Tin = L;
-        io.alpha_in = enc_alpha_out.as<float>();
         io.y = residual; io.y_bstride = (int64_t)latent * Tz; io.y_cstride = Tz;
         launch_conv(enc_out, io, B, stream, &prof);
     }
@@ -310,6 +311,7 @@ void DacModel::decode_dev(const float* z, int B, int64_t Tz, float* pcm) {
     {
         ConvIO io{};
         io.x = z; io.x_bstride = (int64_t)latent * Tz; io.x_cstride = Tz; io.x_len = (int32_t)Tz; io.Tin = Tz;
+        io.alpha_out = dec[0].a_up.as<float>();   // consumed only through the first DecoderBlock's Snake (DecoderBlock.cs:24)
         io.y = cur; io.y_bstride = (int64_t)C * L; io.y_cstride = L;
         launch_conv(dec_in, io, B, stream, &prof);
     }
@@ -320,16 +322,15 @@ void DacModel::decode_dev(const float* z, int B, int64_t Tz, float* pcm) {
         float* o = act[o_idx].as<float>();
         ConvIO io{};
         io.x = cur; io.x_bstride = (int64_t)C * L; io.x_cstride = L; io.x_len = (int32_t)L; io.Tin = L;
-        io.alpha_in = dec[bi].a_up.as<float>();
         io.y = o; io.y_bstride = (int64_t)Co * Lo; io.y_cstride = Lo;
         launch_conv(dec[bi].up, io, B, stream, &prof);
         cur = o; cur_idx = o_idx; C = Co; L = Lo;
-        for (int u = 0; u < 3; ++u) cur = run_res_unit(dec[bi].ru[u], kDil[u], cur, C, L, B, cur_idx);
+        const float* a_next = bi + 1 < cfg.n_decoder_rates ? dec[bi + 1].a_up.as<float>() : dec_alpha_out.as<float>();
+        for (int u = 0; u < 3; ++u) cur = run_res_unit(dec[bi].ru[u], kDil[u], cur, C, L, B, cur_idx, u == 2 ? a_next : nullptr);
     }
     {
         ConvIO io{};
         io.x = cur; io.x_bstride = (int64_t)C * L; io.x_cstride = L; io.x_len = (int32_t)L; io.Tin = L;
-        io.alpha_in = dec_alpha_out.as<float>();
         io.y = pcm; io.y_bstride = L; io.y_cstride = L;
         io.epi = EPI_TANH;
         launch_conv(dec_out, io, B, stream, &prof);

@@ -85,7 +85,7 @@ struct DacModel : Codec {
     void from_codes_dev(const int64_t* codes, int B, int n_q, int64_t frames, float* z);
 
   private:
-    float* run_res_unit(ResUnit& ru, int dil, float* cur, int C, int64_t L, int B, int& cur_idx);
+    float* run_res_unit(ResUnit& ru, int dil, float* cur, int C, int64_t L, int B, int& cur_idx, const float* alpha_next);
 };
 
 struct SnacModel : Codec {
