@@ -145,8 +145,8 @@ struct SnacModel : Codec {
   private:
     void load_res_unit(const Blob& b, const std::string& q, ResUnit& ru, int C, int dil);
     void load_mha(const Blob& b, const std::string& p, Mha& m, int C);
-    float* run_res_unit(ResUnit& ru, float* cur, int C, int64_t L, int B, int& cur_idx);
-    float* run_mha(Mha& m, float* cur, int C, int64_t L, int B, int& cur_idx);
+    float* run_res_unit(ResUnit& ru, float* cur, int C, int64_t L, int B, int& cur_idx, const float* alpha_next);
+    float* run_mha(Mha& m, float* cur, int C, int64_t L, int B, int& cur_idx, const float* alpha_next);
     void reserve_act(int B, int64_t Tp);
 };
 

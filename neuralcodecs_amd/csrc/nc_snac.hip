@@ -237,7 +237,7 @@ static ConvIO io_for(const float* x, int C, int64_t L, float* y, int Cy, int64_t
 }
 
 // x + conv1(snake(conv7(snake(x))))
-float* SnacModel::run_res_unit(ResUnit& ru, float* cur, int C, int64_t L, int B, int& cur_idx) {
+float* SnacModel::run_res_unit(ResUnit& ru, float* cur, int C, int64_t L, int B, int& cur_idx, const float* alpha_next) {
     const int h_idx = (cur_idx + 1) % 3, o_idx = (cur_idx + 2) % 3;
     float* h = act[h_idx].as<float>();
     float* o = act[o_idx].as<float>();
@@ -249,14 +249,14 @@ float* SnacModel::run_res_unit(ResUnit& ru, float* cur, int C, int64_t L, int B,
         launch_conv(ru.c7, io, B, stream, &prof);
     }
     ConvIO i2 = io_for(h, C, L, o, C, L);
-    i2.res = cur;
+    i2.res = cur; i2.alpha_out = alpha_next;   // Snake of the only consumer, fused into the store
     launch_conv(ru.c1, i2, B, stream, &prof);
     cur_idx = o_idx;
     return o;
 }
 
 // LocalMHA.cs:78-115: LayerNorm -> qkv -> rotary windowed attention -> out projection + residual
-float* SnacModel::run_mha(Mha& m, float* cur, int C, int64_t L, int B, int& cur_idx) {
+float* SnacModel::run_mha(Mha& m, float* cur, int C, int64_t L, int B, int& cur_idx, const float* alpha_next) {
     if (L % cfg.attn_window_size != 0) fail(NC_EINVAL, "sequence of %lld frames is not a multiple of the attention window", (long long)L);
     const int n_idx = (cur_idx + 1) % 3, o_idx = (cur_idx + 2) % 3;
     float* xn = act[n_idx].as<float>();
@@ -267,7 +267,7 @@ float* SnacModel::run_mha(Mha& m, float* cur, int C, int64_t L, int B, int& cur_
     launch_conv(m.qkv, iq, B, stream, &prof);
     launch_local_attn(qkv_ws.as<float>(), m.cs.as<float>(), m.sn.as<float>(), xn, B, C, L, cfg.attn_window_size, stream);
     ConvIO io = io_for(xn, C, L, o, C, L);
-    io.res = cur;
+    io.res = cur; io.alpha_out = alpha_next;
     launch_conv(m.out, io, B, stream, &prof);
     cur_idx = o_idx;
     return o;
@@ -315,17 +315,16 @@ void SnacModel::encode_dev(const float* pcm, int B, int64_t T, int64_t* codes, f
         launch_conv(enc_stem, io, B, stream, &prof);
     }
     for (int bi = 0; bi < cfg.n_encoder_rates; ++bi) {
-        for (int u = 0; u < 3; ++u) cur = run_res_unit(enc[bi].ru[u], cur, C, L, B, cur_idx);
+        for (int u = 0; u < 3; ++u) cur = run_res_unit(enc[bi].ru[u], cur, C, L, B, cur_idx, u == 2 ? enc[bi].a_down.as<float>() : nullptr);
         const int64_t Lo = enc[bi].down.out_len(L);
         const int o_idx = (cur_idx + 1) % 3;
         float* o = act[o_idx].as<float>();
         ConvIO io = io_for(cur, C, L, o, 2 * C, Lo);
-        io.alpha_in = enc[bi].a_down.as<float>();
-        launch_conv(enc[bi].down, io, B, stream, &prof);
+        launch_conv(enc[bi].down, io, B, stream, &prof);   // input already carries Snake(a_down) (EncoderBlock.cs:42)
         cur = o; cur_idx = o_idx; C *= 2; L = Lo;
     }
     if (L != Tz) fail(NC_ESTATE, "internal: encoder produced %lld frames, expected %lld", (long long)L, (long long)Tz);
-    if (cfg.attn_window_size > 0) cur = run_mha(enc_mha, cur, C, L, B, cur_idx);
+    if (cfg.attn_window_size > 0) cur = run_mha(enc_mha, cur, C, L, B, cur_idx, nullptr);
     float* residual = resid.as<float>();
     if (cfg.depthwise) {
         launch_dwconv(enc_out_dw, cur, nullptr, nullptr, residual, B, L, stream, &prof);
@@ -403,13 +402,15 @@ void SnacModel::decode_dev(const int64_t* codes, int B, int64_t Tz, const float*
     if (cfg.depthwise) {
         launch_dwconv(dec_in_dw, zq.as<float>(), nullptr, nullptr, act[1].as<float>(), B, L, stream, &prof);
         ConvIO io = io_for(act[1].as<float>(), C, L, cur, cfg.decoder_dim, L);
+        if (cfg.attn_window_size <= 0) io.alpha_out = dec[0].a_up.as<float>();   // consumed only through DecoderBlock's Snake
         launch_conv(dec_in, io, B, stream, &prof);
     } else {
         ConvIO io = io_for(zq.as<float>(), C, L, cur, cfg.decoder_dim, L);
+        if (cfg.attn_window_size <= 0) io.alpha_out = dec[0].a_up.as<float>();
         launch_conv(dec_in, io, B, stream, &prof);
     }
     C = cfg.decoder_dim;
-    if (cfg.attn_window_size > 0) cur = run_mha(dec_mha, cur, C, L, B, cur_idx);
+    if (cfg.attn_window_size > 0) cur = run_mha(dec_mha, cur, C, L, B, cur_idx, dec[0].a_up.as<float>());
     int64_t noff = 0;
     for (int bi = 0; bi < cfg.n_decoder_rates; ++bi) {
         const int Co = C / 2;
@@ -417,8 +418,7 @@ void SnacModel::decode_dev(const int64_t* codes, int B, int64_t Tz, const float*
         int o_idx = (cur_idx + 1) % 3;
         float* o = act[o_idx].as<float>();
         ConvIO io = io_for(cur, C, L, o, Co, Lo);
-        io.alpha_in = dec[bi].a_up.as<float>();
-        launch_conv(dec[bi].up, io, B, stream, &prof);
+        launch_conv(dec[bi].up, io, B, stream, &prof);   // input already carries Snake(a_up) (DecoderBlock.cs:37)
         cur = o; cur_idx = o_idx; C = Co; L = Lo;
         if (cfg.noise) {   // x + noise * conv1x1_nobias(x)
             o_idx = (cur_idx + 1) % 3;
@@ -429,10 +429,10 @@ void SnacModel::decode_dev(const int64_t* codes, int B, int64_t Tz, const float*
             cur = o; cur_idx = o_idx;
             noff += (int64_t)B * L;
         }
-        for (int u = 0; u < 3; ++u) cur = run_res_unit(dec[bi].ru[u], cur, C, L, B, cur_idx);
+        const float* a_next = bi + 1 < cfg.n_decoder_rates ? dec[bi + 1].a_up.as<float>() : dec_alpha_out.as<float>();
+        for (int u = 0; u < 3; ++u) cur = run_res_unit(dec[bi].ru[u], cur, C, L, B, cur_idx, u == 2 ? a_next : nullptr);
     }
     ConvIO io = io_for(cur, C, L, pcm, 1, L);
-    io.alpha_in = dec_alpha_out.as<float>();
     io.epi = EPI_TANH;
     launch_conv(dec_out, io, B, stream, &prof);
 }
