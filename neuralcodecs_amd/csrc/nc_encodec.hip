@@ -9,6 +9,7 @@
 // LSTM input projections) run on the matrix-core conv template; the recurrent part of the LSTM is one launch per time step.
 // Arithmetic is the canonical arithmetic of DESIGN.md (same sequences as oracle/c/nc_ref_encodec.c).
 #include <cmath>
+#include <cstdlib>
 
 #include "nc_math.h"
 #include "nc_model.h"
@@ -169,6 +170,63 @@ __global__ __launch_bounds__(64) void lstm_step_kernel(const float* __restrict__
     hnext[(int64_t)j * B + b] = h;
     const int64_t o = ((int64_t)b * C + j) * T + t;
     out[o] = skip ? h + skip[o] : h;
+}
+
+// Matrix-core version of the LSTM step.  One wavefront owns 4 hidden units x 4 gates = 16 rows of W_hh and walks the 512-long
+// reduction with v_mfma_f32_16x16x4_f32 (an exact k-ordered fma chain, like the scalar kernel above), 16 clips per column tile.
+// Row r of the tile = unit (r>>2), gate (r&3), so the D fragment of lane l holds all four gate pre-activations of unit (l>>4),
+// clip (l&15) in its four registers and the cell update needs no cross-lane traffic.  whhp is W_hh re-packed as
+// [C/4 unit blocks][C/4 k-steps][64 lanes] so every A-fragment load is one coalesced 256-B row.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int CH>   // k-steps per register chunk; the loads of chunk c+1 are in flight while chunk c feeds the matrix core
+__global__ __launch_bounds__(256) void lstm_step_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ whhp,
+                                                             const float* __restrict__ bhh, const float* __restrict__ hprev,
+                                                             float* __restrict__ hnext, float* __restrict__ cst, const float* __restrict__ skip,
+                                                             float* __restrict__ out, int B, int C, int64_t T, int64_t t) {
+    const int lane = threadIdx.x & 63;
+    const int ub = blockIdx.x * 4 + (threadIdx.x >> 6);       // unit block: hidden units 4*ub .. 4*ub+3
+    if (ub * 4 >= C) return;
+    const int KS = C / 4;
+    const float* wp = whhp + (int64_t)ub * KS * 64 + lane;
+    const int k4 = lane >> 4, cl = lane & 15;
+    const int j = ub * 4 + k4;                                 // this lane's hidden unit in the D fragment
+    for (int c0 = 0; c0 < B; c0 += 16) {
+        const int bcol = min(c0 + cl, B - 1);
+        const float* hp = hprev + (int64_t)k4 * B + bcol;
+        const int64_t hs = (int64_t)4 * B;
+        f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        float a0[CH], b0[CH], a1[CH], b1[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) { a0[i] = wp[(int64_t)i * 64]; b0[i] = hp[(int64_t)i * hs]; }
+        for (int kc = 0; kc < KS; kc += CH) {
+            const bool more = kc + CH < KS;
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) { a1[i] = wp[(int64_t)(kc + CH + i) * 64]; b1[i] = hp[(int64_t)(kc + CH + i) * hs]; }
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b0[i], acc, 0, 0, 0);
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) { a0[i] = a1[i]; b0[i] = b1[i]; }
+            }
+        }
+        const int b = c0 + cl;
+        if (b < B) {
+            const float* g = gi + ((int64_t)b * 4 * C) * T + t;
+            const float pi = g[(int64_t)j * T] + (acc[0] + bhh[j]);
+            const float pf = g[(int64_t)(C + j) * T] + (acc[1] + bhh[C + j]);
+            const float pg = g[(int64_t)(2 * C + j) * T] + (acc[2] + bhh[2 * C + j]);
+            const float po = g[(int64_t)(3 * C + j) * T] + (acc[3] + bhh[3 * C + j]);
+            const float ig = nc_sigmoidf(pi), fg = nc_sigmoidf(pf), gg = nc_tanhf(pg), og = nc_sigmoidf(po);
+            const float cn = (fg * cst[(int64_t)j * B + b]) + (ig * gg);
+            cst[(int64_t)j * B + b] = cn;
+            const float h = og * nc_tanhf(cn);
+            hnext[(int64_t)j * B + b] = h;
+            const int64_t o = ((int64_t)b * C + j) * T + t;
+            out[o] = skip ? h + skip[o] : h;
+        }
+    }
 }
 
 // Euclidean codebook search, D <= 128 (EuclideanCodebook.cs:155-182): per frame dist_n = (|x|^2 + |e_n|^2) - 2*(x.e_n) with fma
@@ -441,6 +499,18 @@ void EncodecModel::load_lstm(const Blob& b, const std::string& key, Lstm& l, int
         y.ih.kclass = NC_KC_CONV_K1;
         y.ih.build(static_cast<const float*>(wih.data), static_cast<const float*>(bih.data), C, 4 * C, 1, 1, 0, 1, 0, false);
         upload(y.whh, static_cast<const float*>(whh.data), (size_t)4 * C * C);
+        if (C % 4 == 0) {   // A-fragment image for lstm_step_mfma_kernel: [unit block][k-step][lane], lane = (k4 << 4) | (unit << 2) | gate
+            const float* w = static_cast<const float*>(whh.data);
+            std::vector<float> pk((size_t)4 * C * C);
+            const int KS = C / 4;
+            for (int ub = 0; ub < C / 4; ++ub)
+                for (int kp = 0; kp < KS; ++kp)
+                    for (int l = 0; l < 64; ++l) {
+                        const int k4 = l >> 4, r = l & 15, u = r >> 2, gate = r & 3;
+                        pk[((size_t)ub * KS + kp) * 64 + l] = w[(size_t)(gate * C + ub * 4 + u) * C + 4 * kp + k4];
+                    }
+            upload(y.whhp, pk.data(), pk.size());
+        }
         upload(y.bhh, static_cast<const float*>(bhh.data), (size_t)4 * C);
     }
 }
@@ -610,9 +680,17 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
         out = alloc((size_t)N * C * T);
         const bool last = li + 1 == l.layers.size();
         if (prof.on) prof.begin(stream, NC_KC_ELEM, 2.0 * 4 * C * C * (double)N * T, 0.0);
+        static const bool scalar_lstm = std::getenv("NC_LSTM_SCALAR") && std::getenv("NC_LSTM_SCALAR")[0] == '1';
         for (int64_t t = 0; t < T; ++t) {
-            hipLaunchKernelGGL(lstm_step_kernel, dim3((unsigned)C, (unsigned)((N + 63) / 64)), dim3(64), (size_t)4 * C * sizeof(float), stream, gi,
-                               y.whh.as<float>(), y.bhh.as<float>(), (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, cs, last ? x : nullptr, out, N, C, T, t);
+            if (C % 64 == 0 && !scalar_lstm)
+                hipLaunchKernelGGL(lstm_step_mfma_kernel<16>, dim3((unsigned)((C / 4 + 3) / 4)), dim3(256), 0, stream, gi, y.whhp.as<float>(),
+                                   y.bhh.as<float>(), (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, cs, last ? x : nullptr, out, N, C, T, t);
+            else if (C % 16 == 0 && !scalar_lstm)
+                hipLaunchKernelGGL(lstm_step_mfma_kernel<4>, dim3((unsigned)((C / 4 + 3) / 4)), dim3(256), 0, stream, gi, y.whhp.as<float>(),
+                                   y.bhh.as<float>(), (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, cs, last ? x : nullptr, out, N, C, T, t);
+            else
+                hipLaunchKernelGGL(lstm_step_kernel, dim3((unsigned)C, (unsigned)((N + 63) / 64)), dim3(64), (size_t)4 * C * sizeof(float), stream,
+                                   gi, y.whh.as<float>(), y.bhh.as<float>(), (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, cs, last ? x : nullptr, out, N, C, T, t);
         }
         NC_HIP(hipGetLastError());
         if (prof.on) prof.end(stream);
