@@ -233,6 +233,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
             //      the MFMAs of step kp are issued (register double buffer fa/fb)
             constexpr int kp_lo = seg * KP / NSEG, kp_hi = (seg + 1) * KP / NSEG;
             if constexpr (seg == 0) load_frag(Ac, Xc, std::integral_constant<int, 0>{});
+#ifdef NC_EXP_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
             nc_static_for<kp_hi - kp_lo>([&](auto d) __attribute__((always_inline)) {
                 constexpr int kp = kp_lo + decltype(d)::value;
 #if !defined(NC_ABL_NOFRAG)
@@ -247,6 +250,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp & 1][i], fb[kp & 1][j], acc[i][j], 0, 0, 0);
             });
+#ifdef NC_EXP_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         });
 #if !defined(NC_ABL_NOBAR)
         __syncthreads();
