@@ -213,6 +213,21 @@ NC_API nc_status nc_encodec_decode(nc_codec* h, const int64_t* codes, const floa
 NC_API nc_status nc_encodec_decode_dev(nc_codec* h, const int64_t* codes, const float* scales, int32_t B, int64_t T, int32_t n_q,
                                        float* pcm);
 
+/* ------------------------------------------------------------------------------- code containers
+ * Device-side bit packing of code tensors: the wire layout of the reference's BitPacker / BitUnpacker
+ * (Modules/Encodec/BitPacker.cs: values LSB-first into a little-endian bit stream, `bits` per value, flushed to a whole byte) in the
+ * order EncodecCompressor writes a frame (EncodecCompressor.cs:170-181: t outer, codebook k inner).  One packed row per clip.
+ *   codes  [B,K,T] int64 (device)         packed [B, nc_packed_bytes(K*T, bits)] uint8 (device)
+ * Used for `.ecdc` payloads without the language model and to shrink the multi-GPU code all-gather 64/bits times. */
+NC_API int64_t nc_packed_bytes(int64_t n_values, int32_t bits);
+NC_API nc_status nc_pack_codes_dev(int device_index, const int64_t* codes, int32_t B, int32_t K, int64_t T, int32_t bits, uint8_t* packed,
+                                   void* hip_stream);
+NC_API nc_status nc_unpack_codes_dev(int device_index, const uint8_t* packed, int32_t B, int32_t K, int64_t T, int32_t bits,
+                                     int64_t* codes, void* hip_stream);
+/* host-pointer, synchronous variants */
+NC_API nc_status nc_pack_codes(int device_index, const int64_t* codes, int32_t B, int32_t K, int64_t T, int32_t bits, uint8_t* packed);
+NC_API nc_status nc_unpack_codes(int device_index, const uint8_t* packed, int32_t B, int32_t K, int64_t T, int32_t bits, int64_t* codes);
+
 /* ------------------------------------------------------------------------------------ profiling
  * Per-kernel-class timing with HIP events recorded on the handle's stream around every launch
  * (used by bench.py for the roofline object).  Classes are stable small integers. */

@@ -98,6 +98,11 @@ SYMBOLS = [
     ("nc_encodec_encode_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
     ("nc_encodec_decode", C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
     ("nc_encodec_decode_dev", C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
+    ("nc_packed_bytes", C.c_int64, [C.c_int64, C.c_int32]),
+    ("nc_pack_codes_dev", C.c_int, [C.c_int, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _P, _P]),
+    ("nc_unpack_codes_dev", C.c_int, [C.c_int, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _P, _P]),
+    ("nc_pack_codes", C.c_int, [C.c_int, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _P]),
+    ("nc_unpack_codes", C.c_int, [C.c_int, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _P]),
     ("nc_codec_profile_enable", C.c_int, [_P, C.c_int32]),
     ("nc_codec_profile_reset", C.c_int, [_P]),
     ("nc_codec_profile_read", C.c_int, [_P, C.POINTER(NcProfileEntry)]),
