@@ -193,6 +193,38 @@ class DAC:
         _lib.check(_lib.lib().nc_dac_from_codes(self._h, c.ctypes.data, B, nq, Tz, z.ctypes.data))
         return z
 
+    # ---- Dia <-> DAC glue -----------------------------------------------------------
+    def decode_code_matrix(self, audio_codes):
+        """Dia.Decode (Models/Dia.cs:973-981): codes [T, n_q] (or batched [B, T, n_q]) -> FromCodes -> Decode -> waveform
+        [T*hop] (or [B, T*hop]); the transpose to the engine's [B, n_q, T] happens here, batched clips decode in one launch set."""
+        if audio_codes is None:
+            raise ValueError("audio_codes must not be null")
+        single = audio_codes.ndim == 2
+        c = audio_codes[None] if single else audio_codes
+        if c.ndim != 3:
+            raise ValueError("codes must be [T, n_q] or [B, T, n_q]")
+        c = c.transpose(1, 2) if _is_torch(c) else np.transpose(c, (0, 2, 1))
+        audio = self.decode(self.from_codes(c))
+        audio = audio.reshape(audio.shape[0], -1)
+        return audio[0] if single else audio
+
+    def encode_to_code_matrix(self, audio, sample_rate: Optional[int] = None):
+        """Dia.Encode (Models/Dia.cs:989-1002): audio [C=1, T] (or [B, 1, T]) -> Encode -> codes [T', n_q] (or [B, T', n_q])."""
+        if audio is None:
+            raise ValueError("audio must not be null")
+        single = audio.ndim == 2
+        a = audio[None] if single else audio
+        codes = self.encode(a, sample_rate=sample_rate)[1]
+        codes = codes.transpose(1, 2) if _is_torch(codes) else np.transpose(codes, (0, 2, 1))
+        return codes[0] if single else codes
+
+    @staticmethod
+    def decode_one_frame(model: "DAC", audio_codes):
+        """Modules/Dia/AudioUtils.cs:189-199: exactly one [1, n_q, T] frame -> FromCodes -> Decode."""
+        if audio_codes.shape[0] != 1:
+            raise ValueError(f"Expected one frame, got {audio_codes.shape[0]}")
+        return model.decode(model.from_codes(audio_codes))
+
     # ---- forward ---------------------------------------------------------------------------
     def forward(self, audio_data, sample_rate: Optional[int] = None, n_quantizers: Optional[int] = None):
         z, codes, latents, cl, cbl = self.encode(audio_data, n_quantizers, sample_rate)

@@ -157,3 +157,20 @@ def test_batch_invariance_and_determinism(full, golden_full):
     assert np.array_equal(codes[2:3], codes1) and np.array_equal(z[2:3], z1)
     z_again, codes_again, _, _, _ = m.encode(pcm)
     assert np.array_equal(codes, codes_again) and np.array_equal(z, z_again)
+
+
+def test_dia_glue_code_matrix(small, golden_small):
+    """Dia's [T, n_q] code-matrix round trip over DAC (Models/Dia.cs:973-1002, Modules/Dia/AudioUtils.cs:189-199)."""
+    cfg, m, ref = small
+    pcm = golden_small["pcm"]
+    mat = m.encode_to_code_matrix(pcm[0], sample_rate=cfg.sample_rate)              # [T', n_q]
+    _, codes, _, _, _ = m.encode(pcm[:1])
+    assert mat.shape == (codes.shape[2], cfg.n_codebooks) and np.array_equal(mat, codes[0].T)
+    wav = m.decode_code_matrix(mat)
+    assert np.array_equal(wav, m.decode(m.from_codes(codes)).reshape(-1))
+    batch = m.encode_to_code_matrix(pcm)                                           # batched prompts
+    assert batch.shape[0] == 2 and np.array_equal(batch[0], mat)
+    assert np.array_equal(m.decode_code_matrix(batch)[0], wav)
+    assert np.array_equal(type(m).decode_one_frame(m, codes), m.decode(m.from_codes(codes)))
+    with pytest.raises(ValueError, match="one frame"):
+        type(m).decode_one_frame(m, np.concatenate([codes, codes]))
