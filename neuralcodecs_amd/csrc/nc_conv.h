@@ -68,6 +68,7 @@ struct ConvLayer {
     TileCfg cfg{};
     int n_phase = 1, Ktaps = 0;  // taps per phase (== K for conv, ceil(K/stride) for conv-transpose)
     DevBuf w, bias;
+    DevBuf w_skinny; // K==1, Cout<=16, Cin%64==0: [Cin/4][64 lanes] A-fragment image of skinny_proj_kernel (rows >= Cout zero)
     DevBuf w_fused;  // K==1, Cin==Cout<=128: [row block][ci][32 rows] image consumed by the fused residual-unit kernel
     bool has_bias = false;
     int64_t w_phase_stride = 0;

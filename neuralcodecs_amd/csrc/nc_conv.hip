@@ -41,6 +41,8 @@ int conv_kernel_nx_k16();
 
 conv_kernel_fn conv_kernel_table_fused_k7(int, int);
 conv_kernel_fn conv1x1_kernel_table(int);
+void launch_skinny_proj(const float* x, int64_t x_bstride, int64_t x_cstride, const float* wp, const float* bias, float* y, int64_t y_bstride,
+                        int64_t y_cstride, int B, int Cin, int Cout, int64_t T, hipStream_t s);
 
 static int cb_for_k(int K) {
     switch (K) {
@@ -158,6 +160,17 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
         w_fused.reserve(f.size() * sizeof(float));
         NC_HIP(hipMemcpy(w_fused.p, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    if (!transposed && K == 1 && Cout <= 16 && Cin % 64 == 0) {
+        // image for skinny_proj_kernel: lane = (k4 << 4) | row, value W[row][4*kp + k4]
+        std::vector<float> f((size_t)Cin * 16, 0.0f);
+        for (int kp = 0; kp < Cin / 4; ++kp)
+            for (int l = 0; l < 64; ++l) {
+                const int k4 = l >> 4, r = l & 15;
+                if (r < Cout) f[(size_t)kp * 64 + l] = dense_w[(size_t)r * Cin + 4 * kp + k4];
+            }
+        w_skinny.reserve(f.size() * sizeof(float));
+        NC_HIP(hipMemcpy(w_skinny.p, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     has_bias = bias_h != nullptr;
     if (has_bias) {
         bias.reserve(sizeof(float) * Cout);
@@ -210,6 +223,15 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
 }
 
 void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream, Profiler* prof) {
+    static const bool no_skinny = std::getenv("NC_NO_SKINNY") && std::getenv("NC_NO_SKINNY")[0] == '1';
+    if (L.w_skinny.p && !no_skinny && !io.alpha_in && !io.alpha_out && !io.res && io.epi == 0 && !io.fuse_k1 && io.x_len == io.Tin) {
+        if (prof && prof->on)
+            prof->begin(stream, L.kclass, L.flops(B, io.Tin), 4.0 * ((double)B * L.Cin * io.Tin + (double)B * L.Cout * io.Tin + (double)L.Cin * L.Cout));
+        launch_skinny_proj(io.x, io.x_bstride, io.x_cstride, L.w_skinny.as<float>(), L.has_bias ? L.bias.as<float>() : nullptr, io.y,
+                           io.y_bstride, io.y_cstride, B, L.Cin, L.Cout, io.Tin, stream);
+        if (prof && prof->on) prof->end(stream);
+        return;
+    }
     if (launch_conv1x1(L, io, B, stream, prof)) return;
     TileCfg c = L.cfg;
     const int64_t Tout = L.out_len(io.Tin);

@@ -161,6 +161,56 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvArgs p) {
         }
 }
 
+// Skinny projection: 1x1 conv with Cout <= 16 (the RVQ in_proj 1024 -> 8, VectorQuantizer.cs:47,76) over N = B*T frames.  The
+// generic tile would run one workgroup per clip with a barrier every 16 channels; here one wavefront owns 16 frames and walks the
+// whole reduction with v_mfma_f32_16x16x4_f32 (exact k-ordered chain), weights pre-packed [Cin/4][64 lanes] (rows >= Cout are 0),
+// loads issued a 16-step register chunk ahead.
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void skinny_proj_kernel(const float* __restrict__ x, int64_t x_bstride, int64_t x_cstride,
+                                                         const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
+                                                         int64_t y_bstride, int64_t y_cstride, int B, int Cin, int Cout, int64_t T) {
+    constexpr int CH = 16;
+    const int lane = threadIdx.x;
+    const int k4 = lane >> 4, cl = lane & 15;
+    const int64_t total = (int64_t)B * T;
+    const int64_t f = min((int64_t)blockIdx.x * 16 + cl, total - 1);
+    const int64_t b = f / T, t = f - b * T;
+    const float* xp = x + b * x_bstride + (int64_t)k4 * x_cstride + t;
+    const int64_t xs = 4 * x_cstride;
+    const int KS = Cin / 4;
+    f32x4s acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    float a0[CH], b0[CH], a1[CH], b1[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { a0[i] = wp[(int64_t)i * 64 + lane]; b0[i] = xp[(int64_t)i * xs]; }
+    for (int kc = 0; kc < KS; kc += CH) {
+        const bool more = kc + CH < KS;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) { a1[i] = wp[(int64_t)(kc + CH + i) * 64 + lane]; b1[i] = xp[(int64_t)(kc + CH + i) * xs]; }
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b0[i], acc, 0, 0, 0);
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) { a0[i] = a1[i]; b0[i] = b1[i]; }
+        }
+    }
+    if ((int64_t)blockIdx.x * 16 + cl >= total) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int d = 4 * k4 + r;                     // D row of this lane's register r
+        if (d < Cout) y[b * y_bstride + (int64_t)d * y_cstride + t] = acc[r] + (bias ? bias[d] : 0.0f);
+    }
+}
+
+void launch_skinny_proj(const float* x, int64_t x_bstride, int64_t x_cstride, const float* wp, const float* bias, float* y, int64_t y_bstride,
+                        int64_t y_cstride, int B, int Cin, int Cout, int64_t T, hipStream_t s) {
+    const int64_t total = (int64_t)B * T;
+    hipLaunchKernelGGL(skinny_proj_kernel, dim3((unsigned)((total + 15) / 16)), dim3(64), 0, s, x, x_bstride, x_cstride, wp, bias, y, y_bstride,
+                       y_cstride, B, Cin, Cout, T);
+    NC_HIP(hipGetLastError());
+}
+
 typedef void (*conv_kernel_fn)(const ConvArgs);
 
 conv_kernel_fn conv1x1_kernel_table(int TM) {

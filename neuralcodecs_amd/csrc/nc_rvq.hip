@@ -31,27 +31,30 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict_
     const int lane = tid & 63, wave = tid >> 6;
     const int64_t total = (int64_t)B * T;
     const int64_t f0 = ((int64_t)blockIdx.x * 4 + wave) * VQ_FRAMES_PER_WAVE;
+    // all frames of the wave are fetched before any is searched: one global round trip instead of one per frame
+    float e[VQ_FRAMES_PER_WAVE][VQ_MAX_D];
+#pragma unroll
     for (int fi = 0; fi < VQ_FRAMES_PER_WAVE; ++fi) {
-        const int64_t f = f0 + fi;
-        if (f >= total) break;
+        const int64_t f = min(f0 + fi, total - 1);
         const int64_t b = f / T, t = f - b * T;
         const float* zp = z_e + b * ze_bstride + t;
-        float e[VQ_MAX_D];
+#pragma unroll
+        for (int d = 0; d < VQ_MAX_D; ++d) e[fi][d] = d < D ? zp[(int64_t)d * T] : 0.0f;
+    }
+    int win[VQ_FRAMES_PER_WAVE];
+#pragma unroll
+    for (int fi = 0; fi < VQ_FRAMES_PER_WAVE; ++fi) {
         float e2 = 0.0f;
 #pragma unroll
-        for (int d = 0; d < VQ_MAX_D; ++d) {
-            if (d < D) {
-                e[d] = zp[(int64_t)d * T];
-                e2 = nc_fma(e[d], e[d], e2);
-            }
-        }
+        for (int d = 0; d < VQ_MAX_D; ++d)
+            if (d < D) e2 = nc_fma(e[fi][d], e[fi][d], e2);
         float best = __builtin_inff();
         int bi = 0x7fffffff;
         for (int n = lane; n < N; n += 64) {
             float cr = 0.0f;
 #pragma unroll
             for (int d = 0; d < VQ_MAX_D; ++d)
-                if (d < D) cr = nc_fma(e[d], s_cb[d * N + n], cr);
+                if (d < D) cr = nc_fma(e[fi][d], s_cb[d * N + n], cr);
             const float dist = (e2 + s_c2[n]) - 2.0f * cr;
             if (dist < best) {
                 best = dist;
@@ -69,11 +72,22 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict_
             }
         }
         if (bi == 0x7fffffff) bi = 0;  // all-NaN row: ATen returns an index as well; pick 0
-        if (lane == 0) codes[b * codes_bstride + t] = (int64_t)bi;
+        win[fi] = bi;
+    }
+    // epilogue: codes and the straight-through values, restated literally (VectorQuantizer.cs:81): e + (q - e)
+#pragma unroll
+    for (int fi = 0; fi < VQ_FRAMES_PER_WAVE; ++fi) {
+        const int64_t f = f0 + fi;
+        if (f >= total) break;
+        const int64_t b = f / T, t = f - b * T;
+        if (lane == 0) codes[b * codes_bstride + t] = (int64_t)win[fi];
         if (lane < D) {
-            const float q = cb_rm[(int64_t)bi * D + lane];
-            const float ev = zp[(int64_t)lane * T];
-            st[(b * D + lane) * T + t] = ev + (q - ev);  // straight-through value, restated literally (VectorQuantizer.cs:81)
+            const float q = cb_rm[(int64_t)win[fi] * D + lane];
+            float ev = 0.0f;
+#pragma unroll
+            for (int d = 0; d < VQ_MAX_D; ++d)
+                if (d == lane) ev = e[fi][d];
+            st[(b * D + lane) * T + t] = ev + (q - ev);
         }
     }
 }
