@@ -126,38 +126,47 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*hi] for this lane's TN consecutive columns
+    // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*hi] for this lane's TN consecutive columns.  Rows go out in quads: the
+    //      residual / noise reads of a quad are all issued before its first store (one memory round trip per quad).
     if (col >= T) return;
     const int64_t ybase = (int64_t)b * p.y_bstride + col;
+    const bool has_noise = (p.epi & EPI_NOISE) != 0;
+    f32x2 nz = {0.0f, 0.0f};
+    if (has_noise) nz = *reinterpret_cast<const f32x2*>(p.noise + (int64_t)b * p.noise_bstride + col);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const int co = co_tile * BM + row;
-            if (co >= p.Cout) continue;
-            const float bias = p.bias ? p.bias[co] : 0.0f;
-            const float ao = p.alpha_out ? p.alpha_out[co] : 0.0f;
-            const float ao_inv = nc_snake_inv(ao);
-            const int64_t o = ybase + (int64_t)co * p.y_cstride;
-            f32x2 v;
-            v[0] = acc[i][0][r] + bias;
-            v[1] = acc[i][1][r] + bias;
-            if (p.epi & EPI_NOISE) {
-                const f32x2 rs = *reinterpret_cast<const f32x2*>(p.res + o);
-                const f32x2 nz = *reinterpret_cast<const f32x2*>(p.noise + (int64_t)b * p.noise_bstride + col);
-                v[0] = rs[0] + nz[0] * v[0];
-                v[1] = rs[1] + nz[1] * v[1];
-            } else if (p.res) {
-                const f32x2 rs = *reinterpret_cast<const f32x2*>(p.res + o);
-                v[0] = v[0] + rs[0];
-                v[1] = v[1] + rs[1];
+        for (int rq = 0; rq < 4; ++rq) {
+            f32x2 rs[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int co = min(co_tile * BM + i * 32 + rr + 8 * rq + 4 * hi, p.Cout - 1);
+                rs[rr] = p.res ? *reinterpret_cast<const f32x2*>(p.res + ybase + (int64_t)co * p.y_cstride) : f32x2{0.0f, 0.0f};
             }
-            if (p.alpha_out) {   // Snake of the consuming layer, fused into the store
-                v[0] = nc_snakef(v[0], ao, ao_inv);
-                v[1] = nc_snakef(v[1], ao, ao_inv);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int co = co_tile * BM + i * 32 + rr + 8 * rq + 4 * hi;
+                if (co >= p.Cout) continue;
+                const int r = 4 * rq + rr;
+                const float bias = p.bias ? p.bias[co] : 0.0f;
+                const float ao = p.alpha_out ? p.alpha_out[co] : 0.0f;
+                const float ao_inv = nc_snake_inv(ao);
+                f32x2 v;
+                v[0] = acc[i][0][r] + bias;
+                v[1] = acc[i][1][r] + bias;
+                if (has_noise) {
+                    v[0] = rs[rr][0] + nz[0] * v[0];
+                    v[1] = rs[rr][1] + nz[1] * v[1];
+                } else if (p.res) {
+                    v[0] = v[0] + rs[rr][0];
+                    v[1] = v[1] + rs[rr][1];
+                }
+                if (p.alpha_out) {   // Snake of the consuming layer, fused into the store
+                    v[0] = nc_snakef(v[0], ao, ao_inv);
+                    v[1] = nc_snakef(v[1], ao, ao_inv);
+                }
+                *reinterpret_cast<f32x2*>(p.y + ybase + (int64_t)co * p.y_cstride) = v;
             }
-            *reinterpret_cast<f32x2*>(p.y + o) = v;
         }
 }
 

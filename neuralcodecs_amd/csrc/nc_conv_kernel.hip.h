@@ -261,35 +261,61 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
 
     // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*hi][col = l31]
     const int64_t ybase = (int64_t)b * p.y_bstride;
-    // store one 32-row block `ib` of the tile: v[j][r] + bias (+ residual) (Snake) (tanh) -> y / RVQ accumulate
+    // store one 32-row block `ib` of the tile: v[j][r] + bias (+ residual) (Snake) (tanh) -> y / RVQ accumulate.
+    // Rows go out in quads: all global reads of a quad (residual / RVQ operands) are issued before its first store, so the quad
+    // costs one memory round trip -- loads interleaved with possibly-aliasing stores would serialise into one round trip per value.
     auto emit_rows = [&](int ib, const f32x16 (&v)[TN], const float* bias_p, const float* ao_p, const float* res_p) __attribute__((always_inline)) {
+        const bool rvq = (p.epi & EPI_RVQ) != 0, noise = (p.epi & EPI_NOISE) != 0;
+        nc_static_for<4>([&](auto qt) __attribute__((always_inline)) {
+            constexpr int rq = decltype(qt)::value;
+            float rv[4][TN], zv[4][TN], sv[4][TN];
+            int64_t off[4][TN];
+            bool ok[4][TN];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const int co = co_tile * BM + row;
-            if (co >= p.Cout) continue;
-            const float bias = bias_p ? bias_p[co] : 0.0f;
-            const float ao = ao_p ? ao_p[co] : 0.0f;
-            const float ao_inv = nc_snake_inv(ao);
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = ib * 32 + rr + 8 * rq + 4 * hi;     // D row of register r = 4*rq + rr
+                const int co = co_tile * BM + row;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = col0 + wave * BNW + j * 32 + l31;
-                const int t = col * p.y_tstride + p.y_toff + phase;
-                if (col >= p.n_cols || t < 0 || t >= p.Tout) continue;
-                const int64_t o = ybase + (int64_t)co * p.y_cstride + t;
-                float val = v[j][r] + bias;
-                if (p.epi & EPI_NOISE) val = res_p[o] + p.noise[(int64_t)b * p.noise_bstride + t] * val;
-                else if (res_p) val = val + res_p[o];
-                if (ao_p) val = nc_snakef(val, ao, ao_inv);
-                if (p.epi & EPI_TANH) val = nc_tanhf(val);
-                if (p.epi & EPI_RVQ) {
-                    p.rvq_zq[o] = p.rvq_zq[o] + val;
-                    if (p.rvq_res) p.rvq_res[o] = p.rvq_res[o] - val;
-                } else {
-                    p.y[o] = val;
+                for (int j = 0; j < TN; ++j) {
+                    const int col = col0 + wave * BNW + j * 32 + l31;
+                    const int t = col * p.y_tstride + p.y_toff + phase;
+                    ok[rr][j] = (co < p.Cout) & (col < p.n_cols) & (t >= 0) & (t < p.Tout);
+                    off[rr][j] = ybase + (int64_t)co * p.y_cstride + t;
+                    rv[rr][j] = (ok[rr][j] && res_p) ? res_p[off[rr][j]] : 0.0f;
+                    zv[rr][j] = (ok[rr][j] && rvq) ? p.rvq_zq[off[rr][j]] : 0.0f;
+                    sv[rr][j] = (ok[rr][j] && rvq && p.rvq_res) ? p.rvq_res[off[rr][j]] : 0.0f;
                 }
             }
-        }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = ib * 32 + rr + 8 * rq + 4 * hi;
+                const int co = min(co_tile * BM + row, p.Cout - 1);
+                const float bias = bias_p ? bias_p[co] : 0.0f;
+                const float ao = ao_p ? ao_p[co] : 0.0f;
+                const float ao_inv = nc_snake_inv(ao);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (!ok[rr][j]) continue;
+                    const int64_t o = off[rr][j];
+                    float val = v[j][4 * rq + rr] + bias;
+                    if (noise) {
+                        const int col = col0 + wave * BNW + j * 32 + l31;
+                        const int t = col * p.y_tstride + p.y_toff + phase;
+                        val = rv[rr][j] + p.noise[(int64_t)b * p.noise_bstride + t] * val;
+                    } else if (res_p) {
+                        val = val + rv[rr][j];
+                    }
+                    if (ao_p) val = nc_snakef(val, ao, ao_inv);
+                    if (p.epi & EPI_TANH) val = nc_tanhf(val);
+                    if (rvq) {
+                        p.rvq_zq[o] = zv[rr][j] + val;
+                        if (p.rvq_res) p.rvq_res[o] = sv[rr][j] - val;
+                    } else {
+                        p.y[o] = val;
+                    }
+                }
+            }
+        });
     };
 
     if constexpr (!FUSE) {
