@@ -469,7 +469,7 @@ nc_status nc_op_conv1d(int device_index, const nc_conv_desc* d, const float* x, 
         launch_conv(L, io, d->B, nullptr, nullptr);
         NC_HIP(hipDeviceSynchronize());
         NC_HIP(hipMemcpy(y, dy.p, ny, hipMemcpyDeviceToHost));
-        dx.release(); dy.release(); dai.release(); dao.release(); dr.release(); L.w.release(); L.bias.release(); L.w_skinny.release(); L.w_fused.release();
+        dx.release(); dy.release(); dai.release(); dao.release(); dr.release(); L.release_all();
     });
 }
 
@@ -520,7 +520,7 @@ nc_status nc_op_conv1d_bench(int device_index, const nc_conv_desc* d, int32_t fu
         NC_HIP(hipEventElapsedTime(&ms, e0, e1));
         *avg_ms = (double)ms / iters;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        dx.release(); dy.release(); dai.release(); dao.release(); dr.release(); L.w.release(); L.bias.release(); L.w_skinny.release(); L.w_fused.release();
+        dx.release(); dy.release(); dai.release(); dao.release(); dr.release(); L.release_all();
     });
 }
 
@@ -574,7 +574,7 @@ nc_status nc_op_res_unit(int device_index, int32_t B, int32_t C, int64_t T, int3
             (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         }
         dx.release(); dh.release(); dy.release(); d1.release(); d2.release();
-        c7.w.release(); c7.bias.release(); c1.w.release(); c1.bias.release(); c1.w_fused.release();
+        c7.release_all(); c1.release_all();
     });
 }
 

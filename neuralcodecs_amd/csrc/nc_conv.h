@@ -13,6 +13,8 @@
 // Each output element is ONE chain of v_mfma_f32_32x32x2_f32 updates in ascending kk, which is
 // bit-identical to a scalar fmaf loop (MI355X_MICROARCH.md, "FP32-input MFMA").
 #pragma once
+#include <memory>
+
 #include "nc_common.h"
 
 namespace nc {
@@ -68,6 +70,13 @@ struct ConvLayer {
     TileCfg cfg{};
     int n_phase = 1, Ktaps = 0;  // taps per phase (== K for conv, ceil(K/stride) for conv-transpose)
     DevBuf w, bias;
+    // additional row-tile heights (32*TM dividing Cout) packed at load; the launch picks the one that fills the chip best
+    struct Alt {
+        TileCfg cfg{};
+        DevBuf w;
+        int64_t w_phase_stride = 0;
+    };
+    std::vector<std::unique_ptr<Alt>> alts;
     DevBuf w_skinny; // K==1, Cout<=16, Cin%64==0: [Cin/4][64 lanes] A-fragment image of skinny_proj_kernel (rows >= Cout zero)
     DevBuf w_fused;  // K==1, Cin==Cout<=128: [row block][ci][32 rows] image consumed by the fused residual-unit kernel
     bool has_bias = false;
@@ -76,6 +85,11 @@ struct ConvLayer {
     // host: dense folded weight in the reference's layout ([Cout,Cin,K] or [Cin,Cout,K])
     void build(const float* dense_w, const float* bias_h, int Cin, int Cout, int K, int stride, int pad, int dil, int out_pad,
                bool transposed);
+    void release_all() {   // op-level hooks build throw-away layers
+        w.release(); bias.release(); w_skinny.release(); w_fused.release();
+        for (auto& a : alts) a->w.release();
+        alts.clear();
+    }
     int64_t out_len(int64_t Tin) const;
     double flops(int B, int64_t Tin) const;
 };

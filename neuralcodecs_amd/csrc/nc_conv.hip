@@ -93,6 +93,10 @@ TileCfg pick_tile(int Cout, int Ktaps) {
             c.TM = tm;
         }
     }
+    if (const char* e = std::getenv("NC_TM_FORCE")) {   // experiment: force the row-tile height where it divides Cout
+        const int tm = atoi(e);
+        if (tm >= 1 && tm <= 4 && Cout % (32 * tm) == 0) c.TM = tm;
+    }
     c.TN = 2;
     c.K = Ktaps;
     c.CB = cb_for_k(Ktaps);
@@ -122,35 +126,48 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
         Ktaps = K;
     }
     cfg = pick_tile(Cout, Ktaps);
-    const int BM = cfg.BM(), CB = cfg.CB, KB = cfg.KB();
-    const int n_co = (Cout + BM - 1) / BM;
-    const int n_cb = (Cin + CB - 1) / CB;
-    w_phase_stride = (int64_t)n_co * n_cb * KB * BM;
-    std::vector<float> packed((size_t)w_phase_stride * n_phase, 0.0f);
-    for (int ph = 0; ph < n_phase; ++ph)
-        for (int ct = 0; ct < n_co; ++ct)
-            for (int cb = 0; cb < n_cb; ++cb) {
-                float* dst = packed.data() + (size_t)ph * w_phase_stride + ((size_t)ct * n_cb + cb) * KB * BM;
-                for (int kk = 0; kk < KB; ++kk) {
-                    const int ci = cb * CB + kk / Ktaps, k = kk % Ktaps;
-                    if (ci >= Cin) continue;
-                    for (int r = 0; r < BM; ++r) {
-                        const int co = ct * BM + r;
-                        if (co >= Cout) continue;
-                        float v;
-                        if (transposed) {
-                            const int kt = ph + k * stride;  // tap of this phase, ascending (canonical order)
-                            if (kt >= K) continue;
-                            v = dense_w[((size_t)ci * Cout + co) * K + kt];
-                        } else {
-                            v = dense_w[((size_t)co * Cin + ci) * K + k];
+    auto pack = [&](const TileCfg& tc, DevBuf& dstbuf, int64_t& phase_stride) {
+        const int BM = tc.BM(), CB = tc.CB, KB = tc.KB();
+        const int n_co = (Cout + BM - 1) / BM;
+        const int n_cb = (Cin + CB - 1) / CB;
+        phase_stride = (int64_t)n_co * n_cb * KB * BM;
+        std::vector<float> packed((size_t)phase_stride * n_phase, 0.0f);
+        for (int ph = 0; ph < n_phase; ++ph)
+            for (int ct = 0; ct < n_co; ++ct)
+                for (int cb = 0; cb < n_cb; ++cb) {
+                    float* dst = packed.data() + (size_t)ph * phase_stride + ((size_t)ct * n_cb + cb) * KB * BM;
+                    for (int kk = 0; kk < KB; ++kk) {
+                        const int ci = cb * CB + kk / Ktaps, k = kk % Ktaps;
+                        if (ci >= Cin) continue;
+                        for (int r = 0; r < BM; ++r) {
+                            const int co = ct * BM + r;
+                            if (co >= Cout) continue;
+                            float v;
+                            if (transposed) {
+                                const int kt = ph + k * stride;  // tap of this phase, ascending (canonical order)
+                                if (kt >= K) continue;
+                                v = dense_w[((size_t)ci * Cout + co) * K + kt];
+                            } else {
+                                v = dense_w[((size_t)co * Cin + ci) * K + k];
+                            }
+                            dst[(size_t)kk * BM + r] = v;
                         }
-                        dst[(size_t)kk * BM + r] = v;
                     }
                 }
-            }
-    w.reserve(packed.size() * sizeof(float));
-    NC_HIP(hipMemcpy(w.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+        dstbuf.reserve(packed.size() * sizeof(float));
+        NC_HIP(hipMemcpy(dstbuf.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    };
+    pack(cfg, w, w_phase_stride);
+    alts.clear();
+    static const bool no_alts = std::getenv("NC_NO_TILE_ALTS") && std::getenv("NC_NO_TILE_ALTS")[0] == '1';
+    if (!no_alts && Cout >= 128)
+        for (int tm = 3; tm >= 2; --tm) {
+            if (tm == cfg.TM || Cout % (32 * tm) != 0) continue;
+            alts.emplace_back(new Alt());
+            alts.back()->cfg = cfg;
+            alts.back()->cfg.TM = tm;
+            pack(alts.back()->cfg, alts.back()->w, alts.back()->w_phase_stride);
+        }
     if (!transposed && K == 1 && Cin == Cout && Cin % 32 == 0 && Cin <= 128) {
         // image for the fused residual-unit tail: [row block][ci][32 rows]
         std::vector<float> f((size_t)Cin * Cout);
@@ -180,12 +197,42 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
 
 bool can_fuse_res_unit(const ConvLayer& k7, const ConvLayer& k1) {
     return !k7.transposed && k7.K == 7 && k7.stride == 1 && k7.Cin == k7.Cout && k7.Cout % 32 == 0 && k7.Cout >= 64 && k7.Cout <= 128 &&
-           k7.cfg.BM() == k7.Cout && k1.K == 1 && k1.Cin == k7.Cout && k1.Cout == k7.Cout && k1.w_fused.p != nullptr &&
+           k7.Cout % 32 == 0 && k1.K == 1 && k1.Cin == k7.Cout && k1.Cout == k7.Cout && k1.w_fused.p != nullptr &&
            k7.has_bias && k1.has_bias;
 }
 
 static std::mutex g_attr_mu;
 static std::set<const void*> g_attr_done;
+
+// Which packed row-tile height to launch: estimated time = rounds * (blocks per CU) * TM * penalty(TM), with
+// rounds = ceil(blocks / (256 CUs * blocks per CU)).  Smaller tiles waste a little more LDS/issue bandwidth per MFMA (penalty) but
+// can turn a 1.1-round grid into a full one (measured: C=768 at T=696 76 -> 99 TFLOP/s with 96-row tiles).
+struct TileChoice {
+    TileCfg cfg;
+    const float* w;
+    int64_t w_phase_stride;
+};
+static TileChoice choose_tile(const ConvLayer& L, int64_t blocks_per_rowtile, bool pointwise_fast) {
+    auto cost = [&](const TileCfg& c) {
+        const int n_co = (L.Cout + c.BM() - 1) / c.BM();
+        const double blocks = (double)blocks_per_rowtile * n_co;
+        static const int bpc_gen[5] = {0, 4, 3, 2, 2}, bpc_pw[5] = {0, 6, 5, 3, 3};
+        static const double pen[5] = {0, 1.30, 1.10, 1.05, 1.00};
+        const int bpc = pointwise_fast ? bpc_pw[c.TM] : bpc_gen[c.TM];
+        const double rounds = std::ceil(blocks / (256.0 * bpc));
+        return rounds * bpc * c.TM * pen[c.TM];
+    };
+    TileChoice best{L.cfg, L.w.as<float>(), L.w_phase_stride};
+    double bc = cost(L.cfg);
+    for (const auto& a : L.alts) {
+        const double c = cost(a->cfg);
+        if (c < bc) {
+            bc = c;
+            best = TileChoice{a->cfg, a->w.as<float>(), a->w_phase_stride};
+        }
+    }
+    return best;
+}
 
 // Pointwise fast path (nc_conv1x1.hip): B fragments straight from global memory, 2-wide vector loads/stores.
 static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream, Profiler* prof) {
@@ -198,16 +245,17 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
     auto al8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; };
     if (!al8(io.x) || !al8(io.y) || (io.res && !al8(io.res)) || (io.noise && !al8(io.noise))) return false;
     if ((io.epi & EPI_NOISE) && (!io.noise || !io.res)) return false;
-    conv_kernel_fn fn = conv1x1_kernel_table(L.cfg.TM);
+    const TileChoice tc = choose_tile(L, (int64_t)B * ((T + 255) / 256), true);
+    conv_kernel_fn fn = conv1x1_kernel_table(tc.cfg.TM);
     if (!fn) return false;
     ConvArgs a{};
     a.x = io.x; a.x_bstride = io.x_bstride; a.x_cstride = io.x_cstride; a.Cin = L.Cin; a.x_len = io.x_len;
-    a.w = L.w.as<float>();
+    a.w = tc.w;
     a.bias = L.has_bias ? L.bias.as<float>() : nullptr;
     a.res = io.res; a.noise = io.noise; a.noise_bstride = T; a.epi = io.epi; a.alpha_out = io.alpha_out;
     a.y = io.y; a.y_bstride = io.y_bstride; a.y_cstride = io.y_cstride;
     a.Cout = L.Cout; a.B = B; a.Tout = (int32_t)T;
-    const int BM = L.cfg.BM();
+    const int BM = tc.cfg.BM();
     a.n_co_tiles = (L.Cout + BM - 1) / BM;
     a.n_t_tiles = (int32_t)((T + 255) / 256);
     a.n_cb = (L.Cin + 15) / 16;
@@ -233,9 +281,14 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         return;
     }
     if (launch_conv1x1(L, io, B, stream, prof)) return;
-    TileCfg c = L.cfg;
     const int64_t Tout = L.out_len(io.Tin);
     const int64_t n_cols_all = L.transposed ? io.Tin + L.Ktaps - 1 : Tout;
+    TileChoice tsel{L.cfg, L.w.as<float>(), L.w_phase_stride};
+    if (!io.fuse_k1) tsel = choose_tile(L, (int64_t)L.n_phase * B * ((n_cols_all + 255) / 256), false);
+    else
+        for (const auto& alt : L.alts)   // the fused residual unit needs the tile that spans all channels
+            if (alt->cfg.BM() == L.Cout) tsel = TileChoice{alt->cfg, alt->w.as<float>(), alt->w_phase_stride};
+    TileCfg c = tsel.cfg;
     static const int tn_thresh = std::getenv("NC_TN_THRESH") ? atoi(std::getenv("NC_TN_THRESH")) : 192;
     c.TN = n_cols_all >= tn_thresh ? 2 : 1;  // 256-column tiles for long clips, 128 for the deep (short) layers
     {   // the per-lane staging registers bound the window: fall back to 128-column tiles when it does not fit
@@ -247,7 +300,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     ConvArgs a{};
     a.x = io.x; a.x_bstride = io.x_bstride; a.x_cstride = io.x_cstride; a.Cin = L.Cin; a.x_len = io.x_len;
     a.alpha_in = io.alpha_in;
-    a.w = L.w.as<float>(); a.w_phase_stride = L.w_phase_stride;
+    a.w = tsel.w; a.w_phase_stride = tsel.w_phase_stride;
     a.bias = L.has_bias ? L.bias.as<float>() : nullptr;
     a.alpha_out = io.alpha_out; a.res = io.res;
     a.y = io.y; a.y_bstride = io.y_bstride; a.y_cstride = io.y_cstride;
