@@ -54,12 +54,14 @@ struct ConvArgs {
     int32_t stride_magic;          // j / stride     == (j * stride_magic) >> 20     (host-verified)
     int32_t tapoff[16];            // window slot of tap k at column 0 (phase de-interleave folded in)
     int32_t epi;
+    int32_t ep_off;                // float offset in LDS of the per-row epilogue table (bias, Snake alpha, 1/alpha [, fused set])
 };
 
 struct TileCfg {
     int TM, TN, K, CB;
+    int NW = 4;                       // waves per workgroup (8: wide variants)
     int BM() const { return 32 * TM; }
-    int BN() const { return 128 * TN; }
+    int BN() const { return 32 * NW * TN; }
     int KB() const { return CB * K; }
 };
 

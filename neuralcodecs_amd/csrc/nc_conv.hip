@@ -40,6 +40,8 @@ int conv_kernel_nx_k16();
 #define NC_K_CASES(X) X(1) X(2) X(3) X(4) X(6) X(7) X(8) X(10) X(16)
 
 conv_kernel_fn conv_kernel_table_fused_k7(int, int);
+conv_kernel_fn conv_kernel_table_light_k7(int, int);
+conv_kernel_fn conv_kernel_table_wide_k7(int, int);
 conv_kernel_fn conv1x1_kernel_table(int);
 void launch_skinny_proj(const float* x, int64_t x_bstride, int64_t x_cstride, const float* wp, const float* bias, float* y, int64_t y_bstride,
                         int64_t y_cstride, int B, int Cin, int Cout, int64_t T, hipStream_t s);
@@ -296,6 +298,27 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         const int xw2 = (c.BN() - 1) * sx0 + (L.Ktaps - 1) * ad0 + 1;
         if (c.TN == 2 && c.CB * ((xw2 + 63) / 64) > 4 * nx_for_k(c.K)) c.TN = 1;
     }
+    // light variant (reduction block of 4 channels, 3 workgroups per CU): same packed weights when Cin is a multiple of 8
+    int nx = nx_for_k(c.K);
+    bool light = false;
+    {
+        static const int light_mode = std::getenv("NC_LIGHT") ? atoi(std::getenv("NC_LIGHT")) : 0;
+        if (light_mode == 1 && !io.fuse_k1 && c.K == 7 && c.CB == 8 && L.Cin % 8 == 0 && c.TN == 2 && (c.TM == 2 || c.TM == 3)) {
+            light = true;
+            c.CB = 4;
+            nx = 5;
+        }
+    }
+    bool wide = false;
+    {
+        static const int wide_mode = std::getenv("NC_WIDE") ? atoi(std::getenv("NC_WIDE")) : 0;
+        if (wide_mode == 1 && !light && !io.fuse_k1 && c.K == 7 && c.TN == 2 && c.TM >= 2 && n_cols_all >= 2048) {
+            wide = true;
+            c.NW = 8;
+            nx = 9;
+        }
+    }
+    const int NW = c.NW;
     const int BM = c.BM(), BN = c.BN(), CB = c.CB, KB = c.KB();
     ConvArgs a{};
     a.x = io.x; a.x_bstride = io.x_bstride; a.x_cstride = io.x_cstride; a.Cin = L.Cin; a.x_len = io.x_len;
@@ -309,6 +332,8 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     if ((io.epi & EPI_NOISE) && (!io.noise || !io.res)) fail(NC_ESTATE, "internal: noise epilogue needs noise and residual");
     a.Cout = L.Cout; a.B = B; a.epi = io.epi;
     a.Tout = (int32_t)Tout;
+    if ((int64_t)(c.BM() + 4) * io.y_cstride + Tout >= (int64_t)1 << 31)
+        fail(NC_EUNSUPPORTED, "conv output rows of %lld samples exceed the 32-bit tile offsets", (long long)io.y_cstride);
     int sx;  // x step per output column
     if (L.transposed) {
         sx = 1; a.stride = 1; a.dil = -1; a.pad = 0;
@@ -331,18 +356,20 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     a.n_t_tiles = (a.n_cols + BN - 1) / BN;
     a.n_cb = (L.Cin + CB - 1) / CB;
     a.n_items = CB * a.nchunk;
-    const int nx = nx_for_k(c.K);
-    if (a.n_items > 4 * nx)
+    if (a.n_items > NW * nx)
         fail(NC_EUNSUPPORTED, "conv K=%d stride=%d dil=%d: input window of %d words per channel exceeds the staging registers",
              L.K, L.stride, L.dil, a.xw);
-    a.xbuf = (((4 * nx - 1) / a.nchunk + 1) * a.xrow + 3) & ~3;   // items past n_items land in pad rows
-    a.chunk_magic = magic_div(a.nchunk, 4 * nx + 4);
+    a.xbuf = (((NW * nx - 1) / a.nchunk + 1) * a.xrow + 3) & ~3;   // items past n_items land in pad rows
+    a.chunk_magic = magic_div(a.nchunk, NW * nx + NW);
     a.stride_magic = magic_div(sx, a.nchunk * 64 + 64);
     for (int k = 0; k < 16; ++k) {
         const int q = k * a.dil + a.xneg;
         a.tapoff[k] = (k < L.Ktaps) ? (sx == 1 ? q : (q % sx) * a.xwp + q / sx) : 0;
     }
-    size_t lds = sizeof(float) * (2 * (size_t)KB * BM + 2 * (size_t)a.xbuf + (io.alpha_in ? 2 * (size_t)a.n_cb * CB : 0));
+    size_t lds_f = 2 * (size_t)KB * BM + 2 * (size_t)a.xbuf + (io.alpha_in ? 2 * (size_t)a.n_cb * CB : 0);
+    if (io.fuse_k1) lds_f = std::max(lds_f, (size_t)BM * BM);   // the 1x1 weights reuse the tile buffers
+    a.ep_off = (int32_t)lds_f;
+    size_t lds = sizeof(float) * (lds_f + 6 * (size_t)BM);
     conv_kernel_fn fn = nullptr;
     if (io.fuse_k1) {
         if (!can_fuse_res_unit(L, *io.fuse_k1) || !io.alpha_out || !io.res || io.epi != 0)
@@ -350,9 +377,14 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         a.w2 = io.fuse_k1->w_fused.as<float>();
         a.bias2 = io.fuse_k1->bias.as<float>();
         a.alpha_out2 = io.alpha_out2;
-        lds = std::max(lds, sizeof(float) * (size_t)BM * BM);
         fn = conv_kernel_table_fused_k7(c.TM, c.TN);
         if (!fn) fail(NC_EUNSUPPORTED, "no fused residual-unit kernel for TM=%d TN=%d", c.TM, c.TN);
+    } else if (wide) {
+        fn = conv_kernel_table_wide_k7(c.TM, c.TN);
+        if (!fn) fail(NC_EUNSUPPORTED, "no wide conv kernel for TM=%d TN=%d", c.TM, c.TN);
+    } else if (light) {
+        fn = conv_kernel_table_light_k7(c.TM, c.TN);
+        if (!fn) fail(NC_EUNSUPPORTED, "no light conv kernel for TM=%d TN=%d", c.TM, c.TN);
     } else {
         fn = lookup_kernel(c);
     }
@@ -372,7 +404,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         if (io.fuse_k1) fl += io.fuse_k1->flops(B, io.Tin);
         prof->begin(stream, L.kclass, fl, bytes);
     }
-    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64 * NW), lds, stream, a);
     NC_HIP(hipGetLastError());
     if (prof && prof->on) prof->end(stream);
 }

@@ -22,10 +22,25 @@ template <int N, class F>
 __device__ __forceinline__ void nc_static_for(F&& f) {
     nc_static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
+// a flag that is either a compile-time constant (std::true_type / std::false_type) or this run-time value
+struct nc_rt_flag {
+    bool v;
+    __device__ constexpr operator bool() const { return v; }
+};
 typedef __attribute__((address_space(1))) const void* nc_gptr;
+#ifdef NC_DBG_TRACE
+// diagnostic build only: per-wave phase timestamps of the workgroups that ran on one CU
+#define NC_TR_WAVES 96
+#define NC_TR_STAMPS 640
+extern __device__ unsigned long long nc_dbg_buf[NC_TR_WAVES * NC_TR_STAMPS];
+extern __device__ unsigned int nc_dbg_count;
+#define NC_TR() do { if (tr_on) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0 && tr_n < NC_TR_STAMPS) tr_p[tr_n] = t_; ++tr_n; } } while (0)
+#else
+#define NC_TR() do {} while (0)
+#endif
 typedef __attribute__((address_space(3))) void* nc_lptr;
 
-// Block = 4 waves (256 threads).  Wave w owns all BM = 32*TM output channels of the tile and the
+// Block = NW waves (4, or 8 for the wide variants).  Wave w owns all BM = 32*TM output channels of the tile and the
 // 32*TN columns [w*32*TN, (w+1)*32*TN).  The reduction runs over blocks of CB input channels
 // (KB = CB*K flattened kk = ci*K + k, ascending: the canonical chain order).  Per block the
 // workgroup holds in LDS, double-buffered,
@@ -38,17 +53,22 @@ typedef __attribute__((address_space(3))) void* nc_lptr;
 // segment g+1 -- so a load has a whole segment of MFMA time to land, only 1/(NSEG-1) of the staging
 // registers are live at once, and the VALU work sits between matrix-core segments.
 //   MFMA step kp: lane l supplies A[row = l&31][kk = 2*kp + (l>>5)] and B[kk][col = l&31].
-template <int TM, int TN, int K, int CB, int NX, bool FUSE = false>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
+template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4>
+__global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs p) {
+    constexpr int NT = 64 * NW;                    // threads per workgroup
     constexpr int BM = 32 * TM;
     constexpr int BNW = 32 * TN;
-    constexpr int BN = 4 * BNW;
+    constexpr int BN = NW * BNW;
     constexpr int KB = CB * K;
     constexpr int KP = KB / 2;
     constexpr int A_FLOATS = KB * BM;
     constexpr int A_VEC = A_FLOATS / 4;            // float4 words in the weight tile
-    constexpr int NA = (A_VEC + 255) / 256;        // float4 copies per thread
+    constexpr int NA = (A_VEC + NT - 1) / NT;      // float4 copies per thread
+#ifdef NC_NSEG
+    constexpr int NSEG = KP >= 16 ? NC_NSEG : 2;
+#else
     constexpr int NSEG = KP >= 16 ? 4 : 2;
+#endif
     constexpr int NG = NSEG - 1;
     constexpr int GA = (NA + NG - 1) / NG;         // per-group register footprint
     constexpr int GX = (NX + NG - 1) / NG;
@@ -62,7 +82,34 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int hi = lane >> 5;
+#ifdef NC_EXP_ASYMPRIO
+    // co-resident waves of one SIMD get different issue priorities (by hardware wave slot parity): the favoured wave runs its
+    // matrix-core segments at full rate and the other fills the gaps its staging leaves, instead of both stalling together
+    if (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1) __builtin_amdgcn_s_setprio(3);
+#endif
 
+#ifdef NC_DBG_TRACE
+    bool tr_on = false;
+    int tr_n = 0;
+    unsigned long long* tr_p = nullptr;
+    {
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));    // HW_ID
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // XCC_ID
+        const unsigned cu = (hw >> 8) & 15, se = (hw >> 13) & 7, sh = (hw >> 12) & 1;
+        if (xcc == 0 && se == 0 && sh == 0 && cu == 0) {
+            unsigned slot = 0;
+            if (lane == 0) slot = atomicAdd(&nc_dbg_count, 1u);
+            slot = __builtin_amdgcn_readfirstlane(slot);
+            if (slot < NC_TR_WAVES) {
+                tr_on = true;
+                tr_p = nc_dbg_buf + (size_t)slot * NC_TR_STAMPS;
+                if (lane == 0) { tr_p[0] = blockIdx.x; tr_p[1] = hw; tr_p[2] = wave; }
+                tr_n = 3;
+            }
+        }
+    }
+    NC_TR();
+#endif
     // ---- XCD-aware block -> tile map: block id b runs on XCD b%8 (observed; speed only).  Give each
     // XCD a contiguous range of the (phase, co_tile, clip, t_tile) order so the blocks resident on
     // one XCD share a weight panel in that XCD's L2.
@@ -73,12 +120,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int t_tile = lin % p.n_t_tiles;
+    // (integer division runs on the vector ALU: hand the wave-uniform results back to scalar registers)
+    const int t_tile = __builtin_amdgcn_readfirstlane(lin % p.n_t_tiles);
     lin /= p.n_t_tiles;
-    const int b = lin % p.B;
+    const int b = __builtin_amdgcn_readfirstlane(lin % p.B);
     lin /= p.B;
-    const int co_tile = lin % p.n_co_tiles;
-    const int phase = lin / p.n_co_tiles;
+    const int co_tile = __builtin_amdgcn_readfirstlane(lin % p.n_co_tiles);
+    const int phase = __builtin_amdgcn_readfirstlane(lin / p.n_co_tiles);
 
     const int col0 = t_tile * BN;
     const int s = p.stride;
@@ -102,10 +150,26 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
     // Snake alphas of all input channels, staged once per block behind the tile buffers
     float2* const Al = reinterpret_cast<float2*>(Xs0 + 2 * xbuf);   // (alpha, 1/alpha) per input channel
     if (alpha_in != nullptr)
-        for (int i = tid; i < n_cb * CB; i += 256) {
+        for (int i = tid; i < n_cb * CB; i += NT) {
             const float al = alpha_in[min(i, Cin - 1)];
             Al[i] = make_float2(al, nc_snake_inv(al));
         }
+    // per-row epilogue operands of this tile: bias, Snake alpha and 1/alpha (and the fused unit's second set).  The epilogue
+    // reads them from LDS: a global read issued after the first store would wait for every earlier store to be acknowledged.
+    float* const Ep = smem + p.ep_off;
+    for (int i = tid; i < BM; i += NT) {
+        const int co = min(co_tile * BM + i, p.Cout - 1);
+        const float ao = p.alpha_out ? p.alpha_out[co] : 0.0f;
+        Ep[i] = p.bias ? p.bias[co] : 0.0f;
+        Ep[BM + i] = ao;
+        Ep[2 * BM + i] = nc_snake_inv(ao);
+        if constexpr (FUSE) {
+            const float ao2 = p.alpha_out2 ? p.alpha_out2[co] : 0.0f;
+            Ep[3 * BM + i] = p.bias2[co];
+            Ep[4 * BM + i] = ao2;
+            Ep[5 * BM + i] = nc_snake_inv(ao2);
+        }
+    }
     __syncthreads();
 
     // ---- staging (branch-free; every address is clamped into the tensor) ------------------------
@@ -119,18 +183,26 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         nc_static_for<GA>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value, n = g * GA + u;
             if constexpr (n < NA) {
-                const unsigned idx = (unsigned)(tid + 256 * n);
-                ra[u] = src[(A_VEC % 256 == 0) ? idx : min(idx, (unsigned)(A_VEC - 1))];
+                const unsigned idx = (unsigned)(tid + NT * n);
+#ifdef NC_ABL_NOLOADA
+                ra[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
+                ra[u] = src[(A_VEC % NT == 0) ? idx : min(idx, (unsigned)(A_VEC - 1))];
+#endif
             }
         });
         nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value, i = g * GX + u;
             if constexpr (i < NX) {
-                const int item = wave + 4 * i;
+                const int item = wave + NW * i;
                 const int c = (item * chunk_magic) >> 20;
                 const int ci = min(cbn * CB + c, Cin - 1);
                 const int gp = xs0 + (item - c * nchunk) * 64 + lane;
+#ifdef NC_ABL_NOLOADX
+                rx[u] = (float)gp;
+#else
                 rx[u] = xb[(unsigned)ci * x_cstride + (unsigned)min(max(gp, 0), x_len - 1)];
+#endif
             }
         });
     };
@@ -140,8 +212,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         nc_static_for<GA>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value, n = g * GA + u;
             if constexpr (n < NA) {
-                const int idx = tid + 256 * n;
-                if ((A_VEC % 256 == 0) || idx < A_VEC) reinterpret_cast<f32x4*>(Ad)[idx] = ra[u];
+                const int idx = tid + NT * n;
+#ifndef NC_ABL_NOSTOREA
+                if ((A_VEC % NT == 0) || idx < A_VEC) reinterpret_cast<f32x4*>(Ad)[idx] = ra[u];
+#endif
             }
         });
         float2 al[GX];
@@ -149,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
             nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
                 constexpr int u = decltype(ut)::value, i = g * GX + u;
                 if constexpr (i < NX) {
-                    const int item = wave + 4 * i;
+                    const int item = wave + NW * i;
                     al[u] = Al[cbn * CB + ((item * chunk_magic) >> 20)];
                 }
             });
@@ -159,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value, i = g * GX + u;
             if constexpr (i < NX) {
-                const int item = wave + 4 * i;
+                const int item = wave + NW * i;
                 const int c = (item * chunk_magic) >> 20;
                 const int ci = cbn * CB + c;
                 const int j = (item - c * nchunk) * 64 + lane;
@@ -180,7 +254,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         });
     };
     auto store_group_any = [&](int cbn, float* Ad, float* Xd, auto gtag) __attribute__((always_inline)) {
-        if (alpha_in != nullptr) store_group(cbn, Ad, Xd, gtag, std::true_type{});
+#ifdef NC_ABL_NOSNAKE
+        if (false)
+#else
+        if (alpha_in != nullptr)
+#endif
+            store_group(cbn, Ad, Xd, gtag, std::true_type{});
         else store_group(cbn, Ad, Xd, gtag, std::false_type{});
     };
 
@@ -223,6 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         const bool more = cb + 1 < n_cb;
         nc_static_for<NSEG>([&](auto seg_tag) __attribute__((always_inline)) {
             constexpr int seg = decltype(seg_tag)::value;
+            NC_TR();
 #if !defined(NC_ABL_NOSTAGE)
             if (more) {
                 if constexpr (seg >= 1) store_group_any(cb + 1, An, Xn, std::integral_constant<int, (seg >= 1 ? seg - 1 : 0)>{});
@@ -231,6 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
 #endif
             // ---- matrix-core steps of this segment, ascending kk; fragments of step kp+1 are read before
             //      the MFMAs of step kp are issued (register double buffer fa/fb)
+            NC_TR();
             constexpr int kp_lo = seg * KP / NSEG, kp_hi = (seg + 1) * KP / NSEG;
             if constexpr (seg == 0) load_frag(Ac, Xc, std::integral_constant<int, 0>{});
 #ifdef NC_EXP_SETPRIO
@@ -254,64 +335,116 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
             __builtin_amdgcn_s_setprio(0);
 #endif
         });
+        NC_TR();
 #if !defined(NC_ABL_NOBAR)
         __syncthreads();
 #endif
+        NC_TR();
     }
+    NC_TR();
 
     // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*hi][col = l31]
-    const int64_t ybase = (int64_t)b * p.y_bstride;
-    // store one 32-row block `ib` of the tile: v[j][r] + bias (+ residual) (Snake) (tanh) -> y / RVQ accumulate.
-    // Rows go out in quads: all global reads of a quad (residual / RVQ operands) are issued before its first store, so the quad
-    // costs one memory round trip -- loads interleaved with possibly-aliasing stores would serialise into one round trip per value.
-    auto emit_rows = [&](int ib, const f32x16 (&v)[TN], const float* bias_p, const float* ao_p, const float* res_p) __attribute__((always_inline)) {
-        const bool rvq = (p.epi & EPI_RVQ) != 0, noise = (p.epi & EPI_NOISE) != 0;
+    // Element (row block ib, register r, column j) of this lane lives at tile_base + lane_off[j] + R(ib,r)*cstride with
+    // R = 32*ib + (r&3) + 8*(r>>2) a compile-time row: one uniform 64-bit base, 32-bit lane offsets (the host bounds them).
+    const int64_t tile_base = (int64_t)b * p.y_bstride + (int64_t)co_tile * BM * p.y_cstride;
+    const unsigned cstride = (unsigned)p.y_cstride;
+    const int rows_left = p.Cout - co_tile * BM - 4 * hi;   // row R of this lane half is inside the tensor iff R < rows_left
+    unsigned lane_off[TN];
+    bool okc[TN];
+    int tcol[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + wave * BNW + j * 32 + l31;
+        const int t = col * p.y_tstride + p.y_toff + phase;
+        okc[j] = (col < p.n_cols) & (t >= 0) & (t < p.Tout);
+        tcol[j] = min(max(t, 0), p.Tout - 1);
+        lane_off[j] = (unsigned)(4 * hi) * cstride + (unsigned)tcol[j];
+    }
+    bool cols_ok = true;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) cols_ok = cols_ok & okc[j];
+    const bool tile_full = __builtin_amdgcn_ballot_w64(!cols_ok) == 0 && p.Cout - co_tile * BM >= BM;   // wave-uniform
+    // Residual operands of the 32-row block `ib`, all 16*TN reads issued back to back (one memory round trip per row block).
+    // full_tag: every element of this wave's part of the tile is inside the tensor (no per-element predicates: straight-line code)
+    auto load_res = [&](int ib, float (&rv)[16][TN], const float* res_p, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const float* rt = res_p + tile_base;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int R = ib * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (FULL) {
+                    rv[r][j] = rt[lane_off[j] + (unsigned)R * cstride];
+                } else {   // branch-free: the address is clamped into the tile's valid rows / columns, the value masked
+                    const float val = rt[lane_off[j] + (unsigned)max(min(R, rows_left - 1), -4 * hi) * cstride];
+                    rv[r][j] = (okc[j] & (R < rows_left)) ? val : 0.0f;
+                }
+            }
+        }
+    };
+    // v[j][r] = (v[j][r] + bias) (+ residual | residual + noise * .): the value of the canonical chain before the activation
+    auto add_rows = [&](int ib, f32x16 (&v)[TN], const float (&rv)[16][TN], const float (&nz)[TN], const float* bias_t, auto has_res,
+                        auto gen_tag) __attribute__((always_inline)) {
+        const bool noise = decltype(gen_tag)::value && (p.epi & EPI_NOISE) != 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float bias = bias_t[ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float val = v[j][r] + bias;
+                if (noise) val = rv[r][j] + nz[j] * val;
+                else if (has_res) val = val + rv[r][j];
+                v[j][r] = val;
+            }
+        }
+    };
+    // store one 32-row block `ib`: (Snake) (tanh) -> y, or RVQ accumulate.  No global read happens here except the RVQ operands,
+    // which are read per row quad ahead of the quad's stores.
+    auto store_rows = [&](int ib, const f32x16 (&v)[TN], const float* ao_t, auto snake, auto gen_tag, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        // opaque copy of the lane offsets: keeps the compiler from carrying the read phase's 16*TM*TN addresses over to the stores
+        unsigned lane_off_s[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            lane_off_s[j] = lane_off[j];
+            asm volatile("" : "+v"(lane_off_s[j]));
+        }
+        const bool rvq = decltype(gen_tag)::value && (p.epi & EPI_RVQ) != 0;
+        float* const yt = (rvq ? p.rvq_zq : p.y) + tile_base;
+        float* const st = (rvq && p.rvq_res) ? p.rvq_res + tile_base : nullptr;
         nc_static_for<4>([&](auto qt) __attribute__((always_inline)) {
             constexpr int rq = decltype(qt)::value;
-            float rv[4][TN], zv[4][TN], sv[4][TN];
-            int64_t off[4][TN];
-            bool ok[4][TN];
+            float zv[4][TN], sv[4][TN];
+            if (rvq) {
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int row = ib * 32 + rr + 8 * rq + 4 * hi;     // D row of register r = 4*rq + rr
-                const int co = co_tile * BM + row;
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int R = ib * 32 + rr + 8 * rq;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int col = col0 + wave * BNW + j * 32 + l31;
-                    const int t = col * p.y_tstride + p.y_toff + phase;
-                    ok[rr][j] = (co < p.Cout) & (col < p.n_cols) & (t >= 0) & (t < p.Tout);
-                    off[rr][j] = ybase + (int64_t)co * p.y_cstride + t;
-                    rv[rr][j] = (ok[rr][j] && res_p) ? res_p[off[rr][j]] : 0.0f;
-                    zv[rr][j] = (ok[rr][j] && rvq) ? p.rvq_zq[off[rr][j]] : 0.0f;
-                    sv[rr][j] = (ok[rr][j] && rvq && p.rvq_res) ? p.rvq_res[off[rr][j]] : 0.0f;
+                    for (int j = 0; j < TN; ++j) {
+                        const bool ok = FULL || (okc[j] & (R < rows_left));
+                        const unsigned o = lane_off_s[j] + (unsigned)R * cstride;
+                        zv[rr][j] = ok ? yt[o] : 0.0f;
+                        sv[rr][j] = (ok && st) ? st[o] : 0.0f;
+                    }
                 }
             }
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int row = ib * 32 + rr + 8 * rq + 4 * hi;
-                const int co = min(co_tile * BM + row, p.Cout - 1);
-                const float bias = bias_p ? bias_p[co] : 0.0f;
-                const float ao = ao_p ? ao_p[co] : 0.0f;
-                const float ao_inv = nc_snake_inv(ao);
+                const int R = ib * 32 + rr + 8 * rq;     // D row of register r = 4*rq + rr (plus 4*hi)
+                const float ao = ao_t[R + 4 * hi], ao_inv = ao_t[BM + R + 4 * hi];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (!ok[rr][j]) continue;
-                    const int64_t o = off[rr][j];
-                    float val = v[j][4 * rq + rr] + bias;
-                    if (noise) {
-                        const int col = col0 + wave * BNW + j * 32 + l31;
-                        const int t = col * p.y_tstride + p.y_toff + phase;
-                        val = rv[rr][j] + p.noise[(int64_t)b * p.noise_bstride + t] * val;
-                    } else if (res_p) {
-                        val = val + rv[rr][j];
-                    }
-                    if (ao_p) val = nc_snakef(val, ao, ao_inv);
-                    if (p.epi & EPI_TANH) val = nc_tanhf(val);
+                    if (!(FULL || (okc[j] & (R < rows_left)))) continue;
+                    const unsigned o = lane_off_s[j] + (unsigned)R * cstride;
+                    float val = v[j][4 * rq + rr];
+                    if (snake) val = nc_snakef(val, ao, ao_inv);
+                    if (decltype(gen_tag)::value && (p.epi & EPI_TANH)) val = nc_tanhf(val);
                     if (rvq) {
-                        p.rvq_zq[o] = zv[rr][j] + val;
-                        if (p.rvq_res) p.rvq_res[o] = sv[rr][j] - val;
+                        yt[o] = zv[rr][j] + val;
+                        if (st) st[o] = sv[rr][j] - val;
                     } else {
-                        p.y[o] = val;
+                        yt[o] = val;
                     }
                 }
             }
@@ -319,8 +452,43 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
     };
 
     if constexpr (!FUSE) {
+        // phase A: every global read of the epilogue (residual tile, noise row), folded into the accumulators; phase B: stores only.
+        // The rare RVQ-accumulate / noise-injection epilogues take the generic instance, everything else the lean one.
+        auto run_epilogue = [&](auto gen_tag, auto full_tag, auto has_res, auto snake) __attribute__((always_inline)) {
+            float nz[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) emit_rows(i, acc[i], p.bias, p.alpha_out, p.res);
+            for (int j = 0; j < TN; ++j)
+                nz[j] = (decltype(gen_tag)::value && (p.epi & EPI_NOISE)) ? p.noise[(int64_t)b * p.noise_bstride + tcol[j]] : 0.0f;
+            constexpr int NRV = TM * TN >= 6 ? 1 : 2;   // read one row block ahead where the registers allow it
+            float rv[NRV][16][TN];
+            if (has_res) load_res(0, rv[0], p.res, full_tag);
+            nc_static_for<TM>([&](auto it) __attribute__((always_inline)) {
+                constexpr int i = decltype(it)::value;
+                if constexpr (NRV == 2 && i + 1 < TM)
+                    if (has_res) load_res(i + 1, rv[(i + 1) & 1], p.res, full_tag);
+                add_rows(i, acc[i], rv[i % NRV], nz, Ep, has_res, gen_tag);
+                if constexpr (NRV == 1 && i + 1 < TM)
+                    if (has_res) load_res(i + 1, rv[0], p.res, full_tag);
+            });
+            nc_static_for<TM>([&](auto it) __attribute__((always_inline)) {
+                store_rows(decltype(it)::value, acc[decltype(it)::value], Ep + BM, snake, gen_tag, full_tag);
+            });
+        };
+        // The lean instances are straight-line code (flags folded at compile time); RVQ accumulate, noise injection and tanh
+        // (small layers) share the generic instance.
+        const bool has_res = p.res != nullptr, snake = p.alpha_out != nullptr;
+        auto pick = [&](auto full_tag) __attribute__((always_inline)) {
+            if (has_res) {
+                if (snake) run_epilogue(std::false_type{}, full_tag, std::true_type{}, std::true_type{});
+                else run_epilogue(std::false_type{}, full_tag, std::true_type{}, std::false_type{});
+            } else {
+                if (snake) run_epilogue(std::false_type{}, full_tag, std::false_type{}, std::true_type{});
+                else run_epilogue(std::false_type{}, full_tag, std::false_type{}, std::false_type{});
+            }
+        };
+        if (p.epi & (EPI_RVQ | EPI_NOISE | EPI_TANH)) run_epilogue(std::true_type{}, std::false_type{}, nc_rt_flag{has_res}, nc_rt_flag{snake});
+        else if (tile_full) pick(std::true_type{});
+        else pick(std::false_type{});
     } else {
         // ---- fused ResidualUnit tail (ResidualUnit.cs:29-34,50-59): this block holds ALL channels of
         //      h_pre = conv7(snake(x)) for its columns (n_co_tiles == 1, Cin == Cout == BM), so
@@ -335,8 +503,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float bias = p.bias[row], ao = p.alpha_out[row];
-                const float ao_inv = nc_snake_inv(ao);
+                const float bias = Ep[row], ao = Ep[BM + row], ao_inv = Ep[2 * BM + row];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j][r] = nc_snakef(acc[i][j][r] + bias, ao, ao_inv);
             }
@@ -358,10 +525,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
             const f32x4* w2 = reinterpret_cast<const f32x4*>(p.w2);
             f32x4* dst = reinterpret_cast<f32x4*>(smem);
 #pragma unroll 4
-            for (int idx = tid; idx < BM * BM / 4; idx += 256) dst[idx] = w2[idx];
+            for (int idx = tid; idx < BM * BM / 4; idx += NT) dst[idx] = w2[idx];
         }
         __syncthreads();
-        // 4) y = W1 . h + b1 + x, one 32-row block at a time (ascending ci chain, like the stand-alone 1x1 kernel)
+        // 4) y = W1 . h + b1 + x, one 32-row block at a time (ascending ci chain, like the stand-alone 1x1 kernel).  The skip
+        //    operand is read before the first store where the registers allow it (all row blocks up front), else per row block.
+        constexpr bool RES_UPFRONT = TM * TN <= 6;
+        float rvall[RES_UPFRONT ? TM : 1][16][TN];
+        if constexpr (RES_UPFRONT) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) load_res(i, rvall[i], p.res, std::false_type{});
+        }
         nc_static_for<TM>([&](auto i2t) __attribute__((always_inline)) {
             constexpr int i2 = decltype(i2t)::value;
             f32x16 acc2[TN];
@@ -378,16 +552,25 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[i][j][reg], acc2[j], 0, 0, 0);
             });
-            emit_rows(i2, acc2, p.bias2, p.alpha_out2, p.res);
+            const float nz0[TN] = {};
+            if constexpr (RES_UPFRONT) {
+                add_rows(i2, acc2, rvall[i2], nz0, Ep + 3 * BM, std::true_type{}, std::false_type{});
+            } else {
+                float rv[16][TN];
+                load_res(i2, rv, p.res, std::false_type{});
+                add_rows(i2, acc2, rv, nz0, Ep + 3 * BM, std::true_type{}, std::false_type{});
+            }
+            store_rows(i2, acc2, Ep + 4 * BM, nc_rt_flag{p.alpha_out2 != nullptr}, std::false_type{}, std::false_type{});
         });
     }
+    NC_TR();
 }
 
 typedef void (*conv_kernel_fn)(const ConvArgs);
 
-template <int TM, int TN, int K, int CB, int NX, bool FUSE = false>
+template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4>
 inline conv_kernel_fn get_conv_kernel() {
-    return &conv_mfma_kernel<TM, TN, K, CB, NX, FUSE>;
+    return &conv_mfma_kernel<TM, TN, K, CB, NX, FUSE, OCC, NW>;
 }
 
 }  // namespace nc
@@ -423,6 +606,34 @@ inline conv_kernel_fn get_conv_kernel() {
             case 32: return get_conv_kernel<3, 2, KVAL, CBVAL, NXVAL, true>();                             \
             case 41: return get_conv_kernel<4, 1, KVAL, CBVAL, NXVAL, true>();                             \
             case 42: return get_conv_kernel<4, 2, KVAL, CBVAL, NXVAL, true>();                             \
+        }                                                                                                  \
+        return nullptr;                                                                                    \
+    }                                                                                                      \
+    }
+
+// Light variants: a shorter reduction block (smaller LDS tiles, fewer staging registers) compiled for 3 waves per SIMD, for
+// launches whose block count fits the chip in one round only at 3 workgroups per CU.  Same packed weight image as the
+// standard variant when its CB is a multiple of this one's (kk = ci*K + k is contiguous across reduction blocks).
+#define NC_INSTANTIATE_CONV_LIGHT(KVAL, CBVAL, NXVAL)                                                      \
+    namespace nc {                                                                                         \
+    conv_kernel_fn conv_kernel_table_light_k##KVAL(int TM, int TN) {                                       \
+        switch (TM * 10 + TN) {                                                                            \
+            case 22: return get_conv_kernel<2, 2, KVAL, CBVAL, NXVAL, false, 3>();                         \
+            case 32: return get_conv_kernel<3, 2, KVAL, CBVAL, NXVAL, false, 3>();                         \
+        }                                                                                                  \
+        return nullptr;                                                                                    \
+    }                                                                                                      \
+    }
+
+// Wide variants: 8 waves share one weight tile (BN = 512 columns), halving the weight traffic and staging per MFMA for the
+// long-clip layers; one workgroup per CU.
+#define NC_INSTANTIATE_CONV_WIDE(KVAL, CBVAL, NXVAL)                                                       \
+    namespace nc {                                                                                         \
+    conv_kernel_fn conv_kernel_table_wide_k##KVAL(int TM, int TN) {                                        \
+        switch (TM * 10 + TN) {                                                                            \
+            case 22: return get_conv_kernel<2, 2, KVAL, CBVAL, NXVAL, false, 2, 8>();                      \
+            case 32: return get_conv_kernel<3, 2, KVAL, CBVAL, NXVAL, false, 2, 8>();                      \
+            case 42: return get_conv_kernel<4, 2, KVAL, CBVAL, NXVAL, false, 2, 8>();                      \
         }                                                                                                  \
         return nullptr;                                                                                    \
     }                                                                                                      \
