@@ -42,7 +42,7 @@ int conv_kernel_nx_k16();
 conv_kernel_fn conv_kernel_table_fused_k7(int, int);
 conv_kernel_fn conv_kernel_table_light_k7(int, int);
 conv_kernel_fn conv_kernel_table_wide_k7(int, int);
-conv_kernel_fn conv1x1_kernel_table(int);
+conv_kernel_fn conv1x1_kernel_table(int, int);
 void launch_skinny_proj(const float* x, int64_t x_bstride, int64_t x_cstride, const float* wp, const float* bias, float* y, int64_t y_bstride,
                         int64_t y_cstride, int B, int Cin, int Cout, int64_t T, hipStream_t s);
 
@@ -248,7 +248,8 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
     if (!al8(io.x) || !al8(io.y) || (io.res && !al8(io.res)) || (io.noise && !al8(io.noise))) return false;
     if ((io.epi & EPI_NOISE) && (!io.noise || !io.res)) return false;
     const TileChoice tc = choose_tile(L, (int64_t)B * ((T + 255) / 256), true);
-    conv_kernel_fn fn = conv1x1_kernel_table(tc.cfg.TM);
+    const int mode = (io.epi & EPI_NOISE) ? 4 : ((io.res ? 1 : 0) | (io.alpha_out ? 2 : 0));
+    conv_kernel_fn fn = conv1x1_kernel_table(tc.cfg.TM, mode);
     if (!fn) return false;
     ConvArgs a{};
     a.x = io.x; a.x_bstride = io.x_bstride; a.x_cstride = io.x_cstride; a.Cin = L.Cin; a.x_len = io.x_len;

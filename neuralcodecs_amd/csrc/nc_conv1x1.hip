@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <mutex>
 #include <set>
+#include <type_traits>
+#include <utility>
 
 #include "nc_conv.h"
 #include "nc_math.h"
@@ -21,8 +23,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int TM, int CB>
-__global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvArgs p) {
+template <int N, class F, int... I>
+__device__ __forceinline__ void nc_static_for_1x1_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void nc_static_for_1x1(F&& f) {
+    nc_static_for_1x1_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// Waves per SIMD the register budget is held to (the layers this kernel serves are short reductions: occupancy hides their
+// memory latency), matching the workgroups-per-CU table of the launch-time tile choice.
+constexpr int conv1x1_occupancy(int TM) { return TM == 1 ? 6 : TM == 2 ? 5 : 3; }
+
+// MODE: epilogue of this instantiation, chosen at launch (bit 0: residual, bit 1: Snake of the consuming layer, bit 2: noise
+// injection y = res + noise * conv): one straight-line epilogue per kernel keeps the register budget.
+template <int TM, int CB, int MODE>
+__global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(const ConvArgs p) {
     constexpr int TN = 2;
     constexpr int BM = 32 * TM;
     constexpr int BNW = 32 * TN;
@@ -35,6 +52,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvArgs p) {
     static_assert(KP % PF == 0, "prefetch ring must divide the reduction block");
 
     __shared__ __attribute__((aligned(16))) float As[2][A_FLOATS];
+    __shared__ float Ep[3 * BM];   // per-row epilogue operands of this tile: bias, Snake alpha, 1/alpha
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -49,10 +67,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvArgs p) {
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int t_tile = lin % p.n_t_tiles;
+    const int t_tile = __builtin_amdgcn_readfirstlane(lin % p.n_t_tiles);
     lin /= p.n_t_tiles;
-    const int b = lin % p.B;
-    const int co_tile = lin / p.B;
+    const int b = __builtin_amdgcn_readfirstlane(lin % p.B);
+    const int co_tile = __builtin_amdgcn_readfirstlane(lin / p.B);
+    for (int i = tid; i < BM; i += 256) {
+        const int co = min(co_tile * BM + i, p.Cout - 1);
+        const float ao = p.alpha_out ? p.alpha_out[co] : 0.0f;
+        Ep[i] = p.bias ? p.bias[co] : 0.0f;
+        Ep[BM + i] = ao;
+        Ep[2 * BM + i] = nc_snake_inv(ao);
+    }
 
     const int T = p.Tout;
     const int n_cb = p.n_cb, Cin = p.Cin;
@@ -126,48 +151,117 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*hi] for this lane's TN consecutive columns.  Rows go out in quads: the
-    //      residual / noise reads of a quad are all issued before its first store (one memory round trip per quad).
+    // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*hi] for this lane's TN consecutive columns.  Phase A issues every global read
+    //      (residual tile, noise) and folds it into the accumulators; phase B only stores.  A global read issued after a store waits
+    //      for all earlier stores to be acknowledged, so the per-row operands (bias, Snake alpha) come from the LDS table Ep.
     if (col >= T) return;
-    const int64_t ybase = (int64_t)b * p.y_bstride + col;
-    const bool has_noise = (p.epi & EPI_NOISE) != 0;
-    f32x2 nz = {0.0f, 0.0f};
-    if (has_noise) nz = *reinterpret_cast<const f32x2*>(p.noise + (int64_t)b * p.noise_bstride + col);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            f32x2 rs[4];
+    const int64_t tile_base = (int64_t)b * p.y_bstride + (int64_t)co_tile * BM * p.y_cstride;
+    const unsigned cstride = (unsigned)p.y_cstride;
+    const unsigned lane_off = (unsigned)(4 * hi) * cstride + (unsigned)col;
+    const int rows_total = p.Cout - co_tile * BM;   // uniform
+    const int rows_left = rows_total - 4 * hi;
+    // rows_tag: all BM rows of the tile are inside the tensor (row addresses are then uniform base + 32-bit lane offset)
+    auto run_epilogue = [&](auto res_tag, auto snake_tag, auto noise_tag, auto rows_tag) __attribute__((always_inline)) {
+        constexpr bool RES = decltype(res_tag)::value, SNAKE = decltype(snake_tag)::value, NOISE = decltype(noise_tag)::value;
+        f32x2 nz = {0.0f, 0.0f};
+        if constexpr (NOISE) nz = *reinterpret_cast<const f32x2*>(p.noise + (int64_t)b * p.noise_bstride + col);
+        const float* const rt = p.res + tile_base;
+        // residual rows arrive a quad (4 rows) at a time, one quad ahead of the arithmetic, no store in between
+        f32x2 rs[2][4];
+        unsigned loff = lane_off;
+        auto load_quad = [&](int q, f32x2 (&dst)[4]) __attribute__((always_inline)) {   // q = 4*i + rq
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int co = min(co_tile * BM + i * 32 + rr + 8 * rq + 4 * hi, p.Cout - 1);
-                rs[rr] = p.res ? *reinterpret_cast<const f32x2*>(p.res + ybase + (int64_t)co * p.y_cstride) : f32x2{0.0f, 0.0f};
+                const int R = (q >> 2) * 32 + rr + 8 * (q & 3);
+                dst[rr] = *reinterpret_cast<const f32x2*>(rt + (size_t)R * cstride + loff);
+            }
+        };
+        if constexpr (RES) load_quad(0, rs[0]);
+        nc_static_for_1x1<4 * TM>([&](auto qt) __attribute__((always_inline)) {
+            constexpr int q = decltype(qt)::value, i = q >> 2, rq = q & 3;
+            if constexpr (RES && q + 1 < 4 * TM) {
+                // the reads of quad q+1 wait (data dependence through the offset) for the arithmetic of quad q-1: two quads in
+                // flight, instead of the whole tile's reads hoisted to the top at 2 registers each
+                if constexpr (q >= 1) asm volatile("" : "+v"(loff) : "v"(acc[(q - 1) >> 2][0][4 * ((q - 1) & 3) + 3]));
+                load_quad(q + 1, rs[(q + 1) & 1]);
             }
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int co = co_tile * BM + i * 32 + rr + 8 * rq + 4 * hi;
-                if (co >= p.Cout) continue;
                 const int r = 4 * rq + rr;
-                const float bias = p.bias ? p.bias[co] : 0.0f;
-                const float ao = p.alpha_out ? p.alpha_out[co] : 0.0f;
-                const float ao_inv = nc_snake_inv(ao);
-                f32x2 v;
-                v[0] = acc[i][0][r] + bias;
-                v[1] = acc[i][1][r] + bias;
-                if (has_noise) {
-                    v[0] = rs[rr][0] + nz[0] * v[0];
-                    v[1] = rs[rr][1] + nz[1] * v[1];
-                } else if (p.res) {
-                    v[0] = v[0] + rs[rr][0];
-                    v[1] = v[1] + rs[rr][1];
+                const float bias = Ep[i * 32 + rr + 8 * rq + 4 * hi];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float v = acc[i][j][r] + bias;
+                    if constexpr (NOISE) v = rs[q & 1][rr][j] + nz[j] * v;
+                    else if constexpr (RES) v = v + rs[q & 1][rr][j];
+                    acc[i][j][r] = v;
                 }
-                if (p.alpha_out) {   // Snake of the consuming layer, fused into the store
+            }
+        });
+        float* const yt = p.y + tile_base;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int R = i * 32 + (r & 3) + 8 * (r >> 2);
+                f32x2 v = {acc[i][0][r], acc[i][1][r]};
+                if constexpr (SNAKE) {   // Snake of the consuming layer, fused into the store
+                    const float ao = Ep[BM + R + 4 * hi], ao_inv = Ep[2 * BM + R + 4 * hi];
                     v[0] = nc_snakef(v[0], ao, ao_inv);
                     v[1] = nc_snakef(v[1], ao, ao_inv);
                 }
-                *reinterpret_cast<f32x2*>(p.y + ybase + (int64_t)co * p.y_cstride) = v;
+                float* rowp = yt + (size_t)R * cstride;
+                *reinterpret_cast<f32x2*>(rowp + lane_off) = v;
             }
-        }
+    };
+    using res_t = std::integral_constant<bool, (MODE & 5) != 0>;
+    using snake_t = std::integral_constant<bool, (MODE & 2) != 0>;
+    using noise_t = std::integral_constant<bool, (MODE & 4) != 0>;
+    if (rows_total >= BM) {
+        run_epilogue(res_t{}, snake_t{}, noise_t{}, std::true_type{});
+        return;
+    }
+    // Row-partial tile (Cout not a multiple of BM: the narrow layers): rows go out in quads, the residual reads of a quad issued
+    // before its first store (one memory round trip per quad).
+    {
+        constexpr bool RES = res_t::value, SNAKE = snake_t::value, NOISE = noise_t::value;
+        f32x2 nz = {0.0f, 0.0f};
+        if constexpr (NOISE) nz = *reinterpret_cast<const f32x2*>(p.noise + (int64_t)b * p.noise_bstride + col);
+        const float* const rt = p.res + tile_base;
+        float* const yt = p.y + tile_base;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                f32x2 rs[4];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int R = i * 32 + rr + 8 * rq;
+                    rs[rr] = (RES && R < rows_left) ? *reinterpret_cast<const f32x2*>(rt + (size_t)R * cstride + lane_off) : f32x2{0.0f, 0.0f};
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int R = i * 32 + rr + 8 * rq;
+                    if (R >= rows_left) continue;
+                    const int r = 4 * rq + rr;
+                    const float bias = Ep[R + 4 * hi];
+                    f32x2 v = {acc[i][0][r] + bias, acc[i][1][r] + bias};
+                    if constexpr (NOISE) {
+                        v[0] = rs[rr][0] + nz[0] * v[0];
+                        v[1] = rs[rr][1] + nz[1] * v[1];
+                    } else if constexpr (RES) {
+                        v[0] = v[0] + rs[rr][0];
+                        v[1] = v[1] + rs[rr][1];
+                    }
+                    if constexpr (SNAKE) {
+                        const float ao = Ep[BM + R + 4 * hi], ao_inv = Ep[2 * BM + R + 4 * hi];
+                        v[0] = nc_snakef(v[0], ao, ao_inv);
+                        v[1] = nc_snakef(v[1], ao, ao_inv);
+                    }
+                    *reinterpret_cast<f32x2*>(yt + (size_t)R * cstride + lane_off) = v;
+                }
+            }
+    }
 }
 
 // Skinny projection: 1x1 conv with Cout <= 16 (the RVQ in_proj 1024 -> 8, VectorQuantizer.cs:47,76) over N = B*T frames.  The
@@ -222,12 +316,25 @@ void launch_skinny_proj(const float* x, int64_t x_bstride, int64_t x_cstride, co
 
 typedef void (*conv_kernel_fn)(const ConvArgs);
 
-conv_kernel_fn conv1x1_kernel_table(int TM) {
+template <int TM>
+static conv_kernel_fn conv1x1_by_mode(int mode) {
+    switch (mode) {
+        case 0: return &conv1x1_kernel<TM, 16, 0>;
+        case 1: return &conv1x1_kernel<TM, 16, 1>;
+        case 2: return &conv1x1_kernel<TM, 16, 2>;
+        case 3: return &conv1x1_kernel<TM, 16, 3>;
+        case 4: return &conv1x1_kernel<TM, 16, 4>;
+    }
+    return nullptr;
+}
+
+// mode: bit 0 residual, bit 1 Snake-out, 4 = noise injection (with residual, no Snake)
+conv_kernel_fn conv1x1_kernel_table(int TM, int mode) {
     switch (TM) {
-        case 1: return &conv1x1_kernel<1, 16>;
-        case 2: return &conv1x1_kernel<2, 16>;
-        case 3: return &conv1x1_kernel<3, 16>;
-        case 4: return &conv1x1_kernel<4, 16>;
+        case 1: return conv1x1_by_mode<1>(mode);
+        case 2: return conv1x1_by_mode<2>(mode);
+        case 3: return conv1x1_by_mode<3>(mode);
+        case 4: return conv1x1_by_mode<4>(mode);
     }
     return nullptr;
 }
