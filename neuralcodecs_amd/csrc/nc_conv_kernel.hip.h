@@ -34,7 +34,7 @@ typedef __attribute__((address_space(1))) const void* nc_gptr;
 #define NC_TR_STAMPS 640
 extern __device__ unsigned long long nc_dbg_buf[NC_TR_WAVES * NC_TR_STAMPS];
 extern __device__ unsigned int nc_dbg_count;
-#define NC_TR() do { if (tr_on) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0 && tr_n < NC_TR_STAMPS) tr_p[tr_n] = t_; ++tr_n; } } while (0)
+#define NC_TR() do { if (tr_on) { const unsigned t_ = (unsigned)__builtin_readcyclecounter(); if (lane == 0 && tr_n < 512) tr_l[tr_n] = t_; ++tr_n; } } while (0)
 #else
 #define NC_TR() do {} while (0)
 #endif
@@ -92,6 +92,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
     bool tr_on = false;
     int tr_n = 0;
     unsigned long long* tr_p = nullptr;
+    extern __shared__ __attribute__((aligned(16))) float smem_tr[];
+    unsigned* const tr_l = reinterpret_cast<unsigned*>(smem_tr + p.ep_off + 6 * 32 * TM) + 512 * wave;   // stamps staged in LDS
     {
         const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));    // HW_ID
         const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // XCC_ID
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
                 tr_on = true;
                 tr_p = nc_dbg_buf + (size_t)slot * NC_TR_STAMPS;
                 if (lane == 0) { tr_p[0] = blockIdx.x; tr_p[1] = hw; tr_p[2] = wave; }
-                tr_n = 3;
+                tr_p += 3;
             }
         }
     }
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
     // window slots of one channel, item -> wave item%4; items past n_items land in pad rows.
     f32x4 ra[GA];
     float rx[GX];
-    auto issue_group = [&](int cbn, auto gtag) __attribute__((always_inline)) {
+    auto issue_group_to = [&](int cbn, auto gtag, f32x4 (&ra)[GA], float (&rx)[GX]) __attribute__((always_inline)) {
         constexpr int g = decltype(gtag)::value;
         const f32x4* src = wbase + (size_t)cbn * A_VEC;
         nc_static_for<GA>([&](auto ut) __attribute__((always_inline)) {
@@ -206,7 +208,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
             }
         });
     };
-    auto store_group = [&](int cbn, float* Ad, float* Xd, auto gtag, auto snake_tag) __attribute__((always_inline)) {
+    auto issue_group = [&](int cbn, auto gtag) __attribute__((always_inline)) { issue_group_to(cbn, gtag, ra, rx); };
+    auto store_group_from = [&](int cbn, float* Ad, float* Xd, auto gtag, auto snake_tag, const f32x4 (&ra)[GA],
+                                const float (&rx)[GX]) __attribute__((always_inline)) {
         constexpr int g = decltype(gtag)::value;
         constexpr bool SNAKE = decltype(snake_tag)::value;
         nc_static_for<GA>([&](auto ut) __attribute__((always_inline)) {
@@ -253,6 +257,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
             if constexpr (i < NX) Xd[off[u]] = v[u];
         });
     };
+    auto store_group = [&](int cbn, float* Ad, float* Xd, auto gtag, auto snake_tag) __attribute__((always_inline)) {
+        store_group_from(cbn, Ad, Xd, gtag, snake_tag, ra, rx);
+    };
     auto store_group_any = [&](int cbn, float* Ad, float* Xd, auto gtag) __attribute__((always_inline)) {
 #ifdef NC_ABL_NOSNAKE
         if (false)
@@ -271,11 +278,22 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // ---- prologue: stage reduction block 0
-    nc_static_for<NG>([&](auto g) __attribute__((always_inline)) {
-        issue_group(0, g);
-        store_group_any(0, As0, Xs0, g);
-    });
+    // ---- prologue: stage reduction block 0.  All groups' reads are issued back to back (one memory round trip, not NG).
+    {
+        f32x4 ra0[NG][GA];
+        float rx0[NG][GX];
+        nc_static_for<NG>([&](auto g) __attribute__((always_inline)) { issue_group_to(0, g, ra0[decltype(g)::value], rx0[decltype(g)::value]); });
+        nc_static_for<NG>([&](auto g) __attribute__((always_inline)) {
+            constexpr int gi = decltype(g)::value;
+#ifdef NC_ABL_NOSNAKE
+            if (false)
+#else
+            if (alpha_in != nullptr)
+#endif
+                store_group_from(0, As0, Xs0, g, std::true_type{}, ra0[gi], rx0[gi]);
+            else store_group_from(0, As0, Xs0, g, std::false_type{}, ra0[gi], rx0[gi]);
+        });
+    }
     __syncthreads();
 
     const int a_lane = hi * BM + l31;
@@ -451,14 +469,60 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
         });
     };
 
+    // Generic / edge-tile emitter (row-partial or column-partial tiles, RVQ accumulate, noise injection, tanh): rows go out in
+    // quads with per-element predicates; the global reads of a quad are issued before its first store.
+    auto emit_rows_quad = [&](int ib, const f32x16 (&v)[TN], const float* bias_t, const float* ao_t, bool snake, const float* res_p)
+        __attribute__((always_inline)) {
+        const bool rvq = (p.epi & EPI_RVQ) != 0, noise = (p.epi & EPI_NOISE) != 0;
+        float* const yt = (rvq ? p.rvq_zq : p.y) + tile_base;
+        float* const st = (rvq && p.rvq_res) ? p.rvq_res + tile_base : nullptr;
+        const float* const rt = res_p ? res_p + tile_base : nullptr;
+        nc_static_for<4>([&](auto qt) __attribute__((always_inline)) {
+            constexpr int rq = decltype(qt)::value;
+            float rv[4][TN], zv[4][TN], sv[4][TN];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int R = ib * 32 + rr + 8 * rq;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const bool ok = okc[j] & (R < rows_left);
+                    const unsigned o = lane_off[j] + (unsigned)R * cstride;
+                    rv[rr][j] = (ok && rt) ? rt[o] : 0.0f;
+                    zv[rr][j] = (ok && rvq) ? yt[o] : 0.0f;
+                    sv[rr][j] = (ok && st) ? st[o] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int R = ib * 32 + rr + 8 * rq;
+                const float bias = bias_t[R + 4 * hi], ao = ao_t[R + 4 * hi], ao_inv = ao_t[BM + R + 4 * hi];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (!(okc[j] & (R < rows_left))) continue;
+                    const unsigned o = lane_off[j] + (unsigned)R * cstride;
+                    float val = v[j][4 * rq + rr] + bias;
+                    if (noise) val = rv[rr][j] + p.noise[(int64_t)b * p.noise_bstride + tcol[j]] * val;
+                    else if (rt) val = val + rv[rr][j];
+                    if (snake) val = nc_snakef(val, ao, ao_inv);
+                    if (p.epi & EPI_TANH) val = nc_tanhf(val);
+                    if (rvq) {
+                        yt[o] = zv[rr][j] + val;
+                        if (st) st[o] = sv[rr][j] - val;
+                    } else {
+                        yt[o] = val;
+                    }
+                }
+            }
+        });
+    };
+
     if constexpr (!FUSE) {
         // phase A: every global read of the epilogue (residual tile, noise row), folded into the accumulators; phase B: stores only.
         // The rare RVQ-accumulate / noise-injection epilogues take the generic instance, everything else the lean one.
-        auto run_epilogue = [&](auto gen_tag, auto full_tag, auto has_res, auto snake) __attribute__((always_inline)) {
-            float nz[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                nz[j] = (decltype(gen_tag)::value && (p.epi & EPI_NOISE)) ? p.noise[(int64_t)b * p.noise_bstride + tcol[j]] : 0.0f;
+        auto run_epilogue = [&](auto has_res, auto snake) __attribute__((always_inline)) {
+            constexpr std::false_type gen_tag{};
+            constexpr std::true_type full_tag{};
+            const float nz[TN] = {};
             constexpr int NRV = TM * TN >= 6 ? 1 : 2;   // read one row block ahead where the registers allow it
             float rv[NRV][16][TN];
             if (has_res) load_res(0, rv[0], p.res, full_tag);
@@ -474,21 +538,19 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
                 store_rows(decltype(it)::value, acc[decltype(it)::value], Ep + BM, snake, gen_tag, full_tag);
             });
         };
-        // The lean instances are straight-line code (flags folded at compile time); RVQ accumulate, noise injection and tanh
-        // (small layers) share the generic instance.
+        // Full tiles of the plain epilogues run straight-line code (flags folded at compile time); edge tiles and the RVQ / noise /
+        // tanh epilogues (small layers) take the quad emitter.
         const bool has_res = p.res != nullptr, snake = p.alpha_out != nullptr;
-        auto pick = [&](auto full_tag) __attribute__((always_inline)) {
-            if (has_res) {
-                if (snake) run_epilogue(std::false_type{}, full_tag, std::true_type{}, std::true_type{});
-                else run_epilogue(std::false_type{}, full_tag, std::true_type{}, std::false_type{});
-            } else {
-                if (snake) run_epilogue(std::false_type{}, full_tag, std::false_type{}, std::true_type{});
-                else run_epilogue(std::false_type{}, full_tag, std::false_type{}, std::false_type{});
-            }
-        };
-        if (p.epi & (EPI_RVQ | EPI_NOISE | EPI_TANH)) run_epilogue(std::true_type{}, std::false_type{}, nc_rt_flag{has_res}, nc_rt_flag{snake});
-        else if (tile_full) pick(std::true_type{});
-        else pick(std::false_type{});
+        if ((p.epi & (EPI_RVQ | EPI_NOISE | EPI_TANH)) || !tile_full) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) emit_rows_quad(i, acc[i], Ep, Ep + BM, snake, p.res);
+        } else if (has_res) {
+            if (snake) run_epilogue(std::true_type{}, std::true_type{});
+            else run_epilogue(std::true_type{}, std::false_type{});
+        } else {
+            if (snake) run_epilogue(std::false_type{}, std::true_type{});
+            else run_epilogue(std::false_type{}, std::false_type{});
+        }
     } else {
         // ---- fused ResidualUnit tail (ResidualUnit.cs:29-34,50-59): this block holds ALL channels of
         //      h_pre = conv7(snake(x)) for its columns (n_co_tiles == 1, Cin == Cout == BM), so
@@ -533,8 +595,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
         constexpr bool RES_UPFRONT = TM * TN <= 6;
         float rvall[RES_UPFRONT ? TM : 1][16][TN];
         if constexpr (RES_UPFRONT) {
+            if (tile_full) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) load_res(i, rvall[i], p.res, std::false_type{});
+                for (int i = 0; i < TM; ++i) load_res(i, rvall[i], p.res, std::true_type{});
+            }
         }
         nc_static_for<TM>([&](auto i2t) __attribute__((always_inline)) {
             constexpr int i2 = decltype(i2t)::value;
@@ -553,17 +617,31 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
                 for (int j = 0; j < TN; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[i][j][reg], acc2[j], 0, 0, 0);
             });
             const float nz0[TN] = {};
-            if constexpr (RES_UPFRONT) {
-                add_rows(i2, acc2, rvall[i2], nz0, Ep + 3 * BM, std::true_type{}, std::false_type{});
+            if (!tile_full) {
+                emit_rows_quad(i2, acc2, Ep + 3 * BM, Ep + 4 * BM, p.alpha_out2 != nullptr, p.res);
             } else {
-                float rv[16][TN];
-                load_res(i2, rv, p.res, std::false_type{});
-                add_rows(i2, acc2, rv, nz0, Ep + 3 * BM, std::true_type{}, std::false_type{});
+                if constexpr (RES_UPFRONT) {
+                    add_rows(i2, acc2, rvall[i2], nz0, Ep + 3 * BM, std::true_type{}, std::false_type{});
+                } else {
+                    float rv[16][TN];
+                    load_res(i2, rv, p.res, std::true_type{});
+                    add_rows(i2, acc2, rv, nz0, Ep + 3 * BM, std::true_type{}, std::false_type{});
+                }
+                if (p.alpha_out2 != nullptr) store_rows(i2, acc2, Ep + 4 * BM, std::true_type{}, std::false_type{}, std::true_type{});
+                else store_rows(i2, acc2, Ep + 4 * BM, std::false_type{}, std::false_type{}, std::true_type{});
             }
-            store_rows(i2, acc2, Ep + 4 * BM, nc_rt_flag{p.alpha_out2 != nullptr}, std::false_type{}, std::false_type{});
         });
     }
     NC_TR();
+#ifdef NC_DBG_TRACE
+    if (tr_on) {
+        const unsigned long long tnow = __builtin_readcyclecounter();
+        for (int i = lane; i < min(tr_n, 512); i += 64) {   // widen the 32-bit LDS stamps against the final 64-bit reading
+            const unsigned lo = tr_l[i];
+            tr_p[i] = tnow - (unsigned long long)((unsigned)tnow - lo);
+        }
+    }
+#endif
 }
 
 typedef void (*conv_kernel_fn)(const ConvArgs);
