@@ -42,6 +42,19 @@ int conv_kernel_nx_k16();
 conv_kernel_fn conv_kernel_table_fused_k7(int, int);
 conv_kernel_fn conv_kernel_table_light_k7(int, int);
 conv_kernel_fn conv_kernel_table_wide_k7(int, int);
+conv_kernel_fn conv_kernel_table_narrow_k2(int);
+conv_kernel_fn conv_kernel_table_narrow_k3(int);
+conv_kernel_fn conv_kernel_table_narrow_k7(int);
+conv_kernel_fn conv_kernel_table_narrow_k16(int);
+static conv_kernel_fn narrow_kernel(int K, int TM) {
+    switch (K) {
+        case 2: return conv_kernel_table_narrow_k2(TM);
+        case 3: return conv_kernel_table_narrow_k3(TM);
+        case 7: return conv_kernel_table_narrow_k7(TM);
+        case 16: return conv_kernel_table_narrow_k16(TM);
+    }
+    return nullptr;
+}
 conv_kernel_fn conv1x1_kernel_table(int, int);
 void launch_skinny_proj(const float* x, int64_t x_bstride, int64_t x_cstride, const float* wp, const float* bias, float* y, int64_t y_bstride,
                         int64_t y_cstride, int B, int Cin, int Cout, int64_t T, hipStream_t s);
@@ -163,7 +176,7 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
     alts.clear();
     static const bool no_alts = std::getenv("NC_NO_TILE_ALTS") && std::getenv("NC_NO_TILE_ALTS")[0] == '1';
     if (!no_alts && Cout >= 128)
-        for (int tm = 3; tm >= 2; --tm) {
+        for (int tm = 3; tm >= 2; --tm) {   // (single-row-block tiles measured slower everywhere)
             if (tm == cfg.TM || Cout % (32 * tm) != 0) continue;
             alts.emplace_back(new Alt());
             alts.back()->cfg = cfg;
@@ -226,6 +239,12 @@ static TileChoice choose_tile(const ConvLayer& L, int64_t blocks_per_rowtile, bo
     };
     TileChoice best{L.cfg, L.w.as<float>(), L.w_phase_stride};
     double bc = cost(L.cfg);
+    static const int tm_pick = std::getenv("NC_TM_PICK") ? atoi(std::getenv("NC_TM_PICK")) : 0;   // experiment: force a packed variant
+    if (tm_pick) {
+        for (const auto& a : L.alts)
+            if (a->cfg.TM == tm_pick) return TileChoice{a->cfg, a->w.as<float>(), a->w_phase_stride};
+        return best;
+    }
     for (const auto& a : L.alts) {
         const double c = cost(a->cfg);
         if (c < bc) {
@@ -299,12 +318,25 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         const int xw2 = (c.BN() - 1) * sx0 + (L.Ktaps - 1) * ad0 + 1;
         if (c.TN == 2 && c.CB * ((xw2 + 63) / 64) > 4 * nx_for_k(c.K)) c.TN = 1;
     }
+    // narrow variant (3 waves, 96 columns): rows of 65..96 columns would leave a quarter of a 128-column tile on padding
+    bool narrow = false;
+    {
+        static const bool no_narrow = std::getenv("NC_NO_NARROW") && std::getenv("NC_NO_NARROW")[0] == '1';
+        const int rem = (int)(n_cols_all % 128);
+        const int sx0 = L.transposed ? 1 : L.stride, ad0 = L.transposed ? 1 : L.dil;
+        const int xw96 = 95 * sx0 + (L.Ktaps - 1) * ad0 + 1;
+        const bool fits = c.CB * ((xw96 + 63) / 64) <= 3 * nx_for_k(c.K);
+        if (!no_narrow && fits && !io.fuse_k1 && c.TN == 1 && n_cols_all <= 96 && rem > 64 && narrow_kernel(c.K, c.TM)) {
+            narrow = true;
+            c.NW = 3;
+        }
+    }
     // light variant (reduction block of 4 channels, 3 workgroups per CU): same packed weights when Cin is a multiple of 8
     int nx = nx_for_k(c.K);
     bool light = false;
     {
         static const int light_mode = std::getenv("NC_LIGHT") ? atoi(std::getenv("NC_LIGHT")) : 0;
-        if (light_mode == 1 && !io.fuse_k1 && c.K == 7 && c.CB == 8 && L.Cin % 8 == 0 && c.TN == 2 && (c.TM == 2 || c.TM == 3)) {
+        if (light_mode == 1 && !narrow && !io.fuse_k1 && c.K == 7 && c.CB == 8 && L.Cin % 8 == 0 && c.TN == 2 && (c.TM == 2 || c.TM == 3)) {
             light = true;
             c.CB = 4;
             nx = 5;
@@ -313,7 +345,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     bool wide = false;
     {
         static const int wide_mode = std::getenv("NC_WIDE") ? atoi(std::getenv("NC_WIDE")) : 0;
-        if (wide_mode == 1 && !light && !io.fuse_k1 && c.K == 7 && c.TN == 2 && c.TM >= 2 && n_cols_all >= 2048) {
+        if (wide_mode == 1 && !light && !narrow && !io.fuse_k1 && c.K == 7 && c.TN == 2 && c.TM >= 2 && n_cols_all >= 2048) {
             wide = true;
             c.NW = 8;
             nx = 9;
@@ -383,6 +415,8 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         a.alpha_out2 = io.alpha_out2;
         fn = conv_kernel_table_fused_k7(c.TM, c.TN);
         if (!fn) fail(NC_EUNSUPPORTED, "no fused residual-unit kernel for TM=%d TN=%d", c.TM, c.TN);
+    } else if (narrow) {
+        fn = narrow_kernel(c.K, c.TM);
     } else if (wide) {
         fn = conv_kernel_table_wide_k7(c.TM, c.TN);
         if (!fn) fail(NC_EUNSUPPORTED, "no wide conv kernel for TM=%d TN=%d", c.TM, c.TN);

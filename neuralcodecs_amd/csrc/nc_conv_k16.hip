@@ -2,3 +2,4 @@
 // up to 18 prefetched window words per lane).
 #include "nc_conv_kernel.hip.h"
 NC_INSTANTIATE_CONV_K(16, 2, 18)
+NC_INSTANTIATE_CONV_NARROW(16, 2, 18)

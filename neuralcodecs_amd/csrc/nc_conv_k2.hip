@@ -2,3 +2,4 @@
 // up to 20 prefetched window words per lane).
 #include "nc_conv_kernel.hip.h"
 NC_INSTANTIATE_CONV_K(2, 16, 20)
+NC_INSTANTIATE_CONV_NARROW(2, 16, 20)

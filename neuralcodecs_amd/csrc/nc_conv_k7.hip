@@ -18,3 +18,4 @@ extern "C" __attribute__((visibility("default"))) int nc_dbg_trace_read(unsigned
     return 0;
 }
 #endif
+NC_INSTANTIATE_CONV_NARROW(7, 8, 10)

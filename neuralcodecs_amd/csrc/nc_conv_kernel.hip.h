@@ -716,3 +716,18 @@ inline conv_kernel_fn get_conv_kernel() {
         return nullptr;                                                                                    \
     }                                                                                                      \
     }
+
+// Narrow variants: 3 waves / 96 columns per workgroup (TN = 1), for the deep layers whose rows hold ~90 frames: a 128-column
+// tile would idle a quarter of its matrix-core work on padding.
+#define NC_INSTANTIATE_CONV_NARROW(KVAL, CBVAL, NXVAL)                                                     \
+    namespace nc {                                                                                         \
+    conv_kernel_fn conv_kernel_table_narrow_k##KVAL(int TM) {                                              \
+        switch (TM) {                                                                                      \
+            case 1: return get_conv_kernel<1, 1, KVAL, CBVAL, NXVAL, false, 2, 3>();                       \
+            case 2: return get_conv_kernel<2, 1, KVAL, CBVAL, NXVAL, false, 2, 3>();                       \
+            case 3: return get_conv_kernel<3, 1, KVAL, CBVAL, NXVAL, false, 2, 3>();                       \
+            case 4: return get_conv_kernel<4, 1, KVAL, CBVAL, NXVAL, false, 2, 3>();                       \
+        }                                                                                                  \
+        return nullptr;                                                                                    \
+    }                                                                                                      \
+    }
