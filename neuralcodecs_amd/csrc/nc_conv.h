@@ -57,6 +57,13 @@ struct ConvArgs {
     int32_t ep_off;                // float offset in LDS of the per-row epilogue table (bias, Snake alpha, 1/alpha [, fused set])
 };
 
+// Position of row (32*i + r) of a weight tile inside one kk row of BM = 32*TM floats.  The TM values of one matrix-core lane
+// (rows r, 32+r, ...) sit next to each other, so a lane fetches its A fragments with one wide LDS read (b64 / b128; TM = 3:
+// b64 + b32) whose address is lane base + immediate.
+__host__ __device__ constexpr int a_tile_pos(int TM, int i, int r) {
+    return TM == 1 ? r : TM == 2 ? 2 * r + i : TM == 4 ? 4 * r + i : (i < 2 ? 2 * r + i : 64 + r);
+}
+
 struct TileCfg {
     int TM, TN, K, CB;
     int NW = 4;                       // waves per workgroup (8: wide variants)

@@ -165,7 +165,7 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
                             } else {
                                 v = dense_w[((size_t)co * Cin + ci) * K + k];
                             }
-                            dst[(size_t)kk * BM + r] = v;
+                            dst[(size_t)kk * BM + a_tile_pos(tc.TM, r / 32, r % 32)] = v;
                         }
                     }
                 }

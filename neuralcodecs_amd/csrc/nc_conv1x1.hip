@@ -16,6 +16,7 @@
 
 #include "nc_conv.h"
 #include "nc_math.h"
+#include "nc_frag.h"
 
 namespace nc {
 
@@ -114,7 +115,6 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
     }
     __syncthreads();
 
-    const int a_lane = hi * BM + l31;
     for (int cb = 0; cb < n_cb; ++cb) {
         const int cur = cb & 1;
         const bool more = cb + 1 < n_cb;
@@ -126,12 +126,11 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
                 ra[n] = src[(A_VEC % 256 == 0) ? idx : min(idx, (unsigned)(A_VEC - 1))];
             }
         }
-        const float* Ac = As[cur] + a_lane;
+        const float* Ac = As[cur] + hi * BM + nc_a_lane_off<TM>(l31);
 #pragma unroll
         for (int kp = 0; kp < KP; ++kp) {
             float a[TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = Ac[2 * kp * BM + i * 32];
+            nc_load_a_frag<TM>(Ac + 2 * kp * BM, l31, a);
             const f32x2 bv = bq[kp % PF];
             const int g = cb * KP + kp + PF;
             if (g < n_steps) bq[kp % PF] = load_b(g);

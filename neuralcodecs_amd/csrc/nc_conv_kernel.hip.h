@@ -4,6 +4,7 @@
 
 #include "nc_conv.h"
 #include "nc_math.h"
+#include "nc_frag.h"
 
 #include <type_traits>
 #include <utility>
@@ -12,7 +13,6 @@ namespace nc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 template <int N, class F, int... I>
 __device__ __forceinline__ void nc_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -179,31 +179,40 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
     // window slots of one channel, item -> wave item%4; items past n_items land in pad rows.
     f32x4 ra[GA];
     float rx[GX];
+    // loop-invariant part of the window reads: item i of this wave covers channel xc[i] (wave-uniform) of the reduction block and
+    // the 64 window slots starting at xj[i]; its lanes read x[clamp(xs0 + slot)] = xg[i] of that channel row
+    unsigned xg[NX];
+    int xc[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int item = wave + NW * i;
+        xc[i] = (item * chunk_magic) >> 20;
+        xg[i] = (unsigned)min(max(xs0 + (item - xc[i] * nchunk) * 64 + lane, 0), x_len - 1);
+    }
     auto issue_group_to = [&](int cbn, auto gtag, f32x4 (&ra)[GA], float (&rx)[GX]) __attribute__((always_inline)) {
         constexpr int g = decltype(gtag)::value;
         const f32x4* src = wbase + (size_t)cbn * A_VEC;
         nc_static_for<GA>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value, n = g * GA + u;
             if constexpr (n < NA) {
-                const unsigned idx = (unsigned)(tid + NT * n);
 #ifdef NC_ABL_NOLOADA
                 ra[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #else
-                ra[u] = src[(A_VEC % NT == 0) ? idx : min(idx, (unsigned)(A_VEC - 1))];
+                // uniform pointer (scalar arithmetic) + the thread index: no per-read vector address arithmetic
+                const f32x4* srcn = src + NT * n;
+                ra[u] = srcn[(A_VEC % NT == 0) ? (unsigned)tid : min((unsigned)tid, (unsigned)(A_VEC - 1 - NT * n))];
 #endif
             }
         });
         nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value, i = g * GX + u;
             if constexpr (i < NX) {
-                const int item = wave + NW * i;
-                const int c = (item * chunk_magic) >> 20;
-                const int ci = min(cbn * CB + c, Cin - 1);
-                const int gp = xs0 + (item - c * nchunk) * 64 + lane;
+                const int ci = min(cbn * CB + xc[i], Cin - 1);           // wave-uniform
+                const float* row = xb + (size_t)((unsigned)ci * x_cstride);   // uniform base + 32-bit lane offset
 #ifdef NC_ABL_NOLOADX
-                rx[u] = (float)gp;
+                rx[u] = (float)xg[i];
 #else
-                rx[u] = xb[(unsigned)ci * x_cstride + (unsigned)min(max(gp, 0), x_len - 1)];
+                rx[u] = row[xg[i]];
 #endif
             }
         });
@@ -296,25 +305,33 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
     }
     __syncthreads();
 
-    const int a_lane = hi * BM + l31;
     const int x_lane = wave * BNW + l31;
+    // B-fragment addressing: MFMA step kp pairs kk = 2kp (lanes 0-31) with kk+1 (lanes 32-63), i.e. tap k0 of channel c0 with the
+    // next tap (or tap 0 of the next channel).  The lane-half difference depends only on k0: one base per k0, so a step's address
+    // is base[k0] + (wave-uniform offset of (c0, k0)) -- one vector add per step.
+    int xt[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int d = (k + 1 < K) ? tap[k + 1] - tap[k] : xrow + tap[0] - tap[k];
+        xt[k] = x_lane + (hi ? d : 0);
+    }
 
     float fa[2][TM], fb[2][TN];
-    auto load_frag = [&](const float* Ac, const float* Xc, auto kp_tag) __attribute__((always_inline)) {
+    // Ac = current weight buffer + hi*BM (the kk row of this lane half at step 0); xsc = scalar float index of the current window
+    auto load_frag = [&](const float* Ac, int xsc, auto kp_tag) __attribute__((always_inline)) {
         constexpr int kp = decltype(kp_tag)::value;
-        constexpr int c0 = (2 * kp) / K, k0 = (2 * kp) % K, c1 = (2 * kp + 1) / K, k1 = (2 * kp + 1) % K;
-        const int o0 = c0 * xrow + tap[k0], o1 = c1 * xrow + tap[k1];
-        const int o = hi ? o1 : o0;
+        constexpr int c0 = (2 * kp) / K, k0 = (2 * kp) % K;
+        // (readfirstlane pins the wave-uniform part in a scalar register: vector + scalar is then one add per step)
+        const int o = xt[k0] + __builtin_amdgcn_readfirstlane(xsc + c0 * xrow + tap[k0]);
+        nc_load_a_frag<TM>(Ac + 2 * kp * BM, l31, fa[kp & 1]);   // Ac carries the lane part: immediate offsets only
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[kp & 1][i] = Ac[2 * kp * BM + i * 32];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[kp & 1][j] = Xc[o + j * 32];
+        for (int j = 0; j < TN; ++j) fb[kp & 1][j] = smem[o + j * 32];
     };
 
     for (int cb = 0; cb < n_cb; ++cb) {
         const int cur = cb & 1;
-        const float* Ac = As0 + cur * A_FLOATS + a_lane;
-        const float* Xc = Xs0 + cur * xbuf + x_lane;
+        const float* Ac = As0 + cur * A_FLOATS + hi * BM + nc_a_lane_off<TM>(l31);
+        const int Xc = 2 * A_FLOATS + cur * xbuf;   // scalar index of the window buffer in smem; the lane part lives in xt[]
         float* const An = As0 + (cur ^ 1) * A_FLOATS;
         float* const Xn = Xs0 + (cur ^ 1) * xbuf;
         const bool more = cb + 1 < n_cb;

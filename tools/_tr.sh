@@ -1,1 +1,3 @@
-for tm in 4 3 2 1; do echo "NC_TM_PICK=$tm"; NC_TM_PICK=$tm timeout 300 python tools/convbench.py 2>&1 | grep -E "down C512|enc.out|dec.in|up C1536|k7 C768 d1|k7 C512 d1|up C768|k1 C768|k1 C512"; done
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 300 python tools/convbench.py 2>&1 | tail -56 | grep -v res_unit
+timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
