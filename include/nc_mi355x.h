@@ -228,6 +228,31 @@ NC_API nc_status nc_unpack_codes_dev(int device_index, const uint8_t* packed, in
 NC_API nc_status nc_pack_codes(int device_index, const int64_t* codes, int32_t B, int32_t K, int64_t T, int32_t bits, uint8_t* packed);
 NC_API nc_status nc_unpack_codes(int device_index, const uint8_t* packed, int32_t B, int32_t K, int64_t T, int32_t bits, int64_t* codes);
 
+/* ------------------------------------------------------------------------------- audio pre / post
+ * The host-side steps either side of the tensor path as device kernels, so a float[]-level caller can keep its
+ * audio in HBM from the decoded WAV bytes to the codec and back.  Device pointers, asynchronous on `hip_stream` (NULL = null
+ * stream).  Arithmetic follows the reference statement by statement (bit-identical results):
+ *   pcm16_to_float   replaces AudioUtils.AudioBytesToFloatArray (Core/Utils/AudioUtils.cs:13-36): out = int16 * (1/32768f), same
+ *                    order; planar != 0 writes channel-major [channels][n_frames] like NAudioUtils.cs:94-104 / Examples/Program.cs:391-401
+ *   float_to_pcm16   replaces AudioUtils.FloatArrayToAudioBytes (AudioUtils.cs:172-186) with the clamp of Dia.SaveAudio
+ *                    (Models/Dia.cs:918-923): (short)(clamp(x,-1,1) * 32767), truncating
+ *   mix_to_mono      replaces AudioUtils.ConvertToMono (AudioUtils.cs:45-61): interleaved [n_frames][channels] -> [n_frames]
+ *   interleave       replaces AudioUtils.DeinterleaveToInterleave (AudioUtils.cs:90-101), any channel count
+ *   deinterleave     replaces AudioUtils.InterleaveToDeinterleave (AudioUtils.cs:204-219)
+ *   resample_linear  replaces AudioUtils.ResampleLinear (AudioUtils.cs:329-354) == SNAC.ResampleAudio (Models/SNAC.cs:284-308):
+ *                    [B][n_in] -> [B][nc_audio_resample_len(n_in, src, dst)], binary64 position arithmetic */
+NC_API int64_t nc_audio_resample_len(int64_t n_in, int32_t src_rate, int32_t dst_rate);
+NC_API nc_status nc_audio_pcm16_to_float_dev(int device_index, const int16_t* pcm, int64_t n_frames, int32_t channels, int32_t planar,
+                                             float* out, void* hip_stream);
+NC_API nc_status nc_audio_float_to_pcm16_dev(int device_index, const float* in, int64_t n, int16_t* out, void* hip_stream);
+NC_API nc_status nc_audio_mix_to_mono_dev(int device_index, const float* in, int64_t n_frames, int32_t channels, float* out, void* hip_stream);
+NC_API nc_status nc_audio_interleave_dev(int device_index, const float* planar, int64_t n_frames, int32_t channels, float* out,
+                                         void* hip_stream);
+NC_API nc_status nc_audio_deinterleave_dev(int device_index, const float* interleaved, int64_t n_frames, int32_t channels, float* out,
+                                           void* hip_stream);
+NC_API nc_status nc_audio_resample_linear_dev(int device_index, const float* in, int32_t B, int64_t n_in, int32_t src_rate, int32_t dst_rate,
+                                              float* out, void* hip_stream);
+
 /* ------------------------------------------------------------------------------------ profiling
  * Per-kernel-class timing with HIP events recorded on the handle's stream around every launch
  * (used by bench.py for the roofline object).  Classes are stable small integers. */

@@ -10,3 +10,4 @@ from .snac import SNAC  # noqa: F401
 from .encodec import EncodedFrame, Encodec  # noqa: F401
 
 __all__ = ["DAC", "SNAC", "Encodec", "EncodedFrame", "DACConfig", "SNACConfig", "EncodecConfig"]
+from . import audio  # noqa: F401,E402

@@ -103,6 +103,13 @@ SYMBOLS = [
     ("nc_unpack_codes_dev", C.c_int, [C.c_int, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _P, _P]),
     ("nc_pack_codes", C.c_int, [C.c_int, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _P]),
     ("nc_unpack_codes", C.c_int, [C.c_int, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _P]),
+    ("nc_audio_resample_len", C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    ("nc_audio_pcm16_to_float_dev", C.c_int, [C.c_int, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
+    ("nc_audio_float_to_pcm16_dev", C.c_int, [C.c_int, _P, C.c_int64, _P, _P]),
+    ("nc_audio_mix_to_mono_dev", C.c_int, [C.c_int, _P, C.c_int64, C.c_int32, _P, _P]),
+    ("nc_audio_interleave_dev", C.c_int, [C.c_int, _P, C.c_int64, C.c_int32, _P, _P]),
+    ("nc_audio_deinterleave_dev", C.c_int, [C.c_int, _P, C.c_int64, C.c_int32, _P, _P]),
+    ("nc_audio_resample_linear_dev", C.c_int, [C.c_int, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     ("nc_codec_profile_enable", C.c_int, [_P, C.c_int32]),
     ("nc_codec_profile_reset", C.c_int, [_P]),
     ("nc_codec_profile_read", C.c_int, [_P, C.POINTER(NcProfileEntry)]),

@@ -213,20 +213,11 @@ class SNAC:
         return audio[..., :length], codes                                   # SNAC.cs:103 narrow(-1, 0, length)
 
     @staticmethod
-    def resample_linear(x: np.ndarray, src: int, dst: int) -> np.ndarray:
-        """SNAC.ResampleAudio (SNAC.cs:284-308): linear interpolation, float64 position arithmetic like the C#."""
-        x = np.asarray(x, dtype=np.float32)
-        ratio = float(dst) / float(src)
-        n = int(len(x) * ratio)
-        pos = np.arange(n, dtype=np.float64) / ratio
-        idx = pos.astype(np.int64)
-        frac = pos - idx
-        last = idx >= len(x) - 1
-        i0 = np.minimum(idx, len(x) - 1)
-        i1 = np.minimum(idx + 1, len(x) - 1)
-        out = ((1 - frac) * x[i0].astype(np.float64) + frac * x[i1].astype(np.float64)).astype(np.float32)
-        out[last] = x[-1]
-        return out
+    def resample_linear(x, src: int, dst: int):
+        """SNAC.ResampleAudio (SNAC.cs:284-308): linear interpolation with the C#'s float64 position arithmetic, on the device
+        (csrc/nc_audio.hip)."""
+        from . import audio
+        return audio.resample_linear(x, src, dst)
 
     def process_audio(self, audio_data, sample_rate: int, noise=None, seed: int = 0) -> np.ndarray:
         if audio_data is None or len(audio_data) == 0:
