@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--seconds", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=2, help="clips in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-clips", type=int, default=8, help="clips in the bounded CPU-baseline sample")
     ap.add_argument("--check", action="store_true", help="verify clip 0 of the last step against the oracle")
     args = ap.parse_args()
 

@@ -124,3 +124,51 @@ def test_vq_argmin_tie_break_first_index():
     z = np.zeros((1, 8, 3), np.float32)
     idx, _ = ops.vq_argmin(z, cb)
     assert idx.tolist() == [[5, 5, 5]]
+
+
+# Epilogue / tile-variant matrix: every combination of (residual, Snake-out) over shapes that select the straight-line full-tile
+# epilogue, the edge-tile quad emitter, the narrow 96-column variant, the alternate row tiles (Cout >= 128 packs TM = 4/3/2), the
+# pointwise kernel's modes, and row-partial tiles (Cout not a multiple of the tile height).
+EPI_SHAPES = [
+    # (Cin, Cout, K, pad, dil, T, B)
+    (96, 96, 7, 3, 1, 512, 2),       # full 256-column tiles, TM=3
+    (128, 128, 7, 9, 3, 600, 1),     # full + edge tile, TM=4
+    (64, 384, 7, 3, 1, 300, 2),      # Cout 384: alternates packed, edge tile
+    (256, 256, 7, 27, 9, 87, 3),     # ~90 frames: narrow variant
+    (192, 192, 1, 0, 1, 512, 2),     # pointwise kernel, TM=3
+    (256, 128, 1, 0, 1, 258, 2),     # pointwise, edge columns
+    (64, 48, 1, 0, 1, 256, 2),       # pointwise, row-partial tile (48 rows of 64)
+    (32, 40, 3, 1, 1, 333, 2),       # generic kernel, row-partial + edge
+    (64, 64, 1, 0, 1, 255, 1),       # odd length: pointwise kernel not eligible -> generic K=1
+]
+
+
+@pytest.mark.parametrize("with_res", [False, True])
+@pytest.mark.parametrize("with_snake", [False, True])
+@pytest.mark.parametrize("cin,cout,k,p,d,T,B", EPI_SHAPES)
+def test_conv1d_epilogue_matrix_bit_exact(cin, cout, k, p, d, T, B, with_snake, with_res):
+    rng = np.random.default_rng(cin + 7 * cout + 13 * T + k)
+    x = _rand(rng, B, cin, T)
+    w = _rand(rng, cout, cin, k, scale=1.0 / np.sqrt(cin * k))
+    b = _rand(rng, cout, scale=0.1)
+    res = _rand(rng, B, cout, T) if with_res else None
+    ao = _alpha(rng, cout) if with_snake else None
+    want = c_oracle.conv1d(x, w, b, 1, p, d, residual=res)
+    if with_snake:
+        want = c_oracle.snake(want, ao)
+    got = ops.conv1d(x, w, b, 1, p, d, alpha_out=ao, residual=res)
+    assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+
+
+@pytest.mark.parametrize("cin,cout,s,T,B", [(256, 128, 8, 87, 2), (128, 256, 2, 90, 1)])
+def test_conv_transpose_short_rows_bit_exact(cin, cout, s, T, B):
+    """Up-convolutions over ~90-frame rows (the decoder's first block): narrow tiles, all phases, Snake-out."""
+    rng = np.random.default_rng(cin + s)
+    x = _rand(rng, B, cin, T)
+    w = _rand(rng, cin, cout, 2 * s, scale=1.0 / np.sqrt(cin * 2))
+    b = _rand(rng, cout, scale=0.1)
+    ao = _alpha(rng, cout)
+    pad = (s + 1) // 2
+    want = c_oracle.snake(c_oracle.conv_transpose1d(x, w, b, s, pad, s % 2), ao)
+    got = ops.conv1d(x, w, b, s, pad, 1, alpha_out=ao, transposed=True, out_pad=s % 2)
+    assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
