@@ -123,12 +123,15 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
         lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     // (integer division runs on the vector ALU: hand the wave-uniform results back to scalar registers)
+    // Polyphase (transposed) launches: the stride phases of one output tile are adjacent in the order, so they run together on
+    // one XCD -- their interleaved 4-byte stores (every stride-th sample of the same lines) merge in that L2 instead of each
+    // going to HBM as a partial line, and they share the input window.
+    const int phase = __builtin_amdgcn_readfirstlane(lin % p.n_phase);
+    lin /= p.n_phase;
     const int t_tile = __builtin_amdgcn_readfirstlane(lin % p.n_t_tiles);
     lin /= p.n_t_tiles;
     const int b = __builtin_amdgcn_readfirstlane(lin % p.B);
-    lin /= p.B;
-    const int co_tile = __builtin_amdgcn_readfirstlane(lin % p.n_co_tiles);
-    const int phase = __builtin_amdgcn_readfirstlane(lin / p.n_co_tiles);
+    const int co_tile = __builtin_amdgcn_readfirstlane(lin / p.B);
 
     const int col0 = t_tile * BN;
     const int s = p.stride;
