@@ -56,6 +56,8 @@ static conv_kernel_fn narrow_kernel(int K, int TM) {
     return nullptr;
 }
 conv_kernel_fn conv1x1_kernel_table(int, int);
+bool launch_conv_thin(const float* x, int64_t x_bstride, int64_t x_cstride, int Cin, int x_len, const float* w_dense, const float* bias, float* y,
+                      int64_t y_bstride, int64_t y_cstride, int B, int Cout, int K, int pad, int dil, int64_t Tout, bool tanh_out, hipStream_t s);
 void launch_skinny_proj(const float* x, int64_t x_bstride, int64_t x_cstride, const float* wp, const float* bias, float* y, int64_t y_bstride,
                         int64_t y_cstride, int B, int Cin, int Cout, int64_t T, hipStream_t s);
 
@@ -203,6 +205,10 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
         w_skinny.reserve(f.size() * sizeof(float));
         NC_HIP(hipMemcpy(w_skinny.p, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    if (!transposed && stride == 1 && Cout <= 2 && (K == 7 || K == 3 || K == 1)) {
+        w_thin.reserve(sizeof(float) * (size_t)Cout * Cin * K);
+        NC_HIP(hipMemcpy(w_thin.p, dense_w, sizeof(float) * (size_t)Cout * Cin * K, hipMemcpyHostToDevice));
+    }
     has_bias = bias_h != nullptr;
     if (has_bias) {
         bias.reserve(sizeof(float) * Cout);
@@ -301,6 +307,18 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
                            io.y_bstride, io.y_cstride, B, L.Cin, L.Cout, io.Tin, stream);
         if (prof && prof->on) prof->end(stream);
         return;
+    }
+    {   // thin-output layers (PCM heads): streaming kernel instead of a 32-row matrix tile with 1-2 live rows
+        static const bool no_thin = std::getenv("NC_NO_THIN") && std::getenv("NC_NO_THIN")[0] == '1';
+        if (L.w_thin.p && !no_thin && !io.alpha_in && !io.alpha_out && !io.res && !io.fuse_k1 && (io.epi & ~EPI_TANH) == 0) {
+            const int64_t Tout = L.out_len(io.Tin);
+            if (prof && prof->on)
+                prof->begin(stream, L.kclass, L.flops(B, io.Tin), 4.0 * ((double)B * L.Cin * io.Tin + (double)B * L.Cout * Tout + (double)L.Cin * L.Cout * L.K));
+            const bool done = launch_conv_thin(io.x, io.x_bstride, io.x_cstride, L.Cin, io.x_len, L.w_thin.as<float>(), L.has_bias ? L.bias.as<float>() : nullptr,
+                                               io.y, io.y_bstride, io.y_cstride, B, L.Cout, L.K, L.pad, L.dil, Tout, (io.epi & EPI_TANH) != 0, stream);
+            if (prof && prof->on) prof->end(stream);
+            if (done) return;
+        }
     }
     if (launch_conv1x1(L, io, B, stream, prof)) return;
     const int64_t Tout = L.out_len(io.Tin);

@@ -319,16 +319,20 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
         xt[k] = x_lane + (hi ? d : 0);
     }
 
-    float fa[2][TM], fb[2][TN];
+#ifndef NC_FRAG_DEPTH
+#define NC_FRAG_DEPTH 1
+#endif
+    constexpr int FD = NC_FRAG_DEPTH;            // fragment reads run FD matrix-core steps ahead (FD + 1 register sets)
+    float fa[FD + 1][TM], fb[FD + 1][TN];
     // Ac = current weight buffer + hi*BM (the kk row of this lane half at step 0); xsc = scalar float index of the current window
     auto load_frag = [&](const float* Ac, int xsc, auto kp_tag) __attribute__((always_inline)) {
         constexpr int kp = decltype(kp_tag)::value;
         constexpr int c0 = (2 * kp) / K, k0 = (2 * kp) % K;
         // (readfirstlane pins the wave-uniform part in a scalar register: vector + scalar is then one add per step)
         const int o = xt[k0] + __builtin_amdgcn_readfirstlane(xsc + c0 * xrow + tap[k0]);
-        nc_load_a_frag<TM>(Ac + 2 * kp * BM, l31, fa[kp & 1]);   // Ac carries the lane part: immediate offsets only
+        nc_load_a_frag<TM>(Ac + 2 * kp * BM, l31, fa[kp % (FD + 1)]);   // Ac carries the lane part: immediate offsets only
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[kp & 1][j] = smem[o + j * 32];
+        for (int j = 0; j < TN; ++j) fb[kp % (FD + 1)][j] = smem[o + j * 32];
     };
 
     for (int cb = 0; cb < n_cb; ++cb) {
@@ -351,14 +355,17 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
             //      the MFMAs of step kp are issued (register double buffer fa/fb)
             NC_TR();
             constexpr int kp_lo = seg * KP / NSEG, kp_hi = (seg + 1) * KP / NSEG;
-            if constexpr (seg == 0) load_frag(Ac, Xc, std::integral_constant<int, 0>{});
+            if constexpr (seg == 0)
+                nc_static_for<FD>([&](auto d) __attribute__((always_inline)) {
+                    if constexpr (decltype(d)::value < KP) load_frag(Ac, Xc, d);
+                });
 #ifdef NC_EXP_SETPRIO
             __builtin_amdgcn_s_setprio(1);
 #endif
             nc_static_for<kp_hi - kp_lo>([&](auto d) __attribute__((always_inline)) {
                 constexpr int kp = kp_lo + decltype(d)::value;
 #if !defined(NC_ABL_NOFRAG)
-                if constexpr (kp + 1 < KP) load_frag(Ac, Xc, std::integral_constant<int, kp + 1>{});
+                if constexpr (kp + FD < KP) load_frag(Ac, Xc, std::integral_constant<int, kp + FD>{});
 #endif
 #ifdef NC_EXP_SCHED
                 __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of step kp+1 ahead of the MFMAs of step kp
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp & 1][i], fb[kp & 1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp % (FD + 1)][i], fb[kp % (FD + 1)][j], acc[i][j], 0, 0, 0);
             });
 #ifdef NC_EXP_SETPRIO
             __builtin_amdgcn_s_setprio(0);

@@ -1,0 +1,145 @@
+// Thin-output convolution: Cout <= 4 (the decoders' PCM head: Conv1d(C, 1 or 2, k=7) + tanh, Decoder.cs:44-46, Modules/SNAC/Decoder.cs,
+// SEANetDecoder final conv).  On the matrix-core template such a layer fills 1-2 of 32 tile rows and runs at its instruction rate;
+// the work is really one pass over the input tensor (HBM-bound: 4*Cin bytes per output step), so it gets a streaming kernel:
+// one workgroup = 1024 output steps of one clip, CC input channels at a time staged in LDS (coalesced 16-byte reads, zero padding by
+// predicate), each thread 4 consecutive outputs x all output channels with the weights in scalar registers.
+// Arithmetic per output = the canonical chain: fmaf over kk = ci*K + k ascending from +0, then + bias, then tanh.
+#include <type_traits>
+
+#include "nc_conv.h"
+#include "nc_math.h"
+
+namespace nc {
+
+typedef float thin_f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int THIN_TILE = 1024;   // output steps per workgroup
+constexpr int THIN_CC = 8;        // input channels staged per round
+
+template <int COUT, int K>
+__global__ __launch_bounds__(256) void conv_thin_kernel(const float* __restrict__ x, int64_t x_bstride, int64_t x_cstride, int Cin, int x_len,
+                                                        const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+                                                        int64_t y_bstride, int64_t y_cstride, int Tout, int pad, int dil, int n_t_tiles, int tanh_out) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [CC][row], row = THIN_TILE + (K-1)*dil rounded up to 4
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / n_t_tiles, tt = blockIdx.x - b * n_t_tiles;
+    const int t0 = tt * THIN_TILE;
+    const int halo = (K - 1) * dil;
+    const int row = (THIN_TILE + halo + 3 + 4) & ~3;
+    const float* xb = x + (int64_t)b * x_bstride;
+    const int g0 = t0 - pad;              // input position of window slot 0
+
+    float acc[COUT][4];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[c][o] = 0.0f;
+
+    constexpr int NJ = 5;                 // window slots per thread per channel row (row <= 1280)
+    for (int c0 = 0; c0 < Cin; c0 += THIN_CC) {
+        const int nc = min(THIN_CC, Cin - c0);
+        // all reads of the round are issued before the first LDS store (a store between them would serialise the round trips)
+        float r[THIN_CC][NJ];
+#pragma unroll
+        for (int c = 0; c < THIN_CC; ++c) {
+            const float* xr = xb + (int64_t)min(c0 + c, Cin - 1) * x_cstride;
+#pragma unroll
+            for (int u = 0; u < NJ; ++u) r[c][u] = xr[min(max(g0 + tid + 256 * u, 0), x_len - 1)];   // clamped: always in bounds
+        }
+        // (opaque uses after the last read keep every read unconditional and in flight together; the zero padding is a select)
+#pragma unroll
+        for (int c = 0; c < THIN_CC; ++c)
+#pragma unroll
+            for (int u = 0; u < NJ; ++u) {
+                asm volatile("" : "+v"(r[c][u]));
+                const int g = g0 + tid + 256 * u;
+                r[c][u] = (g >= 0 && g < x_len) ? r[c][u] : 0.0f;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < THIN_CC; ++c)
+#pragma unroll
+            for (int u = 0; u < NJ; ++u) {
+                const int j = tid + 256 * u;
+                if (j < row) xs[c * row + j] = r[c][u];
+            }
+        __syncthreads();
+        for (int c = 0; c < nc; ++c) {
+            const float* xl = xs + c * row + 4 * tid;
+            float wv[COUT][K];
+#pragma unroll
+            for (int co = 0; co < COUT; ++co)
+#pragma unroll
+                for (int k = 0; k < K; ++k) wv[co][k] = w[((int64_t)co * Cin + (c0 + c)) * K + k];   // uniform: scalar loads
+            if (dil == 1) {
+                // the 4 outputs of this thread read window slots [4*tid, 4*tid + K + 3): whole 16-byte words
+                constexpr int NV = (K + 3 + 3) / 4;
+                float xw[4 * NV];
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    const thin_f32x4 v = *reinterpret_cast<const thin_f32x4*>(xl + 4 * q);
+                    xw[4 * q] = v[0]; xw[4 * q + 1] = v[1]; xw[4 * q + 2] = v[2]; xw[4 * q + 3] = v[3];
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co)
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) acc[co][o] = fmaf(wv[co][k], xw[k + o], acc[co][o]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    float xv[4];
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) xv[o] = xl[k * dil + o];
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co)
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) acc[co][o] = fmaf(wv[co][k], xv[o], acc[co][o]);
+                }
+            }
+        }
+    }
+    const int t = t0 + 4 * tid;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        const float bv = bias ? bias[co] : 0.0f;
+        float* yr = y + (int64_t)b * y_bstride + (int64_t)co * y_cstride;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float v = acc[co][o] + bv;
+            if (tanh_out) v = nc_tanhf(v);
+            if (t + o < Tout) yr[t + o] = v;
+        }
+    }
+}
+
+template <int COUT>
+static bool launch_thin_k(int K, dim3 grid, size_t lds, hipStream_t s, const float* x, int64_t xb, int64_t xc, int Cin, int x_len, const float* w,
+                          const float* bias, float* y, int64_t yb, int64_t yc, int Tout, int pad, int dil, int ntt, int tanh_out) {
+    switch (K) {
+        case 7: hipLaunchKernelGGL((conv_thin_kernel<COUT, 7>), grid, dim3(256), lds, s, x, xb, xc, Cin, x_len, w, bias, y, yb, yc, Tout, pad, dil, ntt, tanh_out); return true;
+        case 3: hipLaunchKernelGGL((conv_thin_kernel<COUT, 3>), grid, dim3(256), lds, s, x, xb, xc, Cin, x_len, w, bias, y, yb, yc, Tout, pad, dil, ntt, tanh_out); return true;
+        case 1: hipLaunchKernelGGL((conv_thin_kernel<COUT, 1>), grid, dim3(256), lds, s, x, xb, xc, Cin, x_len, w, bias, y, yb, yc, Tout, pad, dil, ntt, tanh_out); return true;
+    }
+    return false;
+}
+
+// dense weights [Cout][Cin][K]; returns false when the shape has no instantiation (the caller takes the generic template)
+bool launch_conv_thin(const float* x, int64_t x_bstride, int64_t x_cstride, int Cin, int x_len, const float* w_dense, const float* bias, float* y,
+                      int64_t y_bstride, int64_t y_cstride, int B, int Cout, int K, int pad, int dil, int64_t Tout, bool tanh_out, hipStream_t s) {
+    if (Cout < 1 || Cout > 2 || (K != 7 && K != 3 && K != 1) || Tout <= 0) return false;
+    const int halo = (K - 1) * dil;
+    const int row = (THIN_TILE + halo + 3 + 4) & ~3;   // + one spare 16-byte word for the whole-word reads
+    if (row > 1280) return false;
+    const size_t lds = sizeof(float) * (size_t)THIN_CC * row;
+    if (lds > 64 * 1024) return false;
+    const int ntt = (int)((Tout + THIN_TILE - 1) / THIN_TILE);
+    const dim3 grid((unsigned)(B * ntt));
+    bool ok = Cout == 1 ? launch_thin_k<1>(K, grid, lds, s, x, x_bstride, x_cstride, Cin, x_len, w_dense, bias, y, y_bstride, y_cstride, (int)Tout, pad, dil, ntt, tanh_out)
+                        : launch_thin_k<2>(K, grid, lds, s, x, x_bstride, x_cstride, Cin, x_len, w_dense, bias, y, y_bstride, y_cstride, (int)Tout, pad, dil, ntt, tanh_out);
+    if (ok) NC_HIP(hipGetLastError());
+    return ok;
+}
+
+}  // namespace nc

@@ -15,7 +15,7 @@
 namespace nc {
 
 constexpr int VQ_MAX_D = 16;
-constexpr int VQ_FRAMES_PER_WAVE = 8;
+constexpr int VQ_FRAMES_PER_WAVE = 4;   // 16 frames per workgroup: enough workgroups to spread a ~3 k-frame launch over the chip
 
 __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict__ cbT, const float* __restrict__ c2,
                                                         const float* __restrict__ cb_rm, int N, int D, const float* z_e,
@@ -25,8 +25,23 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict_
     float* s_cb = smem;          // [D][N]
     float* s_c2 = smem + D * N;  // [N]
     const int tid = threadIdx.x;
-    for (int i = tid; i < D * N; i += 256) s_cb[i] = cbT[i];
-    for (int i = tid; i < N; i += 256) s_c2[i] = c2[i];
+    // codebook -> LDS, 16-byte words, 8 reads per thread in flight before their LDS stores (a read/store pair per iteration would
+    // cost one global round trip per word); cbT and c2 are contiguous float arrays of D*N and N entries, N a multiple of 4
+    {
+        typedef float vq_f32x4 __attribute__((ext_vector_type(4)));
+        const vq_f32x4* src = reinterpret_cast<const vq_f32x4*>(cbT);
+        vq_f32x4* dst = reinterpret_cast<vq_f32x4*>(s_cb);
+        const int nv = D * N / 4;
+        for (int i0 = 0; i0 < nv; i0 += 8 * 256) {
+            vq_f32x4 r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = src[min(i0 + tid + 256 * u, nv - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + tid + 256 * u < nv) dst[i0 + tid + 256 * u] = r[u];
+        }
+        for (int i = tid; i < N; i += 256) s_c2[i] = c2[i];
+    }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     const int64_t total = (int64_t)B * T;
@@ -131,6 +146,7 @@ static bool g_vq_attr = false;
 void launch_vq_argmin(const Codebook& cb, const float* z_e, int64_t ze_bstride, int B, int64_t T, int64_t* codes,
                       int64_t codes_bstride, float* st, hipStream_t s, Profiler* prof) {
     if (cb.D > VQ_MAX_D) fail(NC_EUNSUPPORTED, "codebook_dim %d > %d", cb.D, VQ_MAX_D);
+    if ((cb.D * cb.N) % 4 != 0) fail(NC_EUNSUPPORTED, "codebook of %d x %d entries is not a whole number of 16-byte words", cb.N, cb.D);
     const size_t lds = sizeof(float) * ((size_t)cb.D * cb.N + cb.N);
     if (lds > 160 * 1024) fail(NC_EUNSUPPORTED, "codebook of %d x %d does not fit LDS", cb.N, cb.D);
     if (!g_vq_attr) {

@@ -37,7 +37,7 @@ def dac44k_layers(B=32):
         for d in (1, 3, 9):
             L.append((f"dec.k7 C{c} d{d}", 1, c, c, 7, 1, 3 * d, d, T, 0, 3))
         L.append((f"dec.k1 C{c}", 3, c, c, 1, 1, 0, 1, T, 0, 4))
-    L.append(("dec.head", 1, 96, 1, 7, 1, 3, 1, T, 0, 1))
+    L.append(("dec.head", 1, 96, 1, 7, 1, 3, 1, T, 0, 0))   # Snake arrives fused by the producer
     return L
 
 
