@@ -154,28 +154,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
     for (int k = 0; k < K; ++k) tap[k] = p.tapoff[k];
     // Snake alphas of all input channels, staged once per block behind the tile buffers
     float2* const Al = reinterpret_cast<float2*>(Xs0 + 2 * xbuf);   // (alpha, 1/alpha) per input channel
-    if (alpha_in != nullptr)
-        for (int i = tid; i < n_cb * CB; i += NT) {
-            const float al = alpha_in[min(i, Cin - 1)];
-            Al[i] = make_float2(al, nc_snake_inv(al));
-        }
     // per-row epilogue operands of this tile: bias, Snake alpha and 1/alpha (and the fused unit's second set).  The epilogue
     // reads them from LDS: a global read issued after the first store would wait for every earlier store to be acknowledged.
+    // (Both tables are filled in the prologue below, behind the first tile's reads.)
     float* const Ep = smem + p.ep_off;
-    for (int i = tid; i < BM; i += NT) {
-        const int co = min(co_tile * BM + i, p.Cout - 1);
-        const float ao = p.alpha_out ? p.alpha_out[co] : 0.0f;
-        Ep[i] = p.bias ? p.bias[co] : 0.0f;
-        Ep[BM + i] = ao;
-        Ep[2 * BM + i] = nc_snake_inv(ao);
-        if constexpr (FUSE) {
-            const float ao2 = p.alpha_out2 ? p.alpha_out2[co] : 0.0f;
-            Ep[3 * BM + i] = p.bias2[co];
-            Ep[4 * BM + i] = ao2;
-            Ep[5 * BM + i] = nc_snake_inv(ao2);
-        }
-    }
-    __syncthreads();
 
     // ---- staging (branch-free; every address is clamped into the tensor) ------------------------
     // weights: thread t copies float4 words t + 256*n; input window: wave-level items of 64 consecutive
@@ -290,11 +272,38 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // ---- prologue: stage reduction block 0.  All groups' reads are issued back to back (one memory round trip, not NG).
+    // ---- prologue: stage reduction block 0.  Every global read of the prologue -- the first tile's groups and the operands of
+    // the two LDS tables -- is issued before anything waits: one memory round trip in all.
     {
         f32x4 ra0[NG][GA];
         float rx0[NG][GX];
         nc_static_for<NG>([&](auto g) __attribute__((always_inline)) { issue_group_to(0, g, ra0[decltype(g)::value], rx0[decltype(g)::value]); });
+        // Snake alphas of all input channels -> (alpha, 1/alpha), 4 reads per thread in flight per pass
+        if (alpha_in != nullptr) {
+            const int n_al = n_cb * CB;
+            for (int i0 = 0; i0 < n_al; i0 += 4 * NT) {
+                float av[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) av[u] = alpha_in[min(i0 + tid + u * NT, Cin - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + tid + u * NT < n_al) Al[i0 + tid + u * NT] = make_float2(av[u], nc_snake_inv(av[u]));
+            }
+        }
+        for (int i = tid; i < BM; i += NT) {
+            const int co = min(co_tile * BM + i, p.Cout - 1);
+            const float ao = p.alpha_out ? p.alpha_out[co] : 0.0f;
+            Ep[i] = p.bias ? p.bias[co] : 0.0f;
+            Ep[BM + i] = ao;
+            Ep[2 * BM + i] = nc_snake_inv(ao);
+            if constexpr (FUSE) {
+                const float ao2 = p.alpha_out2 ? p.alpha_out2[co] : 0.0f;
+                Ep[3 * BM + i] = p.bias2[co];
+                Ep[4 * BM + i] = ao2;
+                Ep[5 * BM + i] = nc_snake_inv(ao2);
+            }
+        }
+        __syncthreads();   // the alpha table is complete before the Snake of the first tile reads it
         nc_static_for<NG>([&](auto g) __attribute__((always_inline)) {
             constexpr int gi = decltype(g)::value;
 #ifdef NC_ABL_NOSNAKE
