@@ -28,11 +28,22 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
     const float* xr = x + ((int64_t)b * C + c) * T;
     const float ai = alpha_in ? alpha_in[c] : 0.0f;
     const float ai_inv = nc_snake_inv(ai);
-    for (int j = threadIdx.x; j < span; j += 256) {
-        const int gp = t0 - pad + j;
-        float v = (gp >= 0 && gp < T) ? xr[gp] : 0.0f;
-        if (alpha_in) v = nc_snakef(v, ai, ai_inv);
-        win[j] = v;
+    // window -> LDS: all reads of the window are in flight before the first LDS store (a read/store pair per iteration costs one
+    // global round trip each); addresses clamped into the row, zero padding by select
+    constexpr int NJ = (DW_TT + 6 * 9 + 255) / 256 + 1;   // slots per thread for K <= 7, dil <= 9 ... generic spans take more passes
+    for (int j0 = 0; j0 < span; j0 += NJ * 256) {
+        float r[NJ];
+#pragma unroll
+        for (int u = 0; u < NJ; ++u) r[u] = xr[min(max(t0 - pad + j0 + (int)threadIdx.x + 256 * u, 0), T - 1)];
+#pragma unroll
+        for (int u = 0; u < NJ; ++u) {
+            asm volatile("" : "+v"(r[u]));
+            const int j = j0 + threadIdx.x + 256 * u;
+            const int gp = t0 - pad + j;
+            float v = (gp >= 0 && gp < T) ? r[u] : 0.0f;
+            if (alpha_in) v = nc_snakef(v, ai, ai_inv);
+            if (j < span) win[j] = v;
+        }
     }
     __syncthreads();
     float wk[DW_MAXK];
@@ -122,18 +133,44 @@ __global__ void layernorm_ct_kernel(const float* __restrict__ x, const float* __
     if (i >= (int64_t)B * T) return;
     const int64_t b = i / T, t = i - b * T;
     const float* xp = x + b * C * T + t;
+    // Channel loops run in batches of 8 reads issued together (same accumulation order as a plain loop); in the output loop this
+    // also keeps the reads of a batch ahead of its stores -- a read behind a store waits for the store's acknowledgement.
+    constexpr int U = 8;
     double s1 = 0.0;
-    for (int c = 0; c < C; ++c) s1 += (double)xp[(int64_t)c * T];
+    for (int c0 = 0; c0 < C; c0 += U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = xp[(int64_t)min(c0 + u, C - 1) * T];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (c0 + u < C) s1 += (double)v[u];
+    }
     const double mu = s1 / C;
     double s2 = 0.0;
-    for (int c = 0; c < C; ++c) {
-        const double d = (double)xp[(int64_t)c * T] - mu;
-        s2 += d * d;
+    for (int c0 = 0; c0 < C; c0 += U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = xp[(int64_t)min(c0 + u, C - 1) * T];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (c0 + u < C) {
+                const double d = (double)v[u] - mu;
+                s2 += d * d;
+            }
     }
     const float r = (float)(1.0 / sqrt(s2 / C + 1e-5));
     const float muf = (float)mu;
     float* yp = y + b * C * T + t;
-    for (int c = 0; c < C; ++c) yp[(int64_t)c * T] = ((xp[(int64_t)c * T] - muf) * r) * gamma[c] + beta[c];
+    for (int c0 = 0; c0 < C; c0 += U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = xp[(int64_t)min(c0 + u, C - 1) * T];
+#pragma unroll
+        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (c0 + u < C) yp[(int64_t)(c0 + u) * T] = ((v[u] - muf) * r) * gamma[c0 + u] + beta[c0 + u];
+    }
 }
 void launch_layernorm_ct(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int64_t T, hipStream_t st) {
     const int64_t n = (int64_t)B * T;

@@ -56,16 +56,38 @@ __global__ void pad_act_kernel(ActView a, ActView b2, int has_b, int elu, float*
     dst[i] = v;
 }
 
-// per 256-sample chunk of one row: binary64 sum and sum of squares, ascending t
-__global__ void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int64_t rows, int64_t T, int nchunk) {
-    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (i >= rows * nchunk) return;
+// per 256-sample chunk of one row: binary64 sum and sum of squares, ascending t (the canonical order: one sequential chain per
+// chunk).  A workgroup of 64 threads owns 64 consecutive chunks: their samples are read coalesced (16 reads per thread in flight)
+// into an LDS tile padded to 257 words per chunk, then thread i walks chunk i from LDS (conflict-free) -- the arithmetic is the
+// plain loop's, only the memory access pattern differs.
+__global__ __launch_bounds__(64) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int64_t rows, int64_t T, int nchunk) {
+    __shared__ float tile[64 * (GN_CHUNK + 1)];
+    const int64_t i0 = (int64_t)blockIdx.x * 64, total = rows * nchunk;
+    const int tid = threadIdx.x;
+    for (int c = 0; c < 64; c += 16) {          // 16 chunks per pass: 16 x 256 samples = 64 reads per thread, in 4 batches of 16
+        for (int q = 0; q < 4; ++q) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int64_t ci = min(i0 + c + u, total - 1);
+                const int64_t r = ci / nchunk, ch = ci - r * nchunk;
+                const int64_t t = min(ch * GN_CHUNK + q * 64 + tid, T - 1);
+                v[u] = x[r * T + t];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) tile[(c + u) * (GN_CHUNK + 1) + q * 64 + tid] = v[u];
+        }
+    }
+    __syncthreads();
+    const int64_t i = i0 + tid;
+    if (i >= total) return;
     const int64_t r = i / nchunk, ch = i - r * nchunk;
     const int64_t t0 = ch * GN_CHUNK, t1 = t0 + GN_CHUNK < T ? t0 + GN_CHUNK : T;
-    const float* xp = x + r * T;
+    const float* tp = tile + tid * (GN_CHUNK + 1);
     double s1 = 0.0, s2 = 0.0;
-    for (int64_t t = t0; t < t1; ++t) {
-        const double v = (double)xp[t];
+    const int n = (int)(t1 - t0);
+    for (int t = 0; t < n; ++t) {
+        const double v = (double)tp[t];
         s1 += v;
         s2 += v * v;
     }
