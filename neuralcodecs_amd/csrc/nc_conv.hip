@@ -42,6 +42,7 @@ int conv_kernel_nx_k16();
 conv_kernel_fn conv_kernel_table_fused_k7(int, int);
 conv_kernel_fn conv_kernel_table_light_k7(int, int);
 conv_kernel_fn conv_kernel_table_wide_k7(int, int);
+conv_kernel_fn conv_kernel_table_spec_k7(int, int);
 conv_kernel_fn conv_kernel_table_narrow_k2(int);
 conv_kernel_fn conv_kernel_table_narrow_k3(int);
 conv_kernel_fn conv_kernel_table_narrow_k7(int);
@@ -369,7 +370,16 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
             nx = 9;
         }
     }
-    const int NW = c.NW;
+    // wave-specialised variant (4 consumer + 2 producer waves): k=7, 64/96-row tiles, long rows
+    int n_prod = 0;
+    {
+        static const int spec_mode = std::getenv("NC_SPEC") ? atoi(std::getenv("NC_SPEC")) : 0;
+        if (spec_mode == 1 && !light && !narrow && !wide && !io.fuse_k1 && c.K == 7 && c.TN == 2 && (c.TM == 2 || c.TM == 3)) {
+            n_prod = 2;
+            nx = 20;
+        }
+    }
+    const int NW = n_prod ? n_prod : c.NW;   // waves that stage the input window
     const int BM = c.BM(), BN = c.BN(), CB = c.CB, KB = c.KB();
     ConvArgs a{};
     a.x = io.x; a.x_bstride = io.x_bstride; a.x_cstride = io.x_cstride; a.Cin = L.Cin; a.x_len = io.x_len;
@@ -433,6 +443,9 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         a.alpha_out2 = io.alpha_out2;
         fn = conv_kernel_table_fused_k7(c.TM, c.TN);
         if (!fn) fail(NC_EUNSUPPORTED, "no fused residual-unit kernel for TM=%d TN=%d", c.TM, c.TN);
+    } else if (n_prod) {
+        fn = conv_kernel_table_spec_k7(c.TM, c.TN);
+        if (!fn) fail(NC_EUNSUPPORTED, "no specialised conv kernel for TM=%d TN=%d", c.TM, c.TN);
     } else if (narrow) {
         fn = narrow_kernel(c.K, c.TM);
     } else if (wide) {
@@ -460,7 +473,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         if (io.fuse_k1) fl += io.fuse_k1->flops(B, io.Tin);
         prof->begin(stream, L.kclass, fl, bytes);
     }
-    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64 * NW), lds, stream, a);
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64 * (c.NW + n_prod)), lds, stream, a);
     NC_HIP(hipGetLastError());
     if (prof && prof->on) prof->end(stream);
 }

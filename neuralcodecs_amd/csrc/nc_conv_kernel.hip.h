@@ -53,9 +53,16 @@ typedef __attribute__((address_space(3))) void* nc_lptr;
 // segment g+1 -- so a load has a whole segment of MFMA time to land, only 1/(NSEG-1) of the staging
 // registers are live at once, and the VALU work sits between matrix-core segments.
 //   MFMA step kp: lane l supplies A[row = l&31][kk = 2*kp + (l>>5)] and B[kk][col = l&31].
-template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4>
-__global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs p) {
-    constexpr int NT = 64 * NW;                    // threads per workgroup
+// NP > 0: wave-specialised variant.  NW consumer waves do nothing but fragment reads and matrix-core steps; NP producer waves
+// stage the next reduction block (global reads, Snake, LDS writes).  In the classic variant every wave alternates between the two
+// roles, and its vector-ALU staging run issues slowly while the co-resident wave saturates the matrix pipe -- time during which
+// its own matrix-core steps cannot issue.  With the roles split, the consumers always have matrix-core work ready.
+template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0>
+__global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const ConvArgs p) {
+    constexpr bool SPEC = NP > 0;
+    constexpr int NT = 64 * (NW + NP);             // threads per workgroup
+    constexpr int SW = SPEC ? NP : NW;             // waves that stage
+    constexpr int SNT = 64 * SW;
     constexpr int BM = 32 * TM;
     constexpr int BNW = 32 * TN;
     constexpr int BN = NW * BNW;
@@ -63,11 +70,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
     constexpr int KP = KB / 2;
     constexpr int A_FLOATS = KB * BM;
     constexpr int A_VEC = A_FLOATS / 4;            // float4 words in the weight tile
-    constexpr int NA = (A_VEC + NT - 1) / NT;      // float4 copies per thread
+    constexpr int NA = (A_VEC + SNT - 1) / SNT;    // float4 copies per staging thread
 #ifdef NC_NSEG
-    constexpr int NSEG = KP >= 16 ? NC_NSEG : 2;
+    constexpr int NSEG = SPEC ? 3 : (KP >= 16 ? NC_NSEG : 2);
 #else
-    constexpr int NSEG = KP >= 16 ? 4 : 2;
+    constexpr int NSEG = SPEC ? 3 : (KP >= 16 ? 4 : 2);   // (specialised: the producers stage a block in two groups)
 #endif
     constexpr int NG = NSEG - 1;
     constexpr int GA = (NA + NG - 1) / NG;         // per-group register footprint
@@ -82,6 +89,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int hi = lane >> 5;
+    const bool producer = SPEC && wave >= NW;
+    const int swave = SPEC ? wave - NW : wave;     // index among the staging waves (consumers of the specialised variant: unused)
+    const int stid = SPEC ? tid - 64 * NW : tid;
 #ifdef NC_EXP_ASYMPRIO
     // co-resident waves of one SIMD get different issue priorities (by hardware wave slot parity): the favoured wave runs its
     // matrix-core segments at full rate and the other fills the gaps its staging leaves, instead of both stalling together
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
     int xc[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        const int item = wave + NW * i;
+        const int item = swave + SW * i;
         xc[i] = (item * chunk_magic) >> 20;
         xg[i] = (unsigned)min(max(xs0 + (item - xc[i] * nchunk) * 64 + lane, 0), x_len - 1);
     }
@@ -184,8 +194,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
                 ra[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #else
                 // uniform pointer (scalar arithmetic) + the thread index: no per-read vector address arithmetic
-                const f32x4* srcn = src + NT * n;
-                ra[u] = srcn[(A_VEC % NT == 0) ? (unsigned)tid : min((unsigned)tid, (unsigned)(A_VEC - 1 - NT * n))];
+                const f32x4* srcn = src + SNT * n;
+                ra[u] = srcn[(A_VEC % SNT == 0) ? (unsigned)stid : min((unsigned)stid, (unsigned)(A_VEC - 1 - SNT * n))];
 #endif
             }
         });
@@ -210,9 +220,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
         nc_static_for<GA>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value, n = g * GA + u;
             if constexpr (n < NA) {
-                const int idx = tid + NT * n;
+                const int idx = stid + SNT * n;
 #ifndef NC_ABL_NOSTOREA
-                if ((A_VEC % NT == 0) || idx < A_VEC) reinterpret_cast<f32x4*>(Ad)[idx] = ra[u];
+                if ((A_VEC % SNT == 0) || idx < A_VEC) reinterpret_cast<f32x4*>(Ad)[idx] = ra[u];
 #endif
             }
         });
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
             nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
                 constexpr int u = decltype(ut)::value, i = g * GX + u;
                 if constexpr (i < NX) {
-                    const int item = wave + NW * i;
+                    const int item = swave + SW * i;
                     al[u] = Al[cbn * CB + ((item * chunk_magic) >> 20)];
                 }
             });
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
         nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value, i = g * GX + u;
             if constexpr (i < NX) {
-                const int item = wave + NW * i;
+                const int item = swave + SW * i;
                 const int c = (item * chunk_magic) >> 20;
                 const int ci = cbn * CB + c;
                 const int j = (item - c * nchunk) * 64 + lane;
@@ -277,7 +287,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
     {
         f32x4 ra0[NG][GA];
         float rx0[NG][GX];
-        nc_static_for<NG>([&](auto g) __attribute__((always_inline)) { issue_group_to(0, g, ra0[decltype(g)::value], rx0[decltype(g)::value]); });
+        if (!SPEC || producer)
+            nc_static_for<NG>([&](auto g) __attribute__((always_inline)) { issue_group_to(0, g, ra0[decltype(g)::value], rx0[decltype(g)::value]); });
         // Snake alphas of all input channels -> (alpha, 1/alpha), 4 reads per thread in flight per pass
         if (alpha_in != nullptr) {
             const int n_al = n_cb * CB;
@@ -304,16 +315,17 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
             }
         }
         __syncthreads();   // the alpha table is complete before the Snake of the first tile reads it
-        nc_static_for<NG>([&](auto g) __attribute__((always_inline)) {
-            constexpr int gi = decltype(g)::value;
+        if (!SPEC || producer)
+            nc_static_for<NG>([&](auto g) __attribute__((always_inline)) {
+                constexpr int gi = decltype(g)::value;
 #ifdef NC_ABL_NOSNAKE
-            if (false)
+                if (false)
 #else
-            if (alpha_in != nullptr)
+                if (alpha_in != nullptr)
 #endif
-                store_group_from(0, As0, Xs0, g, std::true_type{}, ra0[gi], rx0[gi]);
-            else store_group_from(0, As0, Xs0, g, std::false_type{}, ra0[gi], rx0[gi]);
-        });
+                    store_group_from(0, As0, Xs0, g, std::true_type{}, ra0[gi], rx0[gi]);
+                else store_group_from(0, As0, Xs0, g, std::false_type{}, ra0[gi], rx0[gi]);
+            });
     }
     __syncthreads();
 
@@ -344,6 +356,39 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
         for (int j = 0; j < TN; ++j) fb[kp % (FD + 1)][j] = smem[o + j * 32];
     };
 
+    if constexpr (SPEC) {
+        static_assert(!SPEC || !FUSE, "the fused tail has workgroup barriers: not combined with producer waves");
+        if (producer) {
+            // Producer waves: their own loop (no accumulators live), one barrier per reduction block like the consumers.  Each
+            // block is staged in NG groups, a group's reads all in flight before its Snake + LDS writes.
+            // The reads of group q+1 are issued before group q is transformed and written (two register sets), and the producer
+            // waves run at raised issue priority: their short vector instructions are not starved by the consumers' matrix stream.
+            __builtin_amdgcn_s_setprio(3);
+            f32x4 pa[2][GA];
+            float px[2][GX];
+            if (n_cb > 1) issue_group_to(1, std::integral_constant<int, 0>{}, pa[0], px[0]);
+            for (int cb = 0; cb < n_cb; ++cb) {
+                const int cur = cb & 1;
+                float* const An = As0 + (cur ^ 1) * A_FLOATS;
+                float* const Xn = Xs0 + (cur ^ 1) * xbuf;
+#if !defined(NC_ABL_NOSTAGE)
+                if (cb + 1 < n_cb)
+#else
+                if (false)
+#endif
+                    nc_static_for<NG>([&](auto g) __attribute__((always_inline)) {
+                        constexpr int gi = decltype(g)::value;
+                        // next group in flight: group gi+1 of this block, or group 0 of the block after
+                        if constexpr (gi + 1 < NG) issue_group_to(cb + 1, std::integral_constant<int, gi + 1>{}, pa[(gi + 1) & 1], px[(gi + 1) & 1]);
+                        else if (cb + 2 < n_cb) issue_group_to(cb + 2, std::integral_constant<int, 0>{}, pa[(gi + 1) & 1], px[(gi + 1) & 1]);
+                        if (alpha_in != nullptr) store_group_from(cb + 1, An, Xn, g, std::true_type{}, pa[gi & 1], px[gi & 1]);
+                        else store_group_from(cb + 1, An, Xn, g, std::false_type{}, pa[gi & 1], px[gi & 1]);
+                    });
+                __syncthreads();
+            }
+            return;
+        }
+    }
     for (int cb = 0; cb < n_cb; ++cb) {
         const int cur = cb & 1;
         const float* Ac = As0 + cur * A_FLOATS + hi * BM + nc_a_lane_off<TM>(l31);
@@ -351,6 +396,21 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
         float* const An = As0 + (cur ^ 1) * A_FLOATS;
         float* const Xn = Xs0 + (cur ^ 1) * xbuf;
         const bool more = cb + 1 < n_cb;
+        if constexpr (SPEC) {
+            nc_static_for<FD>([&](auto d) __attribute__((always_inline)) {
+                if constexpr (decltype(d)::value < KP) load_frag(Ac, Xc, d);
+            });
+            nc_static_for<KP>([&](auto d) __attribute__((always_inline)) {
+                constexpr int kp = decltype(d)::value;
+                if constexpr (kp + FD < KP) load_frag(Ac, Xc, std::integral_constant<int, kp + FD>{});
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp % (FD + 1)][i], fb[kp % (FD + 1)][j], acc[i][j], 0, 0, 0);
+            });
+        } else
         nc_static_for<NSEG>([&](auto seg_tag) __attribute__((always_inline)) {
             constexpr int seg = decltype(seg_tag)::value;
             NC_TR();
@@ -396,7 +456,6 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
         NC_TR();
     }
     NC_TR();
-
     // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*hi][col = l31]
     // Element (row block ib, register r, column j) of this lane lives at tile_base + lane_off[j] + R(ib,r)*cstride with
     // R = 32*ib + (r&3) + 8*(r>>2) a compile-time row: one uniform 64-bit base, 32-bit lane offsets (the host bounds them).
@@ -682,9 +741,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv_mfma_kernel(const ConvArgs 
 
 typedef void (*conv_kernel_fn)(const ConvArgs);
 
-template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4>
+template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0>
 inline conv_kernel_fn get_conv_kernel() {
-    return &conv_mfma_kernel<TM, TN, K, CB, NX, FUSE, OCC, NW>;
+    return &conv_mfma_kernel<TM, TN, K, CB, NX, FUSE, OCC, NW, NP>;
 }
 
 }  // namespace nc
@@ -763,6 +822,18 @@ inline conv_kernel_fn get_conv_kernel() {
             case 2: return get_conv_kernel<2, 1, KVAL, CBVAL, NXVAL, false, 2, 3>();                       \
             case 3: return get_conv_kernel<3, 1, KVAL, CBVAL, NXVAL, false, 2, 3>();                       \
             case 4: return get_conv_kernel<4, 1, KVAL, CBVAL, NXVAL, false, 2, 3>();                       \
+        }                                                                                                  \
+        return nullptr;                                                                                    \
+    }                                                                                                      \
+    }
+
+// Wave-specialised variants: 4 consumer + 2 producer waves (384 threads), 3 waves per SIMD with two workgroups per CU.
+#define NC_INSTANTIATE_CONV_SPEC(KVAL, CBVAL, NXVAL)                                                       \
+    namespace nc {                                                                                         \
+    conv_kernel_fn conv_kernel_table_spec_k##KVAL(int TM, int TN) {                                        \
+        switch (TM * 10 + TN) {                                                                            \
+            case 22: return get_conv_kernel<2, 2, KVAL, CBVAL, NXVAL, false, 3, 4, 2>();                   \
+            case 32: return get_conv_kernel<3, 2, KVAL, CBVAL, NXVAL, false, 3, 4, 2>();                   \
         }                                                                                                  \
         return nullptr;                                                                                    \
     }                                                                                                      \
