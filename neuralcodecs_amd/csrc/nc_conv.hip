@@ -43,6 +43,7 @@ conv_kernel_fn conv_kernel_table_fused_k7(int, int);
 conv_kernel_fn conv_kernel_table_light_k7(int, int);
 conv_kernel_fn conv_kernel_table_wide_k7(int, int);
 conv_kernel_fn conv_kernel_table_spec_k7(int, int);
+conv_kernel_fn conv_kernel_table_dist_k7(int, int);
 conv_kernel_fn conv_kernel_table_narrow_k2(int);
 conv_kernel_fn conv_kernel_table_narrow_k3(int);
 conv_kernel_fn conv_kernel_table_narrow_k7(int);
@@ -379,6 +380,11 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
             nx = 20;
         }
     }
+    bool dist = false;
+    {
+        static const int dist_mode = std::getenv("NC_DIST") ? atoi(std::getenv("NC_DIST")) : 0;
+        if (dist_mode == 1 && !n_prod && !light && !narrow && !wide && !io.fuse_k1 && c.K == 7 && c.TN == 2 && c.TM >= 2) dist = true;
+    }
     const int NW = n_prod ? n_prod : c.NW;   // waves that stage the input window
     const int BM = c.BM(), BN = c.BN(), CB = c.CB, KB = c.KB();
     ConvArgs a{};
@@ -443,6 +449,9 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         a.alpha_out2 = io.alpha_out2;
         fn = conv_kernel_table_fused_k7(c.TM, c.TN);
         if (!fn) fail(NC_EUNSUPPORTED, "no fused residual-unit kernel for TM=%d TN=%d", c.TM, c.TN);
+    } else if (dist) {
+        fn = conv_kernel_table_dist_k7(c.TM, c.TN);
+        if (!fn) fail(NC_EUNSUPPORTED, "no distributed-staging conv kernel for TM=%d TN=%d", c.TM, c.TN);
     } else if (n_prod) {
         fn = conv_kernel_table_spec_k7(c.TM, c.TN);
         if (!fn) fail(NC_EUNSUPPORTED, "no specialised conv kernel for TM=%d TN=%d", c.TM, c.TN);

@@ -57,7 +57,13 @@ typedef __attribute__((address_space(3))) void* nc_lptr;
 // stage the next reduction block (global reads, Snake, LDS writes).  In the classic variant every wave alternates between the two
 // roles, and its vector-ALU staging run issues slowly while the co-resident wave saturates the matrix pipe -- time during which
 // its own matrix-core steps cannot issue.  With the roles split, the consumers always have matrix-core work ready.
-template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0>
+// DIST: distributed staging.  A wave issues in order, and a matrix-core instruction holds its wave until the pipe accepts it; the
+// few instructions that sit BETWEEN two matrix-core instructions issue in the shadow of the first (64 cycles), but a cluster of
+// staging instructions between two matrix-core streaks keeps the wave away from the pipe for its whole length.  So the reads of the
+// next reduction block are issued at the top of the step and its transform + LDS writes are dealt out over the step's matrix-core
+// steps, a unit (one weight vector or one window item) per step, in ONE basic block (no `if (more)`: the last step re-stages the
+// last block into the idle buffer).
+template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0, bool DIST = false>
 __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const ConvArgs p) {
     constexpr bool SPEC = NP > 0;
     constexpr int NT = 64 * (NW + NP);             // threads per workgroup
@@ -72,9 +78,9 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     constexpr int A_VEC = A_FLOATS / 4;            // float4 words in the weight tile
     constexpr int NA = (A_VEC + SNT - 1) / SNT;    // float4 copies per staging thread
 #ifdef NC_NSEG
-    constexpr int NSEG = SPEC ? 3 : (KP >= 16 ? NC_NSEG : 2);
+    constexpr int NSEG = SPEC ? 3 : DIST ? 2 : (KP >= 16 ? NC_NSEG : 2);
 #else
-    constexpr int NSEG = SPEC ? 3 : (KP >= 16 ? 4 : 2);   // (specialised: the producers stage a block in two groups)
+    constexpr int NSEG = SPEC ? 3 : DIST ? 2 : (KP >= 16 ? 4 : 2);   // (specialised: the producers stage a block in two groups)
 #endif
     constexpr int NG = NSEG - 1;
     constexpr int GA = (NA + NG - 1) / NG;         // per-group register footprint
@@ -389,6 +395,81 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
             return;
         }
     }
+    if constexpr (DIST) {
+        static_assert(!DIST || NG == 1, "distributed staging holds the whole next block in one register group");
+        // one staging unit: weight vector `un` (un < NA) or window item un - NA of block cbn
+        auto stage_unit = [&](int cbn, float* Ad, float* Xd, auto unit_tag, auto snake_tag) __attribute__((always_inline)) {
+            constexpr int un = decltype(unit_tag)::value;
+            constexpr bool SNAKE = decltype(snake_tag)::value;
+            if constexpr (un < NA) {
+                // (threads past the tile's end hold a copy of its last vector and rewrite it: branch-free)
+                const int idx = (A_VEC % SNT == 0) ? stid + SNT * un : min(stid + SNT * un, A_VEC - 1);
+                reinterpret_cast<f32x4*>(Ad)[idx] = ra[un];
+            } else {
+                constexpr int i = un - NA;
+                const int item = swave + SW * i;
+                const int c = xc[i];
+                const int j = (item - c * nchunk) * 64 + lane;
+                const int gp = xs0 + j;
+                const bool ok = (cbn * CB + c < Cin) & (gp >= 0) & (gp < x_len);
+                float v = ok ? rx[i] : 0.0f;
+                if constexpr (SNAKE) {
+                    const float2 al = Al[cbn * CB + c];
+                    v = nc_snakef(v, al.x, al.y);
+                }
+                int off = item * 64 + lane;
+                if (s != 1) {
+                    const int q = (j * stride_magic) >> 20;
+                    off = c * xrow + (j - q * s) * xwp + q;
+                }
+                Xd[off] = v;
+            }
+        };
+        auto run_loop = [&](auto snake_tag) __attribute__((always_inline)) {
+            constexpr int UN = NA + NX;                       // staging units per block
+            constexpr int KS0 = KP >= 12 ? KP / 3 : 0;        // the reads get the first third of the step to land
+            for (int cb = 0; cb < n_cb; ++cb) {
+                const int cur = cb & 1;
+                const float* Ac = As0 + cur * A_FLOATS + hi * BM + nc_a_lane_off<TM>(l31);
+                const int Xc = 2 * A_FLOATS + cur * xbuf;
+                float* const An = As0 + (cur ^ 1) * A_FLOATS;
+                float* const Xn = Xs0 + (cur ^ 1) * xbuf;
+                const int cbn = min(cb + 1, n_cb - 1);
+                issue_group(cbn, std::integral_constant<int, 0>{});
+                nc_static_for<FD>([&](auto d) __attribute__((always_inline)) {
+                    if constexpr (decltype(d)::value < KP) load_frag(Ac, Xc, d);
+                });
+                nc_static_for<KP>([&](auto d) __attribute__((always_inline)) {
+                    constexpr int kp = decltype(d)::value;
+                    if constexpr (kp + FD < KP) load_frag(Ac, Xc, std::integral_constant<int, kp + FD>{});
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp % (FD + 1)][i], fb[kp % (FD + 1)][j], acc[i][j], 0, 0, 0);
+                    constexpr int lo = kp < KS0 ? 0 : (kp - KS0) * UN / (KP - KS0), hi_u = kp < KS0 ? 0 : (kp - KS0 + 1) * UN / (KP - KS0);
+                    nc_static_for<hi_u - lo>([&](auto e) __attribute__((always_inline)) {
+                        stage_unit(cbn, An, Xn, std::integral_constant<int, lo + decltype(e)::value>{}, snake_tag);
+                    });
+                    // deal this step's staging instructions into the shadows of its matrix-core instructions
+#pragma unroll
+                    for (int m = 0; m < TM * TN; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);    // up to 8 VALU / SALU
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // an LDS write
+                    }
+                });
+                __syncthreads();
+            }
+        };
+#ifdef NC_ABL_NOSNAKE
+        run_loop(std::false_type{});
+#else
+        if (alpha_in != nullptr) run_loop(std::true_type{});
+        else run_loop(std::false_type{});
+#endif
+    } else
     for (int cb = 0; cb < n_cb; ++cb) {
         const int cur = cb & 1;
         const float* Ac = As0 + cur * A_FLOATS + hi * BM + nc_a_lane_off<TM>(l31);
@@ -741,9 +822,9 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
 
 typedef void (*conv_kernel_fn)(const ConvArgs);
 
-template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0>
+template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0, bool DIST = false>
 inline conv_kernel_fn get_conv_kernel() {
-    return &conv_mfma_kernel<TM, TN, K, CB, NX, FUSE, OCC, NW, NP>;
+    return &conv_mfma_kernel<TM, TN, K, CB, NX, FUSE, OCC, NW, NP, DIST>;
 }
 
 }  // namespace nc
@@ -834,6 +915,19 @@ inline conv_kernel_fn get_conv_kernel() {
         switch (TM * 10 + TN) {                                                                            \
             case 22: return get_conv_kernel<2, 2, KVAL, CBVAL, NXVAL, false, 3, 4, 2>();                   \
             case 32: return get_conv_kernel<3, 2, KVAL, CBVAL, NXVAL, false, 3, 4, 2>();                   \
+        }                                                                                                  \
+        return nullptr;                                                                                    \
+    }                                                                                                      \
+    }
+
+// Distributed-staging variants (see DIST above).
+#define NC_INSTANTIATE_CONV_DIST(KVAL, CBVAL, NXVAL)                                                       \
+    namespace nc {                                                                                         \
+    conv_kernel_fn conv_kernel_table_dist_k##KVAL(int TM, int TN) {                                        \
+        switch (TM * 10 + TN) {                                                                            \
+            case 22: return get_conv_kernel<2, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, true>();             \
+            case 32: return get_conv_kernel<3, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, true>();             \
+            case 42: return get_conv_kernel<4, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, true>();             \
         }                                                                                                  \
         return nullptr;                                                                                    \
     }                                                                                                      \
