@@ -267,7 +267,7 @@ static TileChoice choose_tile(const ConvLayer& L, int64_t blocks_per_rowtile, bo
 static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream, Profiler* prof) {
     static const bool off = std::getenv("NC_NO_CONV1X1") && std::getenv("NC_NO_CONV1X1")[0] == '1';
     const int64_t T = io.Tin;
-    if (off || L.transposed || L.K != 1 || L.stride != 1 || L.pad != 0 || L.cfg.CB != 16 || io.fuse_k1) return false;
+    if (off || L.transposed || L.K != 1 || L.stride != 1 || L.pad != 0 || L.cfg.CB != 16 || io.fuse_k1 || (L.Cin & 1)) return false;
     if (io.alpha_in || (io.epi & ~EPI_NOISE) || T < 2 || (T & 1) || io.x_len != T) return false;
     if (io.alpha_out && (io.epi & EPI_NOISE)) return false;
     if ((io.x_cstride & 1) || (io.x_bstride & 1) || (io.y_cstride & 1) || (io.y_bstride & 1)) return false;

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
     const unsigned x_cstride = (unsigned)p.x_cstride;
     const int col = t_tile * BN + wave * BNW + TN * l31;          // first of this lane's TN columns
     const int colc = min(col, T - TN);                             // clamped (T % TN == 0, T >= TN): loads stay inside the row
-    const float* const xb = p.x + (int64_t)b * p.x_bstride + colc;
+    const float* const xb = p.x + (int64_t)b * p.x_bstride;       // uniform; the lane part is a 32-bit offset
+    const unsigned x_lane_off = (unsigned)hi * x_cstride + (unsigned)colc;
     const f32x4* const wbase = reinterpret_cast<const f32x4*>(p.w + (int64_t)co_tile * n_cb * A_FLOATS);
 
     f32x16 acc[TM][TN];
@@ -98,11 +99,13 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
 
     // B ring: step g (global MFMA step index) uses channel ci = 2g + hi
     f32x2 bq[PF];
+    // step g reads channel rows 2g (lanes 0-31) and 2g+1 (lanes 32-63): a uniform row pointer (scalar arithmetic, clamped to the
+    // last channel pair -- rows past Cin meet zero weights) plus the lane offset, i.e. no vector address arithmetic per step
+    const int last_pair = Cin / 2 - 1;                            // (the launcher admits even Cin only)
     auto load_b = [&](int g) __attribute__((always_inline)) {
-        const int ci = min(2 * g + hi, Cin - 1);                  // channels past Cin meet zero weights
-        return *reinterpret_cast<const f32x2*>(xb + (unsigned)ci * x_cstride);
+        const float* row = xb + (size_t)(2 * min(g, last_pair)) * x_cstride;
+        return *reinterpret_cast<const f32x2*>(row + x_lane_off);
     };
-    const int n_steps = n_cb * KP;
 #pragma unroll
     for (int u = 0; u < PF; ++u) bq[u] = load_b(u);
 
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
             nc_load_a_frag<TM>(Ac + 2 * kp * BM, l31, a);
             const f32x2 bv = bq[kp % PF];
             const int g = cb * KP + kp + PF;
-            if (g < n_steps) bq[kp % PF] = load_b(g);
+            bq[kp % PF] = load_b(g);   // unconditional (clamped): the step is one basic block
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[0], acc[i][0], 0, 0, 0);
