@@ -212,7 +212,10 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(const float* __rest
     const float* wp = whhp + (int64_t)ub * KS * 64 + lane;
     const int k4 = lane >> 4, cl = lane & 15;
     const int j = ub * 4 + k4;                                 // this lane's hidden unit in the D fragment
-    for (int c0 = 0; c0 < B; c0 += 16) {
+    // blockIdx.y = 16-clip column tile: the tiles are independent 512-long chains, so they run side by side on different CUs
+    // instead of back to back inside one wave (the step is bound by the dependent matrix-core chain of a tile)
+    {
+        const int c0 = blockIdx.y * 16;
         const int bcol = min(c0 + cl, B - 1);
         const float* hp = hprev + (int64_t)k4 * B + bcol;
         const int64_t hs = (int64_t)4 * B;
@@ -705,10 +708,10 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
         static const bool scalar_lstm = std::getenv("NC_LSTM_SCALAR") && std::getenv("NC_LSTM_SCALAR")[0] == '1';
         for (int64_t t = 0; t < T; ++t) {
             if (C % 64 == 0 && !scalar_lstm)
-                hipLaunchKernelGGL(lstm_step_mfma_kernel<16>, dim3((unsigned)((C / 4 + 3) / 4)), dim3(256), 0, stream, gi, y.whhp.as<float>(),
+                hipLaunchKernelGGL(lstm_step_mfma_kernel<16>, dim3((unsigned)((C / 4 + 3) / 4), (unsigned)((N + 15) / 16)), dim3(256), 0, stream, gi, y.whhp.as<float>(),
                                    y.bhh.as<float>(), (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, cs, last ? x : nullptr, out, N, C, T, t);
             else if (C % 16 == 0 && !scalar_lstm)
-                hipLaunchKernelGGL(lstm_step_mfma_kernel<4>, dim3((unsigned)((C / 4 + 3) / 4)), dim3(256), 0, stream, gi, y.whhp.as<float>(),
+                hipLaunchKernelGGL(lstm_step_mfma_kernel<4>, dim3((unsigned)((C / 4 + 3) / 4), (unsigned)((N + 15) / 16)), dim3(256), 0, stream, gi, y.whhp.as<float>(),
                                    y.bhh.as<float>(), (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, cs, last ? x : nullptr, out, N, C, T, t);
             else
                 hipLaunchKernelGGL(lstm_step_kernel, dim3((unsigned)C, (unsigned)((N + 63) / 64)), dim3(64), (size_t)4 * C * sizeof(float), stream,
