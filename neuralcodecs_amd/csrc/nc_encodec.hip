@@ -254,6 +254,61 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(const float* __rest
     }
 }
 
+// LSTM step with the whole reduction in flight at once.  The step is latency-bound: a wave's 512-long chain is 128 dependent
+// matrix-core instructions (~2 us) and the chunked version above pays an L2 round trip per 16-step chunk on top.  Here the wave's
+// 32 KB weight slice goes global -> LDS by DMA (global_load_lds, 16 bytes per lane, no registers) and its 128 h operands into
+// registers, all issued back to back: one memory round trip, then the chain runs from LDS/registers.  C == 4*KS.
+typedef __attribute__((address_space(1))) const void* lstm_gptr;
+typedef __attribute__((address_space(3))) void* lstm_lptr;
+template <int KS>
+__global__ __launch_bounds__(256) void lstm_step_lds_kernel(const float* __restrict__ gi, const float* __restrict__ whhp,
+                                                            const float* __restrict__ bhh, const float* __restrict__ hprev,
+                                                            float* __restrict__ hnext, float* __restrict__ cst, const float* __restrict__ skip,
+                                                            float* __restrict__ out, int B, int C, int64_t T, int64_t t) {
+    extern __shared__ __attribute__((aligned(16))) float lstm_lds[];   // [4 waves][KS][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ub = blockIdx.x * 4 + wave;
+    if (ub * 4 >= C) return;
+    float* Aw = lstm_lds + wave * KS * 64;
+    const float* wsrc = whhp + (int64_t)ub * KS * 64;
+#pragma unroll
+    for (int i = 0; i < KS / 4; ++i)
+        __builtin_amdgcn_global_load_lds((lstm_gptr)(wsrc + i * 256 + lane * 4), (lstm_lptr)(Aw + i * 256), 16, 0, 0);
+    const int k4 = lane >> 4, cl = lane & 15;
+    const int j = ub * 4 + k4;
+    const int c0 = blockIdx.y * 16;
+    const int bcol = min(c0 + cl, B - 1);
+    const float* hp = hprev + (int64_t)k4 * B + bcol;
+    const int64_t hs = (int64_t)4 * B;
+    float hb[KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) hb[i] = hp[(int64_t)i * hs];
+    // gate pre-activations of the input projection: issued with the rest, used after the chain
+    const int b = c0 + cl;
+    const int bb = min(b, B - 1);
+    const float* g = gi + ((int64_t)bb * 4 * C) * T + t;
+    const float g0 = g[(int64_t)j * T], g1 = g[(int64_t)(C + j) * T], g2 = g[(int64_t)(2 * C + j) * T], g3 = g[(int64_t)(3 * C + j) * T];
+    const float cprev = cst[(int64_t)j * B + bb];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA writes and the register reads have landed
+    f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < KS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[i * 64 + lane], hb[i], acc, 0, 0, 0);
+    if (b < B) {
+        const float pi = g0 + (acc[0] + bhh[j]);
+        const float pf = g1 + (acc[1] + bhh[C + j]);
+        const float pg = g2 + (acc[2] + bhh[2 * C + j]);
+        const float po = g3 + (acc[3] + bhh[3 * C + j]);
+        const float ig = nc_sigmoidf(pi), fg = nc_sigmoidf(pf), gg = nc_tanhf(pg), og = nc_sigmoidf(po);
+        const float cn = (fg * cprev) + (ig * gg);
+        cst[(int64_t)j * B + b] = cn;
+        const float h = og * nc_tanhf(cn);
+        hnext[(int64_t)j * B + b] = h;
+        const int64_t o = ((int64_t)b * C + j) * T + t;
+        out[o] = skip ? h + skip[o] : h;
+    }
+}
+
 // Euclidean codebook search, D <= 128 (EuclideanCodebook.cs:155-182): per frame dist_n = (|x|^2 + |e_n|^2) - 2*(x.e_n) with fma
 // chains over d ascending, argmin with lowest-index ties; then residual -= embed[idx] (ResidualVectorQuantizer.cs:150-152).
 // Block = EQ_F frames x 256 threads; thread n scans codes n, n+256, ...; codebook transposed [D][N] streams from L2.
@@ -707,7 +762,16 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
         if (prof.on) prof.begin(stream, NC_KC_ELEM, 2.0 * 4 * C * C * (double)N * T, 0.0);
         static const bool scalar_lstm = std::getenv("NC_LSTM_SCALAR") && std::getenv("NC_LSTM_SCALAR")[0] == '1';
         for (int64_t t = 0; t < T; ++t) {
-            if (C % 64 == 0 && !scalar_lstm)
+            static const bool no_lds_lstm = std::getenv("NC_LSTM_CHUNKED") && std::getenv("NC_LSTM_CHUNKED")[0] == '1';
+            if (C == 512 && !scalar_lstm && !no_lds_lstm) {
+                static bool attr_done = false;
+                if (!attr_done) {
+                    NC_HIP(hipFuncSetAttribute((const void*)lstm_step_lds_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 64 * 4));
+                    attr_done = true;
+                }
+                hipLaunchKernelGGL(lstm_step_lds_kernel<128>, dim3((unsigned)((C / 4 + 3) / 4), (unsigned)((N + 15) / 16)), dim3(256), 4 * 128 * 64 * 4, stream, gi,
+                                   y.whhp.as<float>(), y.bhh.as<float>(), (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, cs, last ? x : nullptr, out, N, C, T, t);
+            } else if (C % 64 == 0 && !scalar_lstm)
                 hipLaunchKernelGGL(lstm_step_mfma_kernel<16>, dim3((unsigned)((C / 4 + 3) / 4), (unsigned)((N + 15) / 16)), dim3(256), 0, stream, gi, y.whhp.as<float>(),
                                    y.bhh.as<float>(), (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, cs, last ? x : nullptr, out, N, C, T, t);
             else if (C % 16 == 0 && !scalar_lstm)
