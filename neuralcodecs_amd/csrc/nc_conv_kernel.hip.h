@@ -13,6 +13,15 @@ namespace nc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifdef NC_A_DMA
+// 16 bytes per lane global -> LDS by DMA (no registers, no LDS store instruction): lane l copies gbase[voff(l)] to lds_addr + 16*l.
+// Issued through inline assembly so that the compiler's wait-count insertion does not treat every later LDS read as dependent on it;
+// the kernel waits for vmcnt(0) itself before the barrier that publishes the buffer.
+__device__ __forceinline__ void nc_dma16(const void* gbase, unsigned voff_bytes, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff_bytes), "s"(gbase) : "memory");
+}
+#endif
+
 template <int N, class F, int... I>
 __device__ __forceinline__ void nc_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -77,6 +86,11 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     constexpr int A_FLOATS = KB * BM;
     constexpr int A_VEC = A_FLOATS / 4;            // float4 words in the weight tile
     constexpr int NA = (A_VEC + SNT - 1) / SNT;    // float4 copies per staging thread
+#ifdef NC_A_DMA
+    constexpr bool A_DMA = A_VEC % 64 == 0;        // weight tile = whole wave-sized DMA rows: global -> LDS without registers
+#else
+    constexpr bool A_DMA = false;
+#endif
 #ifdef NC_NSEG
     constexpr int NSEG = SPEC ? 3 : DIST ? 2 : (KP >= 16 ? NC_NSEG : 2);
 #else
@@ -193,18 +207,9 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     auto issue_group_to = [&](int cbn, auto gtag, f32x4 (&ra)[GA], float (&rx)[GX]) __attribute__((always_inline)) {
         constexpr int g = decltype(gtag)::value;
         const f32x4* src = wbase + (size_t)cbn * A_VEC;
-        nc_static_for<GA>([&](auto ut) __attribute__((always_inline)) {
-            constexpr int u = decltype(ut)::value, n = g * GA + u;
-            if constexpr (n < NA) {
-#ifdef NC_ABL_NOLOADA
-                ra[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-#else
-                // uniform pointer (scalar arithmetic) + the thread index: no per-read vector address arithmetic
-                const f32x4* srcn = src + SNT * n;
-                ra[u] = srcn[(A_VEC % SNT == 0) ? (unsigned)stid : min((unsigned)stid, (unsigned)(A_VEC - 1 - SNT * n))];
+#ifdef NC_A_DMA
+        // window reads first: the DMA rows go out behind them, so a wait the compiler places for its own reads never covers a DMA
 #endif
-            }
-        });
         nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value, i = g * GX + u;
             if constexpr (i < NX) {
@@ -214,6 +219,31 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 rx[u] = (float)xg[i];
 #else
                 rx[u] = row[xg[i]];
+#endif
+            }
+        });
+        nc_static_for<GA>([&](auto ut) __attribute__((always_inline)) {
+            constexpr int u = decltype(ut)::value, n = g * GA + u;
+            if constexpr (n < NA) {
+#ifdef NC_ABL_NOLOADA
+                ra[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#elif defined(NC_A_DMA)
+                // weight vectors SNT*n + 64*swave .. +63 of block cbn straight into its LDS buffer (cbn & 1); whole waves only
+                if constexpr (A_DMA) {
+                    const int idx0 = SNT * n + 64 * swave;
+                    if (idx0 < A_VEC) {
+                        typedef __attribute__((address_space(3))) float* lds_fp;
+                        const unsigned lds0 = (unsigned)(uintptr_t)(lds_fp)(As0 + ((cbn & 1) ? A_FLOATS : 0));
+                        nc_dma16(src + idx0, (unsigned)lane * 16u, lds0 + (unsigned)idx0 * 16u);
+                    }
+                } else {
+                    const f32x4* srcn = src + SNT * n;
+                    ra[u] = srcn[(A_VEC % SNT == 0) ? (unsigned)stid : min((unsigned)stid, (unsigned)(A_VEC - 1 - SNT * n))];
+                }
+#else
+                // uniform pointer (scalar arithmetic) + the thread index: no per-read vector address arithmetic
+                const f32x4* srcn = src + SNT * n;
+                ra[u] = srcn[(A_VEC % SNT == 0) ? (unsigned)stid : min((unsigned)stid, (unsigned)(A_VEC - 1 - SNT * n))];
 #endif
             }
         });
@@ -227,8 +257,9 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
             constexpr int u = decltype(ut)::value, n = g * GA + u;
             if constexpr (n < NA) {
                 const int idx = stid + SNT * n;
-#ifndef NC_ABL_NOSTOREA
-                if ((A_VEC % SNT == 0) || idx < A_VEC) reinterpret_cast<f32x4*>(Ad)[idx] = ra[u];
+#if !defined(NC_ABL_NOSTOREA)
+                if constexpr (!A_DMA)
+                    if ((A_VEC % SNT == 0) || idx < A_VEC) reinterpret_cast<f32x4*>(Ad)[idx] = ra[u];
 #endif
             }
         });
@@ -333,6 +364,9 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 else store_group_from(0, As0, Xs0, g, std::false_type{}, ra0[gi], rx0[gi]);
             });
     }
+#ifdef NC_A_DMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __syncthreads();
 
     const int x_lane = wave * BNW + l31;
@@ -531,6 +565,9 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
 #endif
         });
         NC_TR();
+#ifdef NC_A_DMA
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA rows of the next block have landed
+#endif
 #if !defined(NC_ABL_NOBAR)
         __syncthreads();
 #endif
