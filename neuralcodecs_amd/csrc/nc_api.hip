@@ -119,14 +119,14 @@ nc_status nc_codec_load_weights(nc_codec* h, const char* path) {
 nc_status nc_codec_set_stream(nc_codec* h, void* hip_stream) {
     return guard([&] {
         if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");
-        h->impl->stream = static_cast<hipStream_t>(hip_stream);
+        h->impl->switch_stream(static_cast<hipStream_t>(hip_stream));
     });
 }
 
 nc_status nc_codec_reset_stream(nc_codec* h) {
     return guard([&] {
         if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");
-        h->impl->stream = h->impl->own_stream;
+        h->impl->switch_stream(h->impl->own_stream);
     });
 }
 
@@ -167,6 +167,7 @@ nc_status nc_dac_encode(nc_codec* h, const float* pcm, int32_t B, int64_t T, int
         if (!pcm || !codes) fail(NC_EINVAL, "pcm and codes must not be null");
         if (B <= 0 || T <= 0) fail(NC_EINVAL, "B and T must be positive");
         m.use_device();
+        OwnStreamScope own(m);
         const int nq = (n_q <= 0 || n_q > m.cfg.n_codebooks) ? m.cfg.n_codebooks : n_q;
         const int64_t Tz = m.frames(T);
         const size_t n_in = (size_t)B * T * 4, n_codes = (size_t)B * nq * Tz * 8, n_z = (size_t)B * m.latent * Tz * 4,
@@ -187,6 +188,7 @@ nc_status nc_dac_decode(nc_codec* h, const float* z, int32_t B, int64_t frames, 
         if (!z || !pcm) fail(NC_EINVAL, "z and pcm must not be null");
         if (B <= 0 || frames <= 0) fail(NC_EINVAL, "B and frames must be positive");
         m.use_device();
+        OwnStreamScope own(m);
         const size_t n_z = (size_t)B * m.latent * frames * 4, n_out = (size_t)B * m.decoded_len(frames) * 4;
         m.h_aux0.reserve(n_z); m.h_out.reserve(n_out);
         h2d(m.h_aux0.p, z, n_z, m.stream);
@@ -202,6 +204,7 @@ nc_status nc_dac_from_codes(nc_codec* h, const int64_t* codes, int32_t B, int32_
         if (!codes || !z) fail(NC_EINVAL, "codes and z must not be null");
         if (B <= 0 || frames <= 0 || n_q <= 0) fail(NC_EINVAL, "bad codes shape");
         m.use_device();
+        OwnStreamScope own(m);
         const size_t n_codes = (size_t)B * n_q * frames * 8, n_z = (size_t)B * m.latent * frames * 4;
         m.h_codes.reserve(n_codes); m.h_aux0.reserve(n_z);
         h2d(m.h_codes.p, codes, n_codes, m.stream);
@@ -265,6 +268,7 @@ nc_status nc_snac_encode(nc_codec* h, const float* pcm, int32_t B, int64_t T, in
         if (!pcm || !codes) fail(NC_EINVAL, "pcm and codes must not be null");
         if (B <= 0 || T <= 0) fail(NC_EINVAL, "B and T must be positive");
         m.use_device();
+        OwnStreamScope own(m);
         const int64_t Tz = m.padded_len(T) / m.hop;
         const size_t n_in = (size_t)B * T * 4, n_codes = (size_t)B * m.codes_per_clip(Tz) * 8, n_z = (size_t)B * m.latent * Tz * 4;
         m.h_in.reserve(n_in); m.h_codes.reserve(n_codes); m.h_aux0.reserve(n_z); m.h_aux1.reserve(n_z);
@@ -283,6 +287,7 @@ nc_status nc_snac_from_codes(nc_codec* h, const int64_t* codes, int32_t B, int64
         if (!codes || !zq) fail(NC_EINVAL, "codes and zq must not be null");
         if (B <= 0 || frames <= 0) fail(NC_EINVAL, "B and frames must be positive");
         m.use_device();
+        OwnStreamScope own(m);
         const size_t n_codes = (size_t)B * m.codes_per_clip(frames) * 8, n_z = (size_t)B * m.latent * frames * 4;
         m.h_codes.reserve(n_codes); m.h_aux0.reserve(n_z);
         h2d(m.h_codes.p, codes, n_codes, m.stream);
@@ -299,6 +304,7 @@ nc_status nc_snac_decode(nc_codec* h, const int64_t* codes, int32_t B, int64_t f
         if (!codes || !pcm) fail(NC_EINVAL, "codes and pcm must not be null");   // ArgumentNullException, SNAC.cs:175
         if (B <= 0 || frames <= 0) fail(NC_EINVAL, "Codes list cannot be empty");   // ArgumentException, SNAC.cs:177-180
         m.use_device();
+        OwnStreamScope own(m);
         const size_t n_codes = (size_t)B * m.codes_per_clip(frames) * 8, n_out = (size_t)B * m.decoded_len(frames) * 4;
         const size_t n_noise = (size_t)m.noise_len(B, frames) * 4;
         m.h_codes.reserve(n_codes); m.h_out.reserve(n_out);
@@ -363,6 +369,7 @@ nc_status nc_encodec_encode(nc_codec* h, const float* pcm, int32_t B, int64_t T,
         if (!pcm || !codes) fail(NC_EINVAL, "pcm and codes must not be null");                  // ArgumentNullException, Encodec.cs:245
         if (B <= 0 || T <= 0) fail(NC_EINVAL, "B and T must be positive");
         m.use_device();
+        OwnStreamScope own(m);
         const auto segs = m.segments(T);
         int64_t fr = 0;
         for (auto& s : segs) fr += s.frames;
@@ -385,6 +392,7 @@ nc_status nc_encodec_decode(nc_codec* h, const int64_t* codes, const float* scal
         if (B <= 0 || T <= 0 || n_q <= 0) fail(NC_EINVAL, "No frames provided to decode");
         if (m.cfg.normalize && !scales) fail(NC_EINVAL, "this model normalises frames: scales must be given");
         m.use_device();
+        OwnStreamScope own(m);
         const auto segs = m.segments(T);
         int64_t fr = 0;
         for (auto& s : segs) fr += s.frames;

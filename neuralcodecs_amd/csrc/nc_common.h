@@ -39,11 +39,24 @@ struct Error : std::runtime_error {
 
 void set_last_error(const char* msg);
 
+// Opt a kernel into > 64 KB of dynamic LDS on the CURRENT device.  The attribute is per (device, function): the cache is keyed on
+// both and guarded, so models on different GPUs (and host threads calling in concurrently) each get their opt-in.
+void ensure_dynamic_lds(const void* fn, size_t bytes);
+
 // Grow-only device arena: activations for the largest (B,T) seen so far stay resident
 // (288 GB of HBM per GPU: nothing is ever freed or re-allocated inside a timed region).
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }   // a model's packed weights, codebooks and workspaces go back to the device with the handle (Dispose)
     void reserve(size_t bytes) {
         if (bytes <= cap) return;
         if (p) NC_HIP(hipFree(p));

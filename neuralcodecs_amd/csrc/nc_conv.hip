@@ -40,10 +40,21 @@ int conv_kernel_nx_k16();
 #define NC_K_CASES(X) X(1) X(2) X(3) X(4) X(6) X(7) X(8) X(10) X(16)
 
 conv_kernel_fn conv_kernel_table_fused_k7(int, int);
+// Measured-and-rejected k=7 variants (light / wide / wave-specialised / distributed staging): built only with
+// `make EXPERIMENTS=1` (-DNC_EXPERIMENTS); the default library carries neither their code objects nor their switches.
+#ifdef NC_EXPERIMENTS
 conv_kernel_fn conv_kernel_table_light_k7(int, int);
 conv_kernel_fn conv_kernel_table_wide_k7(int, int);
 conv_kernel_fn conv_kernel_table_spec_k7(int, int);
 conv_kernel_fn conv_kernel_table_dist_k7(int, int);
+static int experiment_mode(const char* name) { const char* v = std::getenv(name); return v ? atoi(v) : 0; }
+#else
+static conv_kernel_fn conv_kernel_table_light_k7(int, int) { return nullptr; }
+static conv_kernel_fn conv_kernel_table_wide_k7(int, int) { return nullptr; }
+static conv_kernel_fn conv_kernel_table_spec_k7(int, int) { return nullptr; }
+static conv_kernel_fn conv_kernel_table_dist_k7(int, int) { return nullptr; }
+static int experiment_mode(const char*) { return 0; }
+#endif
 conv_kernel_fn conv_kernel_table_narrow_k2(int);
 conv_kernel_fn conv_kernel_table_narrow_k3(int);
 conv_kernel_fn conv_kernel_table_narrow_k7(int);
@@ -224,8 +235,6 @@ bool can_fuse_res_unit(const ConvLayer& k7, const ConvLayer& k1) {
            k7.has_bias && k1.has_bias;
 }
 
-static std::mutex g_attr_mu;
-static std::set<const void*> g_attr_done;
 
 // Which packed row-tile height to launch: estimated time = rounds * (blocks per CU) * TM * penalty(TM), with
 // rounds = ceil(blocks / (256 CUs * blocks per CU)).  Smaller tiles waste a little more LDS/issue bandwidth per MFMA (penalty) but
@@ -355,7 +364,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     int nx = nx_for_k(c.K);
     bool light = false;
     {
-        static const int light_mode = std::getenv("NC_LIGHT") ? atoi(std::getenv("NC_LIGHT")) : 0;
+        static const int light_mode = experiment_mode("NC_LIGHT");
         if (light_mode == 1 && !narrow && !io.fuse_k1 && c.K == 7 && c.CB == 8 && L.Cin % 8 == 0 && c.TN == 2 && (c.TM == 2 || c.TM == 3)) {
             light = true;
             c.CB = 4;
@@ -364,7 +373,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     }
     bool wide = false;
     {
-        static const int wide_mode = std::getenv("NC_WIDE") ? atoi(std::getenv("NC_WIDE")) : 0;
+        static const int wide_mode = experiment_mode("NC_WIDE");
         if (wide_mode == 1 && !light && !narrow && !io.fuse_k1 && c.K == 7 && c.TN == 2 && c.TM >= 2 && n_cols_all >= 2048) {
             wide = true;
             c.NW = 8;
@@ -374,7 +383,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     // wave-specialised variant (4 consumer + 2 producer waves): k=7, 64/96-row tiles, long rows
     int n_prod = 0;
     {
-        static const int spec_mode = std::getenv("NC_SPEC") ? atoi(std::getenv("NC_SPEC")) : 0;
+        static const int spec_mode = experiment_mode("NC_SPEC");
         if (spec_mode == 1 && !light && !narrow && !wide && !io.fuse_k1 && c.K == 7 && c.TN == 2 && (c.TM == 2 || c.TM == 3)) {
             n_prod = 2;
             nx = 20;
@@ -382,7 +391,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     }
     bool dist = false;
     {
-        static const int dist_mode = std::getenv("NC_DIST") ? atoi(std::getenv("NC_DIST")) : 0;
+        static const int dist_mode = experiment_mode("NC_DIST");
         if (dist_mode == 1 && !n_prod && !light && !narrow && !wide && !io.fuse_k1 && c.K == 7 && c.TN == 2 && c.TM >= 2) dist = true;
     }
     const int NW = n_prod ? n_prod : c.NW;   // waves that stage the input window
@@ -467,13 +476,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         fn = lookup_kernel(c);
     }
     if (lds > 160 * 1024) fail(NC_EUNSUPPORTED, "conv tile needs %zu B of LDS", lds);
-    {
-        std::lock_guard<std::mutex> g(g_attr_mu);
-        if (!g_attr_done.count((const void*)fn)) {
-            NC_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            g_attr_done.insert((const void*)fn);
-        }
-    }
+    ensure_dynamic_lds((const void*)fn, 160 * 1024);
     const int64_t grid = (int64_t)a.n_phase * a.n_co_tiles * B * a.n_t_tiles;
     if (grid <= 0) return;
     if (prof && prof->on) {

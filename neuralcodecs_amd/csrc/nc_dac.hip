@@ -34,6 +34,18 @@ void Codec::init_device(int device_index) {
 
 void Codec::use_device() const { NC_HIP(hipSetDevice(device)); }
 
+void Codec::switch_stream(hipStream_t s) {
+    if (s == stream) return;
+    use_device();
+    hipEvent_t e;
+    NC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipError_t r = hipEventRecord(e, stream);
+    if (r == hipSuccess) r = hipStreamWaitEvent(s, e, 0);
+    (void)hipEventDestroy(e);   // destruction is deferred by the runtime until the recorded work completes
+    if (r != hipSuccess) fail(NC_EDEVICE, "stream hand-over failed: %s", hipGetErrorString(r));
+    stream = s;
+}
+
 static void upload(DevBuf& d, const float* h, size_t n) {
     d.reserve(n * sizeof(float));
     NC_HIP(hipMemcpy(d.p, h, n * sizeof(float), hipMemcpyHostToDevice));

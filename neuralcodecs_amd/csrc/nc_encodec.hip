@@ -427,20 +427,20 @@ __global__ void emb_sum_kernel(const int64_t* __restrict__ codes, const float* c
 }
 
 // DSP.LinearOverlapAdd (AudioTensorDSP.cs:161-261): out[r,i] = (sum_f frame_f[r, i - f*stride] * w[i - f*stride]) / sw[i]
-struct OlaFrames {
-    const float* p[16];
-    int64_t len[16];
-    int n;
-};
-__global__ void overlap_add_kernel(OlaFrames fr, const float* __restrict__ w, const float* __restrict__ sw, int64_t rows, int64_t stride,
-                                   int64_t total, float* __restrict__ out) {
+// Frame pointers / lengths come from device arrays (any number of segments); only the frames that can cover sample t are visited,
+// in ascending order -- the same additions the all-frames loop performs.
+__global__ void overlap_add_kernel(const float* const* __restrict__ fp, const int64_t* __restrict__ flen, int nfr, int64_t L0,
+                                   const float* __restrict__ w, const float* __restrict__ sw, int64_t rows, int64_t stride, int64_t total,
+                                   float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * total) return;
     const int64_t r = i / total, t = i - r * total;
+    const int64_t f_lo = t >= L0 ? (t - L0) / stride + 1 : 0;
+    const int64_t f_hi = min((int64_t)nfr - 1, t / stride);
     float a = 0.0f;
-    for (int f = 0; f < fr.n; ++f) {
-        const int64_t q = t - (int64_t)f * stride;
-        if (q >= 0 && q < fr.len[f]) a = a + fr.p[f][r * fr.len[f] + q] * w[q];
+    for (int64_t f = f_lo; f <= f_hi; ++f) {
+        const int64_t q = t - f * stride, len = flen[f];
+        if (q >= 0 && q < len) a = a + fp[f][r * len + q] * w[q];
     }
     out[i] = a / sw[t];
 }
@@ -764,11 +764,7 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
         for (int64_t t = 0; t < T; ++t) {
             static const bool no_lds_lstm = std::getenv("NC_LSTM_CHUNKED") && std::getenv("NC_LSTM_CHUNKED")[0] == '1';
             if (C == 512 && !scalar_lstm && !no_lds_lstm) {
-                static bool attr_done = false;
-                if (!attr_done) {
-                    NC_HIP(hipFuncSetAttribute((const void*)lstm_step_lds_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 64 * 4));
-                    attr_done = true;
-                }
+                ensure_dynamic_lds((const void*)lstm_step_lds_kernel<128>, 4 * 128 * 64 * 4);
                 hipLaunchKernelGGL(lstm_step_lds_kernel<128>, dim3((unsigned)((C / 4 + 3) / 4), (unsigned)((N + 15) / 16)), dim3(256), 4 * 128 * 64 * 4, stream, gi,
                                    y.whhp.as<float>(), y.bhh.as<float>(), (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, cs, last ? x : nullptr, out, N, C, T, t);
             } else if (C % 64 == 0 && !scalar_lstm)
@@ -883,42 +879,47 @@ void EncodecModel::decode_dev(const int64_t* codes, const float* scales, int B, 
     use_device();
     pool_i = 0;
     const std::vector<Seg> segs = segments(T);
-    if (segs.size() > 16) fail(NC_EUNSUPPORTED, "more than 16 segments per call");
     const int C = cfg.channels;
-    OlaFrames fr{};
-    fr.n = (int)segs.size();
+    const int nfr = (int)segs.size();
+    std::vector<const float*> fp((size_t)nfr);
+    std::vector<int64_t> flen((size_t)nfr);
     int64_t code_off = 0;
     for (size_t f = 0; f < segs.size(); ++f) {
         int64_t Lo = 0;
-        fr.p[f] = decode_batch(codes + code_off, B, nq, segs[f].frames, cfg.normalize ? scales + (int64_t)f * B : nullptr, &Lo);
-        fr.len[f] = Lo;
+        fp[f] = decode_batch(codes + code_off, B, nq, segs[f].frames, cfg.normalize ? scales + (int64_t)f * B : nullptr, &Lo);
+        flen[f] = Lo;
         code_off += (int64_t)B * nq * segs[f].frames;
     }
     if (cfg.segment_length <= 0) {                                                           // single frame: DecodeFrame output as is
-        NC_HIP(hipMemcpyAsync(pcm, fr.p[0], (size_t)B * C * fr.len[0] * 4, hipMemcpyDeviceToDevice, stream));
+        NC_HIP(hipMemcpyAsync(pcm, fp[0], (size_t)B * C * flen[0] * 4, hipMemcpyDeviceToDevice, stream));
         return;
     }
     // triangular window + weight sum on the host (geometry only), AudioTensorDSP.cs:176-252
-    const int64_t stride = cfg.segment_stride, total = stride * (fr.n - 1) + fr.len[fr.n - 1], L0 = fr.len[0];
-    for (int f = 0; f < fr.n; ++f)
-        if (fr.len[f] > L0) fail(NC_EINVAL, "a later frame is longer than the first one");
+    const int64_t stride = cfg.segment_stride, total = stride * (nfr - 1) + flen[(size_t)nfr - 1], L0 = flen[0];
+    for (int f = 0; f < nfr; ++f)
+        if (flen[(size_t)f] > L0) fail(NC_EINVAL, "a later frame is longer than the first one");
     std::vector<float> w((size_t)L0), sw((size_t)total, 0.0f);
     for (int64_t i = 0; i < L0; ++i) {
         const float t = (float)((double)(i + 1) / (double)(L0 + 1));
         w[(size_t)i] = 0.5f - std::fabs(t - 0.5f);
     }
-    for (int f = 0; f < fr.n; ++f)
-        for (int64_t i = 0; i < fr.len[f]; ++i) sw[(size_t)(f * stride + i)] = sw[(size_t)(f * stride + i)] + w[(size_t)i];
+    for (int f = 0; f < nfr; ++f)
+        for (int64_t i = 0; i < flen[(size_t)f]; ++i) sw[(size_t)(f * stride + i)] = sw[(size_t)(f * stride + i)] + w[(size_t)i];
     float mn = INFINITY;
     for (float v : sw) mn = std::min(mn, v);
     if (mn <= 1e-10f) for (float& v : sw) v = v + 1e-10f;
     float* dw = alloc((size_t)L0);
     float* dsw = alloc((size_t)total);
+    const float** dfp = reinterpret_cast<const float**>(alloc((size_t)nfr * 2));
+    int64_t* dfl = reinterpret_cast<int64_t*>(alloc((size_t)nfr * 2));
     NC_HIP(hipMemcpyAsync(dw, w.data(), (size_t)L0 * 4, hipMemcpyHostToDevice, stream));
     NC_HIP(hipMemcpyAsync(dsw, sw.data(), (size_t)total * 4, hipMemcpyHostToDevice, stream));
-    NC_HIP(hipStreamSynchronize(stream));   // w / sw are stack-owned host vectors
+    NC_HIP(hipMemcpyAsync(dfp, fp.data(), (size_t)nfr * sizeof(float*), hipMemcpyHostToDevice, stream));
+    NC_HIP(hipMemcpyAsync(dfl, flen.data(), (size_t)nfr * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    NC_HIP(hipStreamSynchronize(stream));   // w / sw / fp / flen are stack-owned host vectors
     const int64_t n = (int64_t)B * C * total;
-    hipLaunchKernelGGL(overlap_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, fr, dw, dsw, (int64_t)B * C, stride, total, pcm);
+    hipLaunchKernelGGL(overlap_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dfp, dfl, nfr, L0, dw, dsw, (int64_t)B * C, stride,
+                       total, pcm);
     NC_HIP(hipGetLastError());
 }
 

@@ -39,6 +39,19 @@ struct Codec {
     virtual void load(const Blob& blob) = 0;
     void init_device(int device_index);
     void use_device() const;
+    // Rebind the handle to another stream.  The workspaces are shared by all calls on the handle, so work already queued on the old
+    // stream is ordered before anything the new stream will launch (event record + wait; no host synchronisation).
+    void switch_stream(hipStream_t s);
+};
+
+// Host-pointer entry points run on the handle's own stream whatever stream the device-pointer API was last bound to.
+struct OwnStreamScope {
+    Codec& c;
+    hipStream_t prev;
+    explicit OwnStreamScope(Codec& c_) : c(c_), prev(c_.stream) { c.use_device(); c.switch_stream(c.own_stream); }
+    ~OwnStreamScope() {
+        try { c.switch_stream(prev); } catch (...) {}
+    }
 };
 
 struct DacModel : Codec {

@@ -141,7 +141,6 @@ void Codebook::build(const float* h, int N_, int D_) {
     NC_HIP(hipMemcpy(c2.p, n2.data(), n2.size() * 4, hipMemcpyHostToDevice));
 }
 
-static bool g_vq_attr = false;
 
 void launch_vq_argmin(const Codebook& cb, const float* z_e, int64_t ze_bstride, int B, int64_t T, int64_t* codes,
                       int64_t codes_bstride, float* st, hipStream_t s, Profiler* prof) {
@@ -149,10 +148,7 @@ void launch_vq_argmin(const Codebook& cb, const float* z_e, int64_t ze_bstride, 
     if ((cb.D * cb.N) % 4 != 0) fail(NC_EUNSUPPORTED, "codebook of %d x %d entries is not a whole number of 16-byte words", cb.N, cb.D);
     const size_t lds = sizeof(float) * ((size_t)cb.D * cb.N + cb.N);
     if (lds > 160 * 1024) fail(NC_EUNSUPPORTED, "codebook of %d x %d does not fit LDS", cb.N, cb.D);
-    if (!g_vq_attr) {
-        NC_HIP(hipFuncSetAttribute((const void*)vq_argmin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        g_vq_attr = true;
-    }
+    ensure_dynamic_lds((const void*)vq_argmin_kernel, 160 * 1024);
     const int64_t total = (int64_t)B * T;
     const int64_t per_block = 4 * VQ_FRAMES_PER_WAVE;
     const int64_t grid = (total + per_block - 1) / per_block;

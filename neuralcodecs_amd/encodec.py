@@ -114,8 +114,9 @@ class Encodec:
 
     def query(self, T: int):
         nf, nq, dl = C.c_int32(), C.c_int32(), C.c_int64()
-        lens = (C.c_int64 * 64)()
-        _lib.check(_lib.lib().nc_encodec_query(self._h, T, C.byref(nf), C.byref(nq), lens, 64, C.byref(dl)))
+        _lib.check(_lib.lib().nc_encodec_query(self._h, T, C.byref(nf), C.byref(nq), None, 0, C.byref(dl)))   # count first
+        lens = (C.c_int64 * max(1, nf.value))()
+        _lib.check(_lib.lib().nc_encodec_query(self._h, T, C.byref(nf), C.byref(nq), lens, nf.value, C.byref(dl)))
         return nf.value, nq.value, [lens[i] for i in range(nf.value)], dl.value
 
     def _bind_torch_stream(self):
