@@ -140,14 +140,22 @@ NC_API nc_status nc_snac_create(const nc_snac_config* cfg, int device_index, nc_
 NC_API nc_status nc_snac_query(const nc_codec* h, int64_t T, int64_t* T_padded, int64_t* frames, int32_t* n_levels,
                                int64_t* level_widths, int64_t* decoded_len);
 
-/* replaces: SNAC.Encode(float[]) / Encode(Tensor)   Models/SNAC.cs:113-150  (always pads: the Tensor overload's missing pad
- * is reference bug D7; both agree on lengths that are already multiples)
+/* replaces: SNAC.Encode(float[])   Models/SNAC.cs:129-150 and the encode half of forward :91-106  (Preprocess pads; for the
+ * Tensor overload exactly as written see nc_snac_encode_tensor below; the two agree on lengths that are already multiples)
  *   pcm   [B,1,T] float32
  *   codes [B, sum_i T'/stride_i] int64: the levels of one clip side by side, coarse first (the reference returns a List of
  *         [B, T'/stride_i] tensors; nc_snac_query gives the widths)
  *   z / zq nullable [B, latent, T']: encoder output / quantized latents */
 NC_API nc_status nc_snac_encode(nc_codec* h, const float* pcm, int32_t B, int64_t T, int64_t* codes, float* z, float* zq);
 NC_API nc_status nc_snac_encode_dev(nc_codec* h, const float* pcm, int32_t B, int64_t T, int64_t* codes, float* z, float* zq);
+
+/* replaces: SNAC.Encode(Tensor) AS WRITTEN   Models/SNAC.cs:113-122 (deviation D7: Preprocess's result is dropped and the encoder
+ * runs on the UN-padded tensor).  Frames T' follow the strided convs' floor lengths (nc_snac_query_tensor); where the reference
+ * throws (T' not a multiple of every vq stride: repeat_interleave + add shape mismatch, VectorQuantizer.cs:99-101; LocalMHA
+ * window reshape, LocalMHA.cs:84-91) the call returns NC_EINVAL.  Same buffer layout as nc_snac_encode with T' from the query. */
+NC_API nc_status nc_snac_query_tensor(const nc_codec* h, int64_t T, int64_t* frames, int32_t* n_levels, int64_t* level_widths);
+NC_API nc_status nc_snac_encode_tensor(nc_codec* h, const float* pcm, int32_t B, int64_t T, int64_t* codes, float* z, float* zq);
+NC_API nc_status nc_snac_encode_tensor_dev(nc_codec* h, const float* pcm, int32_t B, int64_t T, int64_t* codes, float* z, float* zq);
 
 /* replaces: ResidualVectorQuantizer.FromCodes      Modules/SNAC/ResidualVectorQuantizer.cs:100-135 */
 NC_API nc_status nc_snac_from_codes(nc_codec* h, const int64_t* codes, int32_t B, int64_t frames, float* zq);

@@ -86,6 +86,9 @@ SYMBOLS = [
     ("nc_snac_noise_len", C.c_int, [_P, C.c_int32, C.c_int64, C.POINTER(C.c_int64)]),
     ("nc_snac_encode", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
     ("nc_snac_encode_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
+    ("nc_snac_query_tensor", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    ("nc_snac_encode_tensor", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
+    ("nc_snac_encode_tensor_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
     ("nc_snac_from_codes", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
     ("nc_snac_from_codes_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
     ("nc_snac_decode", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, C.c_uint64, _P]),

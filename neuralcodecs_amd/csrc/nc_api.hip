@@ -254,6 +254,20 @@ nc_status nc_snac_noise_len(const nc_codec* h, int32_t B, int64_t frames, int64_
 nc_status nc_snac_encode_dev(nc_codec* h, const float* pcm, int32_t B, int64_t T, int64_t* codes, float* z, float* zq) {
     return guard([&] { as_snac(h).encode_dev(pcm, B, T, codes, z, zq); });
 }
+nc_status nc_snac_encode_tensor_dev(nc_codec* h, const float* pcm, int32_t B, int64_t T, int64_t* codes, float* z, float* zq) {
+    return guard([&] { as_snac(h).encode_dev(pcm, B, T, codes, z, zq, false); });
+}
+nc_status nc_snac_query_tensor(const nc_codec* h, int64_t T, int64_t* frames, int32_t* n_levels, int64_t* level_widths) {
+    return guard([&] {
+        SnacModel& m = as_snac(const_cast<nc_codec*>(h));
+        if (T <= 0) fail(NC_EINVAL, "T must be positive");
+        const int64_t Tz = m.unpadded_frames(T);
+        if (frames) *frames = Tz;
+        if (n_levels) *n_levels = m.cfg.n_vq_strides;
+        if (level_widths)
+            for (int i = 0; i < m.cfg.n_vq_strides; ++i) level_widths[i] = Tz / m.cfg.vq_strides[i];
+    });
+}
 nc_status nc_snac_from_codes_dev(nc_codec* h, const int64_t* codes, int32_t B, int64_t frames, float* zq) {
     return guard([&] { as_snac(h).from_codes_dev(codes, B, frames, zq); });
 }
@@ -262,23 +276,28 @@ nc_status nc_snac_decode_dev(nc_codec* h, const int64_t* codes, int32_t B, int64
     return guard([&] { as_snac(h).decode_dev(codes, B, frames, noise, seed, pcm); });
 }
 
+static void snac_encode_host(nc_codec* h, const float* pcm, int32_t B, int64_t T, int64_t* codes, float* z, float* zq, bool pad) {
+    SnacModel& m = as_snac(h);
+    if (!pcm || !codes) fail(NC_EINVAL, "pcm and codes must not be null");
+    if (B <= 0 || T <= 0) fail(NC_EINVAL, "B and T must be positive");
+    m.use_device();
+    OwnStreamScope own(m);
+    const int64_t Tz = pad ? m.padded_len(T) / m.hop : m.unpadded_frames(T);
+    const size_t n_in = (size_t)B * T * 4, n_codes = (size_t)B * m.codes_per_clip(Tz) * 8, n_z = (size_t)B * m.latent * Tz * 4;
+    m.h_in.reserve(n_in); m.h_codes.reserve(n_codes); m.h_aux0.reserve(n_z); m.h_aux1.reserve(n_z);
+    h2d(m.h_in.p, pcm, n_in, m.stream);
+    m.encode_dev(m.h_in.as<float>(), B, T, m.h_codes.as<int64_t>(), m.h_aux0.as<float>(), m.h_aux1.as<float>(), pad);
+    d2h(codes, m.h_codes.p, n_codes, m.stream);
+    if (z) d2h(z, m.h_aux0.p, n_z, m.stream);
+    if (zq) d2h(zq, m.h_aux1.p, n_z, m.stream);
+    NC_HIP(hipStreamSynchronize(m.stream));
+}
+
 nc_status nc_snac_encode(nc_codec* h, const float* pcm, int32_t B, int64_t T, int64_t* codes, float* z, float* zq) {
-    return guard([&] {
-        SnacModel& m = as_snac(h);
-        if (!pcm || !codes) fail(NC_EINVAL, "pcm and codes must not be null");
-        if (B <= 0 || T <= 0) fail(NC_EINVAL, "B and T must be positive");
-        m.use_device();
-        OwnStreamScope own(m);
-        const int64_t Tz = m.padded_len(T) / m.hop;
-        const size_t n_in = (size_t)B * T * 4, n_codes = (size_t)B * m.codes_per_clip(Tz) * 8, n_z = (size_t)B * m.latent * Tz * 4;
-        m.h_in.reserve(n_in); m.h_codes.reserve(n_codes); m.h_aux0.reserve(n_z); m.h_aux1.reserve(n_z);
-        h2d(m.h_in.p, pcm, n_in, m.stream);
-        m.encode_dev(m.h_in.as<float>(), B, T, m.h_codes.as<int64_t>(), m.h_aux0.as<float>(), m.h_aux1.as<float>());
-        d2h(codes, m.h_codes.p, n_codes, m.stream);
-        if (z) d2h(z, m.h_aux0.p, n_z, m.stream);
-        if (zq) d2h(zq, m.h_aux1.p, n_z, m.stream);
-        NC_HIP(hipStreamSynchronize(m.stream));
-    });
+    return guard([&] { snac_encode_host(h, pcm, B, T, codes, z, zq, true); });
+}
+nc_status nc_snac_encode_tensor(nc_codec* h, const float* pcm, int32_t B, int64_t T, int64_t* codes, float* z, float* zq) {
+    return guard([&] { snac_encode_host(h, pcm, B, T, codes, z, zq, false); });
 }
 
 nc_status nc_snac_from_codes(nc_codec* h, const int64_t* codes, int32_t B, int64_t frames, float* zq) {

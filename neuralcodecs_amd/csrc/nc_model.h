@@ -151,7 +151,11 @@ struct SnacModel : Codec {
         for (int i = 0; i < cfg.n_vq_strides; ++i) n += frames / cfg.vq_strides[i];
         return n;
     }
-    void encode_dev(const float* pcm, int B, int64_t T, int64_t* codes, float* z, float* zq);
+    // pad = true: SNAC.Encode(float[]) / forward (Preprocess, then the encoder on the padded tensor; SNAC.cs:129-150, 91-106)
+    // pad = false: SNAC.Encode(Tensor) AS WRITTEN (SNAC.cs:113-122, deviation D7): the encoder runs on the un-padded tensor
+    void encode_dev(const float* pcm, int B, int64_t T, int64_t* codes, float* z, float* zq, bool pad = true);
+    // frames the encoder emits for an un-padded row of T samples; NC_EINVAL where the reference's quantizer / LocalMHA would throw
+    int64_t unpadded_frames(int64_t T) const;
     void from_codes_dev(const int64_t* codes, int B, int64_t frames, float* zq);
     void decode_dev(const int64_t* codes, int B, int64_t frames, const float* noise, uint64_t seed, float* pcm);
 

@@ -289,12 +289,33 @@ void SnacModel::reserve_act(int B, int64_t Tp) {
     for (auto& a : act) a.reserve((size_t)B * maxel * sizeof(float));
 }
 
-void SnacModel::encode_dev(const float* pcm, int B, int64_t T, int64_t* codes, float* z_out, float* zq_out) {
+// Encode(Tensor) as written (SNAC.cs:113-122): `preprocessed` is computed and dropped, the encoder sees the raw tensor.  Every
+// strided conv floors ((L + 2*ceil(s/2) - 2s)/s + 1, EncoderBlock.cs:46-53); the quantizer then needs T' % vq_stride == 0 for its
+// repeat_interleave + add (VectorQuantizer.cs:99-101, ResidualVectorQuantizer.cs:82-83: a libtorch shape exception otherwise) and
+// LocalMHA reshapes into T'/window windows (LocalMHA.cs:84-91).  Lengths on which the reference throws return NC_EINVAL; the
+// attention models additionally need whole windows here (the reference's accidental wider-window cases are not reproduced).
+int64_t SnacModel::unpadded_frames(int64_t T) const {
+    int64_t L = T;
+    for (int bi = 0; bi < cfg.n_encoder_rates; ++bi) {
+        L = enc[bi].down.out_len(L);
+        if (L <= 0) fail(NC_EINVAL, "input of %lld samples is too short for the encoder", (long long)T);
+    }
+    for (int i = 0; i < cfg.n_vq_strides; ++i)
+        if (L % cfg.vq_strides[i] != 0)
+            fail(NC_EINVAL, "un-padded input of %lld samples gives %lld frames, not a multiple of vq stride %d (the reference's quantizer throws)",
+                 (long long)T, (long long)L, cfg.vq_strides[i]);
+    if (cfg.attn_window_size > 0 && L % cfg.attn_window_size != 0)
+        fail(NC_EINVAL, "un-padded input of %lld samples gives %lld frames, not whole attention windows of %d", (long long)T, (long long)L,
+             cfg.attn_window_size);
+    return L;
+}
+
+void SnacModel::encode_dev(const float* pcm, int B, int64_t T, int64_t* codes, float* z_out, float* zq_out, bool pad) {
     if (!loaded) fail(NC_ESTATE, "weights not loaded (call nc_codec_load_weights first)");
     if (!pcm || !codes) fail(NC_EINVAL, "pcm and codes must not be null");
     if (B <= 0 || T <= 0 || T > ((int64_t)1 << 30)) fail(NC_EINVAL, "B and T must be positive");
     use_device();
-    const int64_t Tp = padded_len(T), Tz = Tp / hop;
+    const int64_t Tp = pad ? padded_len(T) : T, Tz = pad ? Tp / hop : unpadded_frames(T);
     reserve_act(B, Tp);
     const int D = cfg.codebook_dim;
     resid.reserve((size_t)B * latent * Tz * 4);

@@ -97,6 +97,13 @@ class SNAC:
         _lib.check(_lib.lib().nc_snac_query(self._h, T, C.byref(tp), C.byref(fr), C.byref(nl), widths, C.byref(dl)))
         return tp.value, fr.value, [widths[i] for i in range(nl.value)], dl.value
 
+    def query_tensor(self, T: int):
+        """Frames / level widths of Encode(Tensor) as written (un-padded, SNAC.cs:113-122); ValueError where the reference throws."""
+        fr, nl = C.c_int64(), C.c_int32()
+        widths = (C.c_int64 * 8)()
+        _lib.check(_lib.lib().nc_snac_query_tensor(self._h, T, C.byref(fr), C.byref(nl), widths))
+        return fr.value, [widths[i] for i in range(nl.value)]
+
     def noise_shapes(self, B: int, frames: int):
         out, L = [], frames
         for s in self.config.decoder_rates:
@@ -112,14 +119,24 @@ class SNAC:
         _lib.check(_lib.lib().nc_codec_synchronize(self._h))
 
     # ---- Encode ----------------------------------------------------------------------------
-    def encode(self, audio_data, return_latents: bool = False):
+    def encode_tensor(self, audio_data, return_latents: bool = False):
+        """SNAC.Encode(Tensor) exactly as written (Models/SNAC.cs:113-122, deviation D7): Preprocess's result is dropped and the
+        encoder runs on the UN-padded tensor.  `encode` below is the padding Encode(float[]) / forward behaviour."""
+        return self.encode(audio_data, return_latents, _pad=False)
+
+    def encode(self, audio_data, return_latents: bool = False, _pad: bool = True):
         if audio_data is None:
             raise ValueError("audio_data must not be null")
         if audio_data.ndim != 3 or audio_data.shape[1] != 1:
             raise ValueError("audio must be [B,1,T]")
         B, _, T = audio_data.shape
-        _, Tz, widths, _ = self.query(T)
+        if _pad:
+            _, Tz, widths, _ = self.query(T)
+        else:
+            Tz, widths = self.query_tensor(T)
         total = sum(widths)
+        L = _lib.lib()
+        fn_dev, fn_host = (L.nc_snac_encode_dev, L.nc_snac_encode) if _pad else (L.nc_snac_encode_tensor_dev, L.nc_snac_encode_tensor)
         if _is_torch(audio_data):
             import torch
             x = audio_data.contiguous().to(torch.float32)
@@ -127,13 +144,13 @@ class SNAC:
             z = torch.empty((B, self.latent_dim, Tz), dtype=torch.float32, device=x.device)
             zq = torch.empty_like(z)
             self._bind_torch_stream()
-            _lib.check(_lib.lib().nc_snac_encode_dev(self._h, x.data_ptr(), B, T, flat.data_ptr(), z.data_ptr(), zq.data_ptr()))
+            _lib.check(fn_dev(self._h, x.data_ptr(), B, T, flat.data_ptr(), z.data_ptr(), zq.data_ptr()))
         else:
             x = np.ascontiguousarray(audio_data, dtype=np.float32)
             flat = np.empty((B, total), np.int64)
             z = np.empty((B, self.latent_dim, Tz), np.float32)
             zq = np.empty_like(z)
-            _lib.check(_lib.lib().nc_snac_encode(self._h, x.ctypes.data, B, T, flat.ctypes.data, z.ctypes.data, zq.ctypes.data))
+            _lib.check(fn_host(self._h, x.ctypes.data, B, T, flat.ctypes.data, z.ctypes.data, zq.ctypes.data))
         codes, o = [], 0
         for w in widths:
             codes.append(flat[:, o:o + w])

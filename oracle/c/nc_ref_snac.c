@@ -40,6 +40,7 @@ typedef struct {
     uint8_t* blob_copy;
     ref_blob blob;
     int bad;
+    int no_pad;   /* Encode(Tensor) as written: the encoder sees the un-padded clip (SNAC.cs:113-122) */
 } ref_snac;
 
 /* D3 fold; norm over all dims but 0 */
@@ -98,7 +99,21 @@ REF_API int64_t ref_snac_padded_length(const ref_snac* m, int64_t T) {
     int64_t pad_to = m->hop * (a / gcd64(a, b) * b);
     return (T + pad_to - 1) / pad_to * pad_to;
 }
-REF_API int64_t ref_snac_frames(const ref_snac* m, int64_t T) { return ref_snac_padded_length(m, T) / m->hop; }
+/* pad = 1 (default): Encode(float[]) / forward semantics; pad = 0: Encode(Tensor) as written (Models/SNAC.cs:113-122, D7) */
+REF_API void ref_snac_set_pad(ref_snac* m, int pad) { m->no_pad = !pad; }
+/* frames of the encoder; -1 where the un-padded path makes the reference's quantizer / LocalMHA throw */
+REF_API int64_t ref_snac_frames(const ref_snac* m, int64_t T) {
+    if (!m->no_pad) return ref_snac_padded_length(m, T) / m->hop;
+    int64_t L = T;
+    for (int i = 0; i < m->cfg.n_enc_rates; i++) {
+        const int s = m->cfg.enc_rates[i];
+        L = (L + 2 * (int64_t)((s + 1) / 2) - 2 * (int64_t)s) / s + 1;          /* EncoderBlock.cs:46-53: k = 2s, stride s, pad ceil(s/2) */
+        if (L <= 0) return -1;
+    }
+    for (int i = 0; i < m->cfg.n_vq; i++) if (L % m->cfg.vq_strides[i]) return -1;
+    if (m->cfg.attn_window > 0 && L % m->cfg.attn_window) return -1;
+    return L;
+}
 
 /* ---- layers ------------------------------------------------------------------------------------ */
 static float* conv_apply(ref_snac* m, const char* prefix, float* x, int64_t B, int Cin, int64_t L, int stride, int pad, int dil,
@@ -223,7 +238,7 @@ static float* local_mha(ref_snac* m, const char* p, float* x, int64_t B, int C, 
 static float* snac_encoder(ref_snac* m, const float* pcm, int64_t B, int64_t T, int64_t* Tz) {
     const ref_snac_config* c = &m->cfg;
     char nm[320];
-    const int64_t Tp = ref_snac_padded_length(m, T);
+    const int64_t Tp = m->no_pad ? T : ref_snac_padded_length(m, T);
     float* x = (float*)calloc(B * Tp, sizeof(float));
     for (int64_t b = 0; b < B; b++) memcpy(x + b * Tp, pcm + b * T, sizeof(float) * T);
     int C = 1; int64_t L = Tp;
@@ -253,6 +268,7 @@ REF_API int ref_snac_encode(ref_snac* m, const float* pcm, int64_t B, int64_t T,
     const ref_snac_config* c = &m->cfg;
     char nm[320];
     m->bad = 0;
+    if (ref_snac_frames(m, T) < 0) return 2;   /* the reference throws on this length */
     int64_t Tz;
     float* z = snac_encoder(m, pcm, B, T, &Tz);
     const int LD = c->latent_dim, D = c->codebook_dim;

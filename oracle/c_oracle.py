@@ -74,6 +74,7 @@ def lib():
         for f in ("ref_snac_padded_length", "ref_snac_frames", "ref_snac_decoded_length"):
             getattr(L, f).restype = C.c_int64
             getattr(L, f).argtypes = [C.c_void_p, C.c_int64]
+        L.ref_snac_set_pad.argtypes = [C.c_void_p, C.c_int]
         L.ref_snac_encode.argtypes = [C.c_void_p, f32p, C.c_int64, C.c_int64, i64p, C.c_void_p, C.c_void_p]
         L.ref_snac_from_codes.argtypes = [C.c_void_p, i64p, C.c_int64, C.c_int64, f32p]
         L.ref_snac_decode.argtypes = [C.c_void_p, f32p, C.c_int64, C.c_int64, C.c_void_p, f32p]
@@ -233,10 +234,20 @@ class RefSNAC:
     def level_widths(self, Tz):
         return [Tz // s for s in self.cfg.vq_strides]
 
+    def encode_tensor(self, pcm):
+        """SNAC.Encode(Tensor) as written (SNAC.cs:113-122, D7): no pad; ValueError where the reference throws."""
+        lib().ref_snac_set_pad(self._h, 0)
+        try:
+            return self.encode(pcm)
+        finally:
+            lib().ref_snac_set_pad(self._h, 1)
+
     def encode(self, pcm):
         pcm = np.ascontiguousarray(pcm, np.float32)
         B, _, T = pcm.shape
         Tz = lib().ref_snac_frames(self._h, T)
+        if Tz < 0:
+            raise ValueError(f"un-padded input of {T} samples: the reference's quantizer / LocalMHA throws on this length")
         widths = self.level_widths(Tz)
         flat = np.empty((B, sum(widths)), np.int64)
         ld = self.cfg.resolved_latent_dim

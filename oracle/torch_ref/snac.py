@@ -205,6 +205,17 @@ class TorchSNAC:
         return (z, zq, codes, dists) if want_dist else (z, zq, codes)
 
     @torch.inference_mode()
+    def encode_tensor(self, pcm, want_dist=False):
+        """SNAC.Encode(Tensor) AS WRITTEN (Models/SNAC.cs:113-122, deviation D7): `preprocessed` is computed and dropped, the
+        encoder runs on the un-padded tensor.  The quantizer raises (repeat_interleave + add shape mismatch) when the frame
+        count is not a multiple of every vq stride -- the same libtorch exception the reference surfaces."""
+        x = _t(pcm).float()
+        _ = self.preprocess(x)
+        z = self.encoder(x)
+        zq, codes, dists = self.quantize(z, want_dist)
+        return (z, zq, codes, dists) if want_dist else (z, zq, codes)
+
+    @torch.inference_mode()
     def decode(self, codes, noises=None):
         zq = self.from_codes([_t(c) for c in codes])
         return self.decoder(zq, None if noises is None else [_t(n).float() for n in noises])

@@ -71,3 +71,31 @@ def test_c_oracle_snac44k_with_local_attention():
     gold_codes = [g[f"codes{i}"].astype(np.int64) for i in range(4)]
     audio = ref.decode(gold_codes, snac_noise(cfg, 1, 64, seed=meta["noise_seed"]))
     assert np.abs(audio[:, :, ::17] - g["audio_slice"]).max() < PCM_TOL
+
+
+def test_c_oracle_snac_encode_tensor_overload_as_written():
+    """SNAC.Encode(Tensor) as written (Models/SNAC.cs:113-122, D7): the encoder runs on the UN-padded tensor.  Goldens come from
+    oracle/torch_ref TorchSNAC.encode_tensor; the padded Encode(float[]) path gives a different frame count on the same input."""
+    g = load_golden("snac_small_tensor")
+    meta = g["meta"]
+    cfg = snac_cfg_from_meta(meta)
+    ref = c_oracle.RefSNAC(cfg, save_blob(snac_synthetic_state_dict(cfg, seed=meta["weight_seed"])))
+    z, zq, codes = ref.encode_tensor(g["pcm"])
+    assert z.shape == g["z"].shape == (2, 128, 32)
+    assert np.abs(z - g["z"]).max() < LATENT_TOL
+    assert audit_snac_levels(codes, g, GAP_TOL) == 0
+    assert np.abs(zq - g["zq"]).max() < LATENT_TOL
+    zp, _, cp = ref.encode(g["pcm"])                                     # Encode(float[]) pads: 36 frames, other codes
+    assert zp.shape[-1] == 36 and cp[-1].shape[-1] == 36
+    with pytest.raises(ValueError):                                      # 3001 samples -> 31 frames: the reference's quantizer throws
+        ref.encode_tensor(synthetic_pcm(1, 1, 3001, cfg.sampling_rate, seed=1))
+    # full-size 24 kHz model, 22628 samples -> 44 frames (the padded path gives 48)
+    g = load_golden("snac24k_tensor_b1")
+    meta = g["meta"]
+    cfg = snac_cfg_from_meta(meta)
+    ref = c_oracle.RefSNAC(cfg, save_blob(snac_synthetic_state_dict(cfg, seed=meta["weight_seed"])))
+    pcm = synthetic_pcm(1, 1, meta["T"], cfg.sampling_rate, seed=meta["pcm_seed"])
+    z, zq, codes = ref.encode_tensor(pcm)
+    assert [c.shape for c in codes] == [(1, 11), (1, 22), (1, 44)]
+    assert audit_snac_levels(codes, g, GAP_TOL) == 0
+    assert np.abs(zq[:, ::16, :] - g["zq_slice"]).max() < LATENT_TOL

@@ -143,3 +143,37 @@ def test_snac44k_attention_full_width_config_c5_shape():
     nz5 = snac_noise(cfg, 1, 576, seed=9)
     assert np.array_equal(m.decode(c5, nz5), ref.decode(r5, nz5))
     m.dispose()
+
+
+def test_snac_encode_tensor_overload_as_written():
+    """SNAC.Encode(Tensor) as written (Models/SNAC.cs:113-122, D7): no pad.  Engine == C oracle bit for bit, == torch goldens within
+    tolerance; the padding path gives other frame counts on the same input; lengths the reference throws on give ValueError."""
+    g, cfg, m, ref = _setup("snac_small_tensor")
+    codes, z, zq = m.encode_tensor(g["pcm"], return_latents=True)
+    rz, rzq, rcodes = ref.encode_tensor(g["pcm"])
+    for a, b in zip(codes, rcodes):
+        assert np.array_equal(a, b)
+    assert np.array_equal(z, rz) and np.array_equal(zq, rzq)
+    assert np.abs(z - g["z"]).max() < LATENT_TOL
+    assert audit_snac_levels(codes, g, GAP_TOL) == 0
+    assert np.abs(zq - g["zq"]).max() < LATENT_TOL
+    assert m.encode(g["pcm"])[-1].shape[-1] == 36 and codes[-1].shape[-1] == 32
+    with pytest.raises(ValueError):
+        m.encode_tensor(synthetic_pcm(1, 1, 3001, cfg.sampling_rate, seed=1))
+    import torch
+    cd = m.encode_tensor(torch.from_numpy(g["pcm"]).cuda())
+    for a, b in zip(cd, codes):
+        assert np.array_equal(a.cpu().numpy(), b)
+    m.dispose()
+    g, cfg, m, ref = _setup("snac24k_tensor_b1")
+    meta = g["meta"]
+    pcm = synthetic_pcm(2, 1, meta["T"], cfg.sampling_rate, seed=meta["pcm_seed"])
+    codes, z, zq = m.encode_tensor(pcm, return_latents=True)
+    rz, rzq, rcodes = ref.encode_tensor(pcm)
+    assert [c.shape for c in codes] == [(2, 11), (2, 22), (2, 44)]
+    for a, b in zip(codes, rcodes):
+        assert np.array_equal(a, b)
+    assert np.array_equal(zq, rzq)
+    assert audit_snac_levels([c[:1] for c in codes], g, GAP_TOL) == 0
+    assert np.abs(zq[:1, ::16, :] - g["zq_slice"]).max() < LATENT_TOL
+    m.dispose()

@@ -66,11 +66,11 @@ SNAC_SMALL_ATTN = dict(sampling_rate=16000, encoder_dim=16, encoder_rates=(2, 3,
                        attn_window_size=8, codebook_size=256, vq_strides=(4, 2, 1))
 
 
-def snac_case(name, cfg_kw, B, T, wseed, pseed, nseed, full):
+def snac_case(name, cfg_kw, B, T, wseed, pseed, nseed, full, tensor_overload=False):
     cfg = SNACConfig(**cfg_kw)
     m = TorchSNAC(cfg, snac_synthetic_state_dict(cfg, seed=wseed))
     pcm = synthetic_pcm(B, 1, T, cfg.sampling_rate, seed=pseed)
-    z, zq, codes, dists = m.encode(pcm, want_dist=True)
+    z, zq, codes, dists = (m.encode_tensor if tensor_overload else m.encode)(pcm, want_dist=True)
     noises = snac_noise(cfg, B, z.shape[-1], seed=nseed)
     audio = m.decode(codes, noises)
     meta = dict(cfg=cfg_kw, B=B, T=T, weight_seed=wseed, pcm_seed=pseed, noise_seed=nseed)
@@ -118,6 +118,11 @@ def encodec_case(name, cfg_kw, B, T, wseed, pseed, full):
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "--round2":   # fixtures added in round 2 (the round-1 files stay byte-identical)
+        # SNAC.Encode(Tensor) as written (D7): 24 kHz model on an un-padded, non-multiple length (22628 samples -> 44 frames, not 48)
+        snac_case("snac24k_tensor_b1", dict(), 1, 22628, 42, 1234, 77, True, tensor_overload=True)
+        snac_case("snac_small_tensor", SNAC_SMALL, 2, 3100, 5, 3, 99, False, tensor_overload=True)
+        sys.exit(0)
     # reduced width, ragged length (not a hop multiple), odd stride 5 (DAC-16/24 kHz presets use it)
     dac_case("dac_small", SMALL, 2, 2000, 7, 11, False)
     # full-size DAC 44.1 kHz 8 kbps, one 1 s clip (BASELINE config C2 at B=1)
