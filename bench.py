@@ -7,12 +7,19 @@
 One "step" = DAC.Encode (pad -> encoder -> 9-stage RVQ -> int64 codes + zQ) followed by DAC.Decode(zQ) on one
 batch of 32 synthetic 1 s clips that is already resident in HBM.  With N>1 every rank (one process per GPU)
 runs its own 32-clip shard (weak scaling, BASELINE config C4 = 256 clips over 8 GPUs) and the emitted code
-tensors are all-gathered over RCCL on a side stream while the local decode runs.
+tensors are all-gathered over RCCL on a side stream while the local decode runs.  `--config snac44k` runs the
+same loop on BASELINE config C5's per-GPU share (SNAC 44.1 kHz + LocalMHA, 8 x 5 s clips per GPU, the four code
+levels of a clip gathered in one collective).
 
-The JSON line carries `roofline` for the dominant kernel class (the dilated k=7 residual-unit convolutions,
-fp32 matrix-core implicit GEMM: bound "mfma", peak = 157.3 TFLOP/s dense fp32 MFMA on MI355X) measured with
-HIP events on the launch stream, and `cpu_baseline`: the C oracle (kind "port") timed on the host cores on a
-bounded sample of the same workload.
+The JSON line carries
+  * `roofline` for the dominant kernel class (the dilated k=7 residual-unit convolutions, fp32 matrix-core implicit
+    GEMM: bound "mfma", peak = 157.3 TFLOP/s dense fp32 MFMA on MI355X) measured with HIP events on the launch stream;
+  * `cpu_baseline`: the C oracle (kind "port") timed on the host cores on a bounded sample of the same workload, the
+    GPU == oracle check on those clips (`gpu_equals_oracle`, outside the timed region) and `aten_proxy`: the same graph
+    as a sequence of ATen CPU operators (oracle/torch_ref, the closest stand-in for the reference's TorchSharp-CPU path);
+  * `extra_configs` (N=1 only): BASELINE configs C3 (Encodec 48 kHz stereo, 16 x 2 s), C5's per-GPU share and C1
+    (SNAC 24 kHz, 1 x 1 s) on the same GPU: ms, x real-time, per-class HIP-event times, dominant kernel class with its
+    roofline fraction, algorithmic vs PMC bytes, and a GPU == oracle check on one clip.
 """
 import argparse
 import json
@@ -27,6 +34,155 @@ import numpy as np  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 HBM_PEAK_GBS = 8000.0
+MFMA_CLASSES = ("conv_k7", "conv_k1", "conv_down", "conv_up", "conv_misc", "lstm")   # dense contractions: priced against the fp32 matrix peak
+# algorithmic work per audio-second of encode+decode (layer-fused byte model)
+ALGO = {"dac44k": (201.8e9, 1.057e9), "encodec48k": (12.28e9 * 1.5, 0.47e9 * 1.5), "snac24k": (14.8e9, 0.44e9), "snac44k": (67.9e9, 1.23e9)}
+
+
+def class_table(prof, steps):
+    out = {}
+    for n, v in prof.items():
+        if v["launches"] == 0:
+            continue
+        ms = v["ms"]
+        out[n] = {"ms_per_step": round(ms / steps, 4), "launches_per_step": round(v["launches"] / steps, 1),
+                  "tflops": round(v["flops"] / (ms * 1e-3) / 1e12, 3) if ms > 0 else 0.0,
+                  "algo_GBps": round(v["bytes"] / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0}
+    return out
+
+
+def dominant(classes):
+    """Class with the largest HIP-event time and its fraction of the roofline that bounds it."""
+    if not classes:
+        return None
+    name = max(classes, key=lambda n: classes[n]["ms_per_step"])
+    c = classes[name]
+    if name in MFMA_CLASSES:
+        return {"class": name, "bound": "mfma", "achieved": c["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(c["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "ms_per_step": c["ms_per_step"]}
+    return {"class": name, "bound": "hbm", "achieved": c["algo_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(c["algo_GBps"] / HBM_PEAK_GBS, 4), "ms_per_step": c["ms_per_step"]}
+
+
+def load_traffic(key):
+    """HBM bytes from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per
+    MI355X_MICROARCH.md), committed under profiles/traffic.json by tools/traffic_json.py: a measured constant of the build."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(p):
+        return None
+    return json.load(open(p)).get(key)
+
+
+def timed(fn, steps, warmup, sync):
+    for _ in range(warmup):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = fn()
+    sync()
+    return (time.perf_counter() - t0) / steps, r
+
+
+def extra_configs(dev, steps, warmup, check):
+    """BASELINE configs C3 / C5-share / C1 on this GPU (inputs resident in HBM; HIP-event class times from the engine's profiler)."""
+    import torch
+    from neuralcodecs_amd import SNAC, Encodec
+    from neuralcodecs_amd.config import EncodecConfig, SNACConfig
+    from neuralcodecs_amd.weights import encodec_synthetic_state_dict, save_blob, snac_noise, snac_synthetic_state_dict, synthetic_pcm
+    out = {}
+
+    def run(name, m, fn, B, secs, algo_key, oracle_check):
+        dt, _ = timed(fn, 1, warmup, torch.cuda.synchronize)
+        m.profile_enable(True)
+        m.profile_reset()
+        dt, _ = timed(fn, steps, 0, torch.cuda.synchronize)
+        prof = m.profile_read()
+        m.profile_enable(False)
+        classes = class_table(prof, steps)
+        fl, by = ALGO[algo_key]
+        e = {"workload": name, "B": B, "clip_seconds": secs, "ms_per_step": round(dt * 1e3, 3), "x_realtime": round(B * secs / dt, 1),
+             "whole_step_tflops": round(fl * B * secs / dt / 1e12, 3), "whole_step_algo_GBps": round(by * B * secs / dt / 1e9, 1),
+             "kernel_ms_per_step": round(sum(c["ms_per_step"] for c in classes.values()), 3),
+             "dominant": dominant(classes), "classes": classes, "pmc_traffic": load_traffic(algo_key)}
+        if check:
+            e["gpu_equals_oracle"] = oracle_check()
+        out[algo_key if algo_key != "snac44k" else "snac44k_c5_share"] = e
+
+    # C3: Encodec 48 kHz stereo 12 kbps, 16 x 2 s
+    cfg = EncodecConfig.encodec_48khz()
+    blob = save_blob(encodec_synthetic_state_dict(cfg, seed=42))
+    m = Encodec(cfg)
+    m.load_blob(blob)
+    B, secs = 16, 2.0
+    T = int(secs * cfg.sampling_rate)
+    xh = synthetic_pcm(B, cfg.channels, T, cfg.sampling_rate, seed=1234)
+    x = torch.from_numpy(xh).to(dev)
+
+    def enc_check():
+        from oracle import c_oracle
+        ref = c_oracle.RefEncodec(cfg, blob)
+        fr = m.encode(x)
+        au = m.decode(fr, T)
+        rfr = ref.encode(xh[:1])
+        rau = ref.decode(rfr)
+        ok = all(np.array_equal(f.codes[:1].cpu().numpy(), r[0]) for f, r in zip(fr, rfr))
+        return {"clips": 1, "codes_bit_exact": bool(ok), "pcm_max_abs_diff": float(np.abs(au[:1].cpu().numpy() - rau).max())}
+
+    run("Encodec 48kHz stereo 12kbps encode+decode, batch=16 x 2 s (BASELINE configs[2])", m, lambda: m.decode(m.encode(x), T), B, secs,
+        "encodec48k", enc_check)
+    m.dispose()
+
+    # C5 per-GPU share (8 x 5 s) and C1 (1 x 1 s)
+    for key, cfg, B, secs, label in (("snac44k", SNACConfig.snac_44khz(), 8, 5.0, "SNAC 44.1kHz + LocalMHA encode+decode, batch=8 x 5 s = one GPU's share of BASELINE configs[4]"),
+                                     ("snac24k", SNACConfig.snac_24khz(), 1, 1.0, "SNAC 24kHz mono encode+decode, 1 x 1 s (BASELINE configs[0])")):
+        blob = save_blob(snac_synthetic_state_dict(cfg, seed=42))
+        m = SNAC(cfg)
+        m.load_blob(blob)
+        T = int(secs * cfg.sampling_rate)
+        xh = synthetic_pcm(B, 1, T, cfg.sampling_rate, seed=1234)
+        x = torch.from_numpy(xh).to(dev)
+        frames = m.query(T)[1]
+        nzh = snac_noise(cfg, B, frames, seed=3)
+        nz = [torch.from_numpy(n).to(dev) for n in nzh]
+
+        def snac_check(cfg=cfg, blob=blob, m=m, x=x, xh=xh, nz=nz, nzh=nzh):
+            from oracle import c_oracle
+            ref = c_oracle.RefSNAC(cfg, blob)
+            codes = m.encode(x)
+            au = m.decode(codes, nz)
+            _, _, rcodes = ref.encode(xh[:1])
+            rau = ref.decode(rcodes, [n[:1] for n in nzh])
+            ok = all(np.array_equal(c[:1].cpu().numpy(), r) for c, r in zip(codes, rcodes))
+            return {"clips": 1, "codes_bit_exact": bool(ok), "pcm_max_abs_diff": float(np.abs(au[:1].cpu().numpy() - rau).max())}
+
+        run(label, m, lambda m=m, x=x, nz=nz: m.decode(m.encode(x), nz), B, secs, key, snac_check)
+        m.dispose()
+    return out
+
+
+def aten_proxy(cfg, blob_sd, pcm_h, seconds):
+    """The DAC graph as a sequence of ATen CPU operators (our torch restatement of the C# graph: F.conv1d / conv_transpose1d,
+    element-wise Snake, per-call weight-norm) -- what TorchSharp-CPU dispatches to.  A reported baseline only."""
+    import torch
+    from oracle.torch_ref.dac import TorchDAC
+    m = TorchDAC(cfg, blob_sd)
+    n = pcm_h.shape[0]
+    with torch.inference_mode():
+        t0 = time.perf_counter()
+        out = m.encode(torch.from_numpy(pcm_h))
+        m.decode(out[0])
+        dt = time.perf_counter() - t0
+    cpu = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(n * seconds / dt, 4), "unit": "audio-seconds/sec", "threads": int(torch.get_num_threads()), "cpu": cpu,
+            "sample": f"{n} clips, one cold encode+decode pass through ATen CPU ops (oracle/torch_ref/dac.py), {dt:.2f} s"}
 
 
 def main():
@@ -34,17 +190,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
-    ap.add_argument("--seconds", type=float, default=1.0)
+    ap.add_argument("--config", default="dac44k", choices=("dac44k", "snac44k"), help="dac44k = BASELINE C2/C4 (headline); snac44k = C5 share per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default: 32 for dac44k, 8 for snac44k)")
+    ap.add_argument("--seconds", type=float, default=0.0, help="clip length (default: 1 s for dac44k, 5 s for snac44k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=8, help="clips in the bounded CPU-baseline sample")
-    ap.add_argument("--check", action="store_true", help="verify clip 0 of the last step against the oracle")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs block (C3 / C5 share / C1)")
+    ap.add_argument("--no-check", action="store_true", help="skip the GPU == oracle comparisons (outside the timed region)")
+    ap.add_argument("--check", action="store_true", help="(default now) kept for compatibility")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from neuralcodecs_amd import DAC, DACConfig
-    from neuralcodecs_amd.weights import dac_synthetic_state_dict, save_blob, synthetic_pcm
+    from neuralcodecs_amd import DAC, SNAC, DACConfig
+    from neuralcodecs_amd.config import SNACConfig
+    from neuralcodecs_amd.weights import dac_synthetic_state_dict, save_blob, snac_noise, snac_synthetic_state_dict, synthetic_pcm
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -61,35 +221,66 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    cfg = DACConfig.dac_44khz()
-    T = int(round(args.seconds * cfg.sample_rate))
-    B = args.batch
-    blob = save_blob(dac_synthetic_state_dict(cfg, seed=42))
-    model = DAC(cfg, device_index=local_rank)
-    model.load_blob(blob)
-
-    # synthetic clips (seed 1234 + global clip index), resident in HBM before the timed region
-    pcm_h = synthetic_pcm(B, 1, T, cfg.sample_rate, seed=1234 + rank * B)
-    pcm = torch.from_numpy(pcm_h).to(dev)
-    Tz = model.frames(T)
-    gathered = torch.empty((world * B, cfg.n_codebooks, Tz), dtype=torch.int64, device=dev) if use_dist else None
+    from neuralcodecs_amd import parallel
+    snac_mode = args.config == "snac44k"
+    B = args.batch or (8 if snac_mode else 32)
+    seconds = args.seconds or (5.0 if snac_mode else 1.0)
     side = torch.cuda.Stream(device=dev) if use_dist else None
 
-    from neuralcodecs_amd import parallel
+    if snac_mode:
+        cfg = SNACConfig.snac_44khz()
+        sd = snac_synthetic_state_dict(cfg, seed=42)
+        blob = save_blob(sd)
+        model = SNAC(cfg, device_index=local_rank)
+        model.load_blob(blob)
+        T = int(round(seconds * cfg.sampling_rate))
+        pcm_h = synthetic_pcm(B, 1, T, cfg.sampling_rate, seed=1234 + rank * B)
+        pcm = torch.from_numpy(pcm_h).to(dev)
+        Tz = model.query(T)[1]
+        widths = model.query(T)[2]
+        noise_h = snac_noise(cfg, B, Tz, seed=3 + rank)
+        noise = [torch.from_numpy(n).to(dev) for n in noise_h]
+        gathered = torch.empty((world * B, sum(widths)), dtype=torch.int64, device=dev) if use_dist else None
 
-    def step():
-        z, codes, lat, _, _ = model.encode(pcm)
-        if use_dist:
-            # all-gather the emitted codes on a side stream; the local decode only needs local z
-            ev = torch.cuda.Event()
-            ev.record()
-            with torch.cuda.stream(side):
-                side.wait_event(ev)
-                parallel.all_gather_codes(codes, world * B, out=gathered)
-        audio = model.decode(z)
-        if use_dist:
-            torch.cuda.current_stream().wait_stream(side)
-        return codes, z, audio
+        def step():
+            codes = model.encode(pcm)
+            if use_dist:
+                # the four code levels of a clip travel as ONE collective (levels side by side, as the C ABI emits them)
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    parallel.all_gather_levels(codes, world * B, out=gathered)
+            audio = model.decode(codes, noise)
+            if use_dist:
+                torch.cuda.current_stream().wait_stream(side)
+            return codes, None, audio
+    else:
+        cfg = DACConfig.dac_44khz()
+        sd = dac_synthetic_state_dict(cfg, seed=42)
+        blob = save_blob(sd)
+        model = DAC(cfg, device_index=local_rank)
+        model.load_blob(blob)
+        T = int(round(seconds * cfg.sample_rate))
+        # synthetic clips (seed 1234 + global clip index), resident in HBM before the timed region
+        pcm_h = synthetic_pcm(B, 1, T, cfg.sample_rate, seed=1234 + rank * B)
+        pcm = torch.from_numpy(pcm_h).to(dev)
+        Tz = model.frames(T)
+        gathered = torch.empty((world * B, cfg.n_codebooks, Tz), dtype=torch.int64, device=dev) if use_dist else None
+
+        def step():
+            z, codes, lat, _, _ = model.encode(pcm)
+            if use_dist:
+                # all-gather the emitted codes on a side stream; the local decode only needs local z
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    parallel.all_gather_codes(codes, world * B, out=gathered)
+            audio = model.decode(z)
+            if use_dist:
+                torch.cuda.current_stream().wait_stream(side)
+            return codes, z, audio
 
     def sync():
         if use_dist:
@@ -113,66 +304,100 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    audio_seconds = world * B * args.seconds * args.steps
+    audio_seconds = world * B * seconds * args.steps
     value = audio_seconds / dt
     ms_per_step = dt / args.steps * 1e3
 
-    out = None
     if rank == 0:
-        k7 = prof["conv_k7"]
-        ach_tflops = (k7["flops"] / (k7["ms"] * 1e-3)) / 1e12 if k7["ms"] > 0 else 0.0
+        classes = class_table(prof, args.steps)
         total_kernel_ms = sum(v["ms"] for v in prof.values())
         total_flops = sum(v["flops"] for v in prof.values())
-        # HBM bytes per launch of the same kernel class from the PMC counters (separate rocprofv3 --pmc passes of this command,
-        # FETCH_SIZE doubled per MI355X_MICROARCH.md; summary committed under profiles/): a measured constant of the build
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_conv_k7.json")
-        if os.path.exists(tpath) and B == 32 and abs(args.seconds - 1.0) < 1e-9:
-            traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
-        roofline = {
-            "kernel": "conv_mfma_kernel<K=7> (dilated k=7 residual-unit conv, fp32 MFMA implicit GEMM)",
-            "bound": "mfma", "achieved": round(ach_tflops, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach_tflops / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_dac_b32.hbm_traffic_pmc.txt)",
-            "algorithmic_bytes_per_launch": round(k7["bytes"] / max(k7["launches"], 1)),
-            "launches_per_step": k7["launches"] / max(args.steps, 1),
-            "avg_launch_ms": k7["ms"] / max(k7["launches"], 1),
-            "flops_per_launch": k7["flops"] / max(k7["launches"], 1),
-            "share_of_kernel_time": round(k7["ms"] / total_kernel_ms, 4) if total_kernel_ms else None,
-            "all_classes": {n: {"ms_per_step": round(v["ms"] / args.steps, 4),
-                                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 3) if v["ms"] > 0 else 0.0,
-                                "algo_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0}
-                            for n, v in prof.items()},
-            "whole_step_tflops": round(total_flops / args.steps / (ms_per_step * 1e-3) / 1e12, 3),
-        }
+        if snac_mode:
+            dom = dominant(classes)
+            roofline = dict(dom, kernel=dom["class"], traffic=None, all_classes=classes,
+                            whole_step_tflops=round(total_flops / args.steps / (ms_per_step * 1e-3) / 1e12, 3))
+            tr = load_traffic("snac44k")
+            if tr:
+                roofline["traffic"] = tr.get(dom["class"], {}).get("hbm_bytes_per_launch")
+        else:
+            k7 = prof["conv_k7"]
+            ach_tflops = (k7["flops"] / (k7["ms"] * 1e-3)) / 1e12 if k7["ms"] > 0 else 0.0
+            tr = load_traffic("dac44k") if (B == 32 and abs(seconds - 1.0) < 1e-9) else None
+            tk7 = (tr or {}).get("conv_k7", {})
+            algo_b = k7["bytes"] / max(k7["launches"], 1)
+            roofline = {
+                "kernel": "conv_mfma_kernel<K=7> (dilated k=7 residual-unit conv, fp32 MFMA implicit GEMM; fused units include their 1x1)",
+                "bound": "mfma", "achieved": round(ach_tflops, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": round(tk7["hbm_bytes_per_launch"]) if tk7 else None,
+                "traffic_unit": "HBM bytes per launch of this class (PMC FETCH_SIZE x2 + WRITE_SIZE over exactly the launches the class counts; profiles/traffic.json)",
+                "traffic_over_algorithmic": round(tk7["hbm_bytes_per_launch"] / algo_b, 3) if tk7 and algo_b else None,
+                "mfma_busy": tk7.get("mfma_busy"),
+                "algorithmic_bytes_per_launch": round(algo_b),
+                "launches_per_step": k7["launches"] / max(args.steps, 1),
+                "avg_launch_ms": k7["ms"] / max(k7["launches"], 1),
+                "flops_per_launch": k7["flops"] / max(k7["launches"], 1),
+                "share_of_kernel_time": round(k7["ms"] / total_kernel_ms, 4) if total_kernel_ms else None,
+                "all_classes": classes,
+                "whole_step_tflops": round(total_flops / args.steps / (ms_per_step * 1e-3) / 1e12, 3),
+            }
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             from oracle import c_oracle
-            ref = c_oracle.RefDAC(cfg, blob)
-            n = max(1, min(args.cpu_clips, B))
+            n = max(1, min(args.cpu_clips if not snac_mode else 1, B))
             tc = time.perf_counter()
-            rz, rcodes, _, _ = ref.encode(pcm_h[:n])
-            raudio = ref.decode(rz)
+            if snac_mode:
+                ref = c_oracle.RefSNAC(cfg, blob)
+                _, _, rcodes = ref.encode(pcm_h[:n])
+                raudio = ref.decode(rcodes, [x[:n] for x in noise_h])
+            else:
+                ref = c_oracle.RefDAC(cfg, blob)
+                rz, rcodes, _, _ = ref.encode(pcm_h[:n])
+                raudio = ref.decode(rz)
             cdt = time.perf_counter() - tc
-            cpu = {"value": round(n * args.seconds / cdt, 4), "unit": "audio-seconds/sec", "cores": int(c_oracle.lib().ref_num_threads()),
+            cpu = {"value": round(n * seconds / cdt, 4), "unit": "audio-seconds/sec", "cores": int(c_oracle.lib().ref_num_threads()),
                    "kind": "port", "sample": f"{n} of the {B} clips of one step (encode+decode, C oracle with OpenMP), {cdt:.2f} s"}
-            if args.check:
-                same_codes = bool(np.array_equal(codes[:n].cpu().numpy(), rcodes))
-                cpu["gpu_equals_oracle"] = {"codes_bit_exact": same_codes,
+            if not args.no_check:
+                if snac_mode:
+                    same_codes = all(np.array_equal(c[:n].cpu().numpy(), r) for c, r in zip(codes, rcodes))
+                else:
+                    same_codes = bool(np.array_equal(codes[:n].cpu().numpy(), rcodes))
+                cpu["gpu_equals_oracle"] = {"clips": n, "codes_bit_exact": bool(same_codes),
                                             "pcm_max_abs_diff": float(np.abs(audio[:n].cpu().numpy() - raudio).max())}
+            if not snac_mode:
+                try:
+                    cpu["aten_proxy"] = aten_proxy(cfg, sd, pcm_h[:min(4, B)], seconds)
+                except Exception as e:   # the proxy is informational: never lose the bench line to it
+                    cpu["aten_proxy"] = {"error": repr(e)}
+        extras = None
+        if world == 1 and not use_dist and not args.no_extra and not snac_mode:
+            try:
+                extras = extra_configs(dev, 5, 2, not args.no_check)
+            except Exception as e:
+                extras = {"error": repr(e)}
+        if snac_mode:
+            metric = "audio-seconds/sec encode+decode (x real-time), SNAC-44.1kHz B=8 x 5 s per GPU"
+            workload = "SNAC 44.1kHz + LocalMHA encode+decode, batch=%d x %.0f s clips per GPU (BASELINE configs[4] share)" % (B, seconds)
+            coll = "RCCL all_gather of int64 codes [B,%d] (4 levels side by side) per rank" % sum(widths)
+        else:
+            metric = "audio-seconds/sec encode+decode (x real-time), DAC-44.1kHz B=32"
+            workload = "DAC 44.1kHz 8kbps encode+decode, batch=%d x %.0f s clips per GPU (BASELINE configs[1])" % (B, seconds)
+            coll = "RCCL all_gather of int64 codes [B,9,87] per rank"
         out = {
-            "metric": "audio-seconds/sec encode+decode (x real-time), DAC-44.1kHz B=32",
+            "metric": metric,
             "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "DAC 44.1kHz 8kbps encode+decode, batch=%d x %.0f s clips per GPU (BASELINE configs[1])" % (B, args.seconds),
-                       "clips_per_gpu": B, "clip_seconds": args.seconds, "global_batch": world * B,
-                       "collective": "RCCL all_gather of int64 codes [B,9,87] per rank" if use_dist else "none"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "config": {"workload": workload, "clips_per_gpu": B, "clip_seconds": seconds, "global_batch": world * B,
+                       "collective": coll if use_dist else "none"},
+            "roofline": roofline, "cpu_baseline": cpu, "extra_configs": extras,
         }
         print(json.dumps(out), flush=True)
-    if use_dist and rank == 0 and args.check:
-        assert torch.equal(gathered[:B], codes), "gathered codes differ from the local codes"
+    if use_dist and rank == 0 and not args.no_check:
+        if snac_mode:
+            assert torch.equal(gathered[:B], torch.cat([c.reshape(B, -1) for c in codes], dim=1)), "gathered codes differ from the local codes"
+        else:
+            assert torch.equal(gathered[:B], codes), "gathered codes differ from the local codes"
     model.dispose()
     if use_dist:
         dist.destroy_process_group()

@@ -271,8 +271,14 @@ typedef enum {
     NC_KC_CONV_UP = 3,   /* transposed (polyphase) up-sampling convolutions */
     NC_KC_CONV_MISC = 4, /* stem / head / k3 / decoder-input convolutions */
     NC_KC_RVQ = 5,       /* codebook argmin + gather kernels */
-    NC_KC_ELEM = 6,      /* HBM-bound element-wise kernels: depthwise conv, norms, pooling, attention windows */
-    NC_KC_COUNT = 7
+    NC_KC_ELEM = 6,      /* HBM-bound element-wise kernels: pooling, RVQ update, pad/activate, scale, embedding sum, overlap-add */
+    NC_KC_DWCONV = 7,    /* depthwise k=7 convolutions (SNAC ResidualUnit.cs:25-60): 8 B per output */
+    NC_KC_NORM = 8,      /* LayerNorm over channels (LocalMHA.cs:56) / GroupNorm(1,C) statistics (NormConv1d.cs:155) */
+    NC_KC_ATTN = 9,      /* windowed rotary attention (LocalMHA.cs:84-113) */
+    NC_KC_LSTM = 10,     /* LSTM recurrence (SLSTM.cs:40-57); the input projections are counted under conv_k1 */
+    NC_KC_STEM = 11,     /* Cin <= 2 stem convolutions (Encoder.cs:31): a streaming store of Cout rows */
+    NC_KC_HEAD = 12,     /* Cout <= 2 PCM-head convolutions (+tanh, Decoder.cs:44-46): a streaming read of Cin rows */
+    NC_KC_COUNT = 13
 } nc_kernel_class;
 
 typedef struct {

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnc_mi355x.so")
 
 NC_OK, NC_EINVAL, NC_ENOTFOUND, NC_ESTATE, NC_EDEVICE, NC_ENOMEM, NC_EUNSUPPORTED = range(7)
-NC_KC_NAMES = ("conv_k7", "conv_k1", "conv_down", "conv_up", "conv_misc", "rvq", "elem")
+NC_KC_NAMES = ("conv_k7", "conv_k1", "conv_down", "conv_up", "conv_misc", "rvq", "elem", "dwconv", "norm", "attn", "lstm", "stem", "head")
 
 
 class NcError(RuntimeError):

@@ -116,4 +116,18 @@ struct Profiler {
     ~Profiler();
 };
 
+// begin/end of one profiled region around a launch (no-op unless the handle's profiler is on)
+struct ProfScope {
+    Profiler* p;
+    hipStream_t s;
+    ProfScope(Profiler* prof, hipStream_t st, int cls, double flops, double bytes) : p(prof && prof->on ? prof : nullptr), s(st) {
+        if (p) p->begin(s, cls, flops, bytes);
+    }
+    ~ProfScope() {
+        if (p) (void)hipEventRecord(p->pending.back().b, s);
+    }
+    ProfScope(const ProfScope&) = delete;
+    ProfScope& operator=(const ProfScope&) = delete;
+};
+
 }  // namespace nc

@@ -488,6 +488,16 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64 * (c.NW + n_prod)), lds, stream, a);
     NC_HIP(hipGetLastError());
     if (prof && prof->on) prof->end(stream);
+    {   // NC_LAUNCH_LOG=<path>: one line per conv-template launch (class, threads, shape) in launch order.  The template serves several
+        // kernel classes under one kernel name; tools/pmc_classes.py zips this log with the rocprofv3 counter rows of the same
+        // kernel name (dispatch order) to attribute HBM traffic / matrix-core busy cycles to exactly the launches a class counts.
+        static FILE* lf = [] { const char* p = std::getenv("NC_LAUNCH_LOG"); return p && p[0] ? std::fopen(p, "w") : (FILE*)nullptr; }();
+        if (lf) {
+            std::fprintf(lf, "conv_mfma %d %lld %d %d %d %lld %d\n", L.kclass, (long long)grid * 64 * (c.NW + n_prod), L.Cin, L.Cout, L.K,
+                         (long long)io.Tin, io.fuse_k1 ? 1 : 0);
+            std::fflush(lf);
+        }
+    }
 }
 
 }  // namespace nc

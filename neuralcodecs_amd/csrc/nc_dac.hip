@@ -99,7 +99,7 @@ void DacModel::load(const Blob& b) {
     use_device();
     char nm[256];
     int d = cfg.encoder_dim;
-    load_wn_conv(b, "encoder.block.0", enc_stem, 1, d, 7, 1, 3, 1, false, NC_KC_CONV_MISC);
+    load_wn_conv(b, "encoder.block.0", enc_stem, 1, d, 7, 1, 3, 1, false, NC_KC_STEM);
     for (int bi = 0; bi < cfg.n_encoder_rates; ++bi) {
         const int s = cfg.encoder_rates[bi];
         for (int u = 0; u < 3; ++u) {
@@ -159,7 +159,7 @@ void DacModel::load(const Blob& b) {
     snprintf(nm, sizeof nm, "decoder.model.%d.alpha", cfg.n_decoder_rates + 1);
     load_alpha(b, nm, out_dim, dec_alpha_out);
     snprintf(nm, sizeof nm, "decoder.model.%d", cfg.n_decoder_rates + 2);
-    load_wn_conv(b, nm, dec_out, out_dim, 1, 7, 1, 3, 1, false, NC_KC_CONV_MISC);
+    load_wn_conv(b, nm, dec_out, out_dim, 1, 7, 1, 3, 1, false, NC_KC_HEAD);
     NC_HIP(hipDeviceSynchronize());
     loaded = true;
 }

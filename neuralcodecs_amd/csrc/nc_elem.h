@@ -13,10 +13,13 @@ struct DwConvLayer {
 };
 void launch_dwconv(const DwConvLayer& L, const float* x, const float* alpha_in, const float* alpha_out, float* y, int B, int64_t T,
                    hipStream_t s, Profiler* prof);
-void launch_avg_pool(const float* x, float* y, int64_t rows, int64_t T, int s, hipStream_t st);
-void launch_rvq_update(const float* q, float* zq, float* residual, int64_t rows, int64_t T, int s, bool first, hipStream_t st);
-void launch_layernorm_ct(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int64_t T, hipStream_t st);
-void launch_local_attn(const float* qkv, const float* cs, const float* sn, float* out, int B, int C, int64_t T, int W, hipStream_t st);
+void launch_avg_pool(const float* x, float* y, int64_t rows, int64_t T, int s, hipStream_t st, Profiler* prof = nullptr);
+void launch_rvq_update(const float* q, float* zq, float* residual, int64_t rows, int64_t T, int s, bool first, hipStream_t st,
+                       Profiler* prof = nullptr);
+void launch_layernorm_ct(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int64_t T, hipStream_t st,
+                         Profiler* prof = nullptr);
+void launch_local_attn(const float* qkv, const float* cs, const float* sn, float* out, int B, int C, int64_t T, int W, hipStream_t st,
+                       Profiler* prof = nullptr);
 void launch_randn(float* out, int64_t n, uint64_t seed, hipStream_t st);
 
 }  // namespace nc

@@ -73,7 +73,7 @@ void launch_dwconv(const DwConvLayer& L, const float* x, const float* alpha_in, 
     if (L.K > DW_MAXK) fail(NC_EUNSUPPORTED, "depthwise kernel size %d > %d", L.K, DW_MAXK);
     const size_t lds = sizeof(float) * (DW_TT + (L.K - 1) * L.dil);
     dim3 grid((unsigned)((T + DW_TT - 1) / DW_TT), (unsigned)L.C, (unsigned)B);
-    if (prof && prof->on) prof->begin(s, NC_KC_ELEM, 2.0 * L.K * L.C * (double)T * B, 8.0 * L.C * (double)T * B);
+    if (prof && prof->on) prof->begin(s, NC_KC_DWCONV, 2.0 * L.K * L.C * (double)T * B, 8.0 * L.C * (double)T * B);
     hipLaunchKernelGGL(dwconv_kernel, grid, dim3(256), lds, s, x, L.w.as<float>(), L.has_bias ? L.bias.as<float>() : nullptr,
                        alpha_in, alpha_out, y, L.C, (int)T, L.K, L.dil, L.pad);
     NC_HIP(hipGetLastError());
@@ -102,8 +102,9 @@ __global__ void avg_pool_kernel(const float* __restrict__ x, float* __restrict__
     for (int j = 1; j < s; ++j) a = a + xp[j];
     y[i] = a / (float)s;
 }
-void launch_avg_pool(const float* x, float* y, int64_t rows, int64_t T, int s, hipStream_t st) {
+void launch_avg_pool(const float* x, float* y, int64_t rows, int64_t T, int s, hipStream_t st, Profiler* prof) {
     const int64_t n = rows * (T / s);
+    ProfScope ps(prof, st, NC_KC_ELEM, (double)rows * T, 4.0 * ((double)rows * T + (double)n));
     hipLaunchKernelGGL(avg_pool_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, rows, T, s);
     NC_HIP(hipGetLastError());
 }
@@ -118,8 +119,10 @@ __global__ void rvq_update_kernel(const float* __restrict__ q, float* __restrict
     zq[i] = first ? qv : zq[i] + qv;
     if (residual) residual[i] = residual[i] - qv;
 }
-void launch_rvq_update(const float* q, float* zq, float* residual, int64_t rows, int64_t T, int s, bool first, hipStream_t st) {
+void launch_rvq_update(const float* q, float* zq, float* residual, int64_t rows, int64_t T, int s, bool first, hipStream_t st,
+                       Profiler* prof) {
     const int64_t n = rows * T;
+    ProfScope ps(prof, st, NC_KC_ELEM, (residual ? 2.0 : 1.0) * n, 4.0 * ((double)n / s + (first ? 1.0 : 2.0) * n + (residual ? 2.0 * n : 0.0)));
     hipLaunchKernelGGL(rvq_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, q, zq, residual, rows, T, s,
                        first ? 1 : 0);
     NC_HIP(hipGetLastError());
@@ -172,8 +175,10 @@ __global__ void layernorm_ct_kernel(const float* __restrict__ x, const float* __
             if (c0 + u < C) yp[(int64_t)(c0 + u) * T] = ((v[u] - muf) * r) * gamma[c0 + u] + beta[c0 + u];
     }
 }
-void launch_layernorm_ct(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int64_t T, hipStream_t st) {
+void launch_layernorm_ct(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int64_t T, hipStream_t st,
+                         Profiler* prof) {
     const int64_t n = (int64_t)B * T;
+    ProfScope ps(prof, st, NC_KC_NORM, 8.0 * C * (double)n, 8.0 * C * (double)n);
     hipLaunchKernelGGL(layernorm_ct_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, x, gamma, beta, y, B, C, T);
     NC_HIP(hipGetLastError());
 }
@@ -238,8 +243,9 @@ __global__ __launch_bounds__(64) void local_attn_kernel(const float* __restrict_
     }
 }
 void launch_local_attn(const float* qkv, const float* cs, const float* sn, float* out, int B, int C, int64_t T, int W,
-                       hipStream_t st) {
+                       hipStream_t st, Profiler* prof) {
     if (W > ATT_W || W <= 0 || T % W != 0 || C % 64 != 0) fail(NC_EUNSUPPORTED, "local attention: window %d / dim %d not supported", W, C);
+    ProfScope ps(prof, st, NC_KC_ATTN, 4.0 * W * C * (double)T * B, 16.0 * C * (double)T * B);
     hipLaunchKernelGGL(local_attn_kernel, dim3((unsigned)(T / W), (unsigned)(C / 64), (unsigned)B), dim3(64), 0, st, qkv, cs, sn, out,
                        C, T, W);
     NC_HIP(hipGetLastError());

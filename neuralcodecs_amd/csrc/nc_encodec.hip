@@ -544,7 +544,7 @@ void EncodecModel::load_sconv(const Blob& b, const std::string& key, SConv& L, i
     }
     if (bias && bias->numel() != Cout) fail(NC_EINVAL, "%s.conv.bias has the wrong length", key.c_str());
     L.K = K; L.stride = stride; L.Cin = Cin; L.Cout = Cout; L.transposed = transposed;
-    L.conv.kclass = transposed ? NC_KC_CONV_UP : (stride > 1 ? NC_KC_CONV_DOWN : (K == 1 ? NC_KC_CONV_K1 : NC_KC_CONV_MISC));
+    L.conv.kclass = transposed ? NC_KC_CONV_UP : (stride > 1 ? NC_KC_CONV_DOWN : (K == 1 ? NC_KC_CONV_K1 : (Cin <= 2 ? NC_KC_STEM : (Cout <= 2 ? NC_KC_HEAD : NC_KC_CONV_MISC))));
     L.conv.build(dense, bias ? static_cast<const float*>(bias->data) : nullptr, Cin, Cout, K, stride, 0, 1, 0, transposed);
     if (cfg.time_group_norm) {
         const BlobTensor& gw = b.get(key + ".norm.weight");
@@ -759,7 +759,7 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
         NC_HIP(hipMemsetAsync(cs, 0, (size_t)C * N * 4, stream));
         out = alloc((size_t)N * C * T);
         const bool last = li + 1 == l.layers.size();
-        if (prof.on) prof.begin(stream, NC_KC_ELEM, 2.0 * 4 * C * C * (double)N * T, 0.0);
+        if (prof.on) prof.begin(stream, NC_KC_LSTM, 2.0 * 4 * C * C * (double)N * T, 4.0 * 6 * C * (double)N * T);
         static const bool scalar_lstm = std::getenv("NC_LSTM_SCALAR") && std::getenv("NC_LSTM_SCALAR")[0] == '1';
         for (int64_t t = 0; t < T; ++t) {
             static const bool no_lds_lstm = std::getenv("NC_LSTM_CHUNKED") && std::getenv("NC_LSTM_CHUNKED")[0] == '1';

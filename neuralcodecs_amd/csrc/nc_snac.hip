@@ -133,7 +133,7 @@ void SnacModel::load(const Blob& b) {
     use_device();
     char nm[256];
     int d = cfg.encoder_dim;
-    load_dense(b, "encoder.block.0", enc_stem, 1, d, 7, 1, 3, 1, 0, false, NC_KC_CONV_MISC);
+    load_dense(b, "encoder.block.0", enc_stem, 1, d, 7, 1, 3, 1, 0, false, NC_KC_STEM);
     static const int kDil[3] = {1, 3, 9};
     for (int bi = 0; bi < cfg.n_encoder_rates; ++bi) {
         const int s = cfg.encoder_rates[bi];
@@ -208,7 +208,7 @@ void SnacModel::load(const Blob& b) {
     snprintf(nm, sizeof nm, "decoder.model.%d.alpha", n);
     load_vec(b, nm, out_dim, dec_alpha_out);
     snprintf(nm, sizeof nm, "decoder.model.%d", n + 1);
-    load_dense(b, nm, dec_out, out_dim, 1, 7, 1, 3, 1, 0, false, NC_KC_CONV_MISC);
+    load_dense(b, nm, dec_out, out_dim, 1, 7, 1, 3, 1, 0, false, NC_KC_HEAD);
     NC_HIP(hipDeviceSynchronize());
     loaded = true;
 }
@@ -262,10 +262,10 @@ float* SnacModel::run_mha(Mha& m, float* cur, int C, int64_t L, int B, int& cur_
     float* xn = act[n_idx].as<float>();
     float* o = act[o_idx].as<float>();
     qkv_ws.reserve((size_t)B * 3 * C * L * 4);
-    launch_layernorm_ct(cur, m.gamma.as<float>(), m.beta.as<float>(), xn, B, C, L, stream);
+    launch_layernorm_ct(cur, m.gamma.as<float>(), m.beta.as<float>(), xn, B, C, L, stream, &prof);
     ConvIO iq = io_for(xn, C, L, qkv_ws.as<float>(), 3 * C, L);
     launch_conv(m.qkv, iq, B, stream, &prof);
-    launch_local_attn(qkv_ws.as<float>(), m.cs.as<float>(), m.sn.as<float>(), xn, B, C, L, cfg.attn_window_size, stream);
+    launch_local_attn(qkv_ws.as<float>(), m.cs.as<float>(), m.sn.as<float>(), xn, B, C, L, cfg.attn_window_size, stream, &prof);
     ConvIO io = io_for(xn, C, L, o, C, L);
     io.res = cur; io.alpha_out = alpha_next;
     launch_conv(m.out, io, B, stream, &prof);
@@ -366,7 +366,7 @@ void SnacModel::encode_dev(const float* pcm, int B, int64_t T, int64_t* codes, f
         const int64_t Ts = Tz / s;
         const float* src = residual;
         if (s > 1) {
-            launch_avg_pool(residual, pooled.as<float>(), (int64_t)B * latent, Tz, s, stream);
+            launch_avg_pool(residual, pooled.as<float>(), (int64_t)B * latent, Tz, s, stream, &prof);
             src = pooled.as<float>();
         }
         ConvIO pi = io_for(src, latent, Ts, lat.as<float>(), D, Ts);
@@ -374,7 +374,7 @@ void SnacModel::encode_dev(const float* pcm, int B, int64_t T, int64_t* codes, f
         launch_vq_argmin(*codebooks[i], lat.as<float>(), (int64_t)D * Ts, B, Ts, codes + off, total, st.as<float>(), stream, &prof);
         ConvIO po = io_for(st.as<float>(), D, Ts, qbuf.as<float>(), latent, Ts);
         launch_conv(*out_proj[i], po, B, stream, &prof);
-        launch_rvq_update(qbuf.as<float>(), zq_d, residual, (int64_t)B * latent, Tz, s, false, stream);
+        launch_rvq_update(qbuf.as<float>(), zq_d, residual, (int64_t)B * latent, Tz, s, false, stream, &prof);
         off += Ts;
     }
 }
@@ -399,7 +399,7 @@ void SnacModel::from_codes_dev(const int64_t* codes, int B, int64_t Tz, float* z
         launch_vq_gather(*codebooks[i], codes + off, total, B, Ts, st.as<float>(), stream, &prof);
         ConvIO po = io_for(st.as<float>(), D, Ts, qbuf.as<float>(), latent, Ts);
         launch_conv(*out_proj[i], po, B, stream, &prof);
-        launch_rvq_update(qbuf.as<float>(), zq_out, nullptr, (int64_t)B * latent, Tz, s, i == 0, stream);
+        launch_rvq_update(qbuf.as<float>(), zq_out, nullptr, (int64_t)B * latent, Tz, s, i == 0, stream, &prof);
         off += Ts;
     }
 }

@@ -57,6 +57,13 @@ def concat_levels(levels: Sequence, ) -> Tuple["object", List[int]]:
     return torch.cat([l.reshape(l.shape[0], -1) for l in levels], dim=-1), widths
 
 
+def all_gather_levels(levels: Sequence, n_clips: int, group=None, out=None):
+    """SNAC.Encode's List<Tensor> (SNAC.cs:113-150) of this rank -> the [n_clips, sum(widths)] tensor of all ranks (levels of a clip
+    side by side, the layout nc_snac_encode emits): one collective for all levels.  split_levels(result, widths) restores the list."""
+    flat, _ = concat_levels(levels)
+    return all_gather_codes(flat.contiguous(), n_clips, group=group, out=out)
+
+
 def split_levels(flat, widths: Sequence[int]):
     out, o = [], 0
     for w in widths:

@@ -53,6 +53,10 @@ def _worker(rank, world, port, n_clips, out_dir):
     flat, widths = parallel.concat_levels([gathered[:, 0, :], gathered[:, 1, :3]])
     lv = parallel.split_levels(flat, widths)
     assert torch.equal(lv[0], gathered[:, 0, :]) and torch.equal(lv[1], gathered[:, 1, :3])
+    # SNAC-style level lists: this rank's levels -> one collective -> every rank holds all clips' levels in clip order
+    mine = [torch.from_numpy(codes[:, 0, :]), torch.from_numpy(codes[:, 1, :3])]
+    allv = parallel.split_levels(parallel.all_gather_levels(mine, n_clips), [codes.shape[-1], 3])
+    assert torch.equal(allv[0], gathered[:, 0, :]) and torch.equal(allv[1], gathered[:, 1, :3])
     if rank == 0:
         _, full, _, _ = ref.encode(pcm)
         np.save(os.path.join(out_dir, "ok.npy"), np.array([int(np.array_equal(gathered.numpy(), full))]))

@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Per kernel-class HBM traffic and matrix-core busy fraction from rocprofv3 --pmc passes of a bench command.
+
+    NC_LAUNCH_LOG=gpurun_out/X/launch_<pass>.log rocprofv3 --pmc FETCH_SIZE --kernel-trace ... -- python3 bench.py ...   (one pass per counter set)
+    python tools/pmc_classes.py --key dac44k --out profiles/traffic.json \
+        fetch=<dir>/p_counter_collection.csv:<launch log>  write=<dir>/...:<log>  sq=<dir>/...:<log>
+
+Every dispatch is assigned a kernel class: by kernel name (dwconv_kernel -> dwconv, conv_thin_kernel -> head, ...) and, for the
+implicit-GEMM template that serves several classes under one name, by zipping the engine's launch log (NC_LAUNCH_LOG, one line
+per template launch in launch order) with the template's counter rows in dispatch order (thread counts must agree).
+FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH is doubled (gfx950 tallies 128-B read requests as 64 B,
+MI355X_MICROARCH.md "HBM").  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES): SQ_BUSY_CU_CYCLES sums, over
+the CUs, the cycles a CU had a wave resident; the MFMA counter sums busy cycles over the SIMDs.
+"""
+import argparse
+import csv
+import json
+import os
+import re
+import sys
+from collections import OrderedDict, defaultdict
+
+KC = ("conv_k7", "conv_k1", "conv_down", "conv_up", "conv_misc", "rvq", "elem", "dwconv", "norm", "attn", "lstm", "stem", "head")
+BY_NAME = [(r"conv1x1_kernel|skinny_proj", "conv_k1"), (r"dwconv_kernel", "dwconv"), (r"layernorm_ct|gn_partial|gn_final|gn_", "norm"),
+           (r"local_attn", "attn"), (r"lstm_", "lstm"), (r"stem_", "stem"), (r"conv_thin_kernel", "head"),
+           (r"vq_argmin|vq_gather|euclid_vq|emb_sum", "rvq"),
+           (r"avg_pool|rvq_update|pad_act|scale_kernel|overlap_add|rms_|randn", "elem")]
+
+
+def load(path_csv, path_log):
+    rows = OrderedDict()      # dispatch id -> (name, threads, {counter: value}, start, end)
+    for r in csv.DictReader(open(path_csv)):
+        d = int(r["Dispatch_Id"])
+        e = rows.setdefault(d, [r["Kernel_Name"], int(r["Grid_Size"]), {}, int(r["Start_Timestamp"]), int(r["End_Timestamp"])])
+        e[2][r["Counter_Name"]] = e[2].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    log = [l.split() for l in open(path_log)] if path_log and os.path.exists(path_log) else []
+    li = 0
+    out = []
+    for d in sorted(rows):
+        name, threads, ctr, t0, t1 = rows[d]
+        cls = None
+        if "conv_mfma_kernel" in name:
+            if li < len(log):
+                rec = log[li]
+                li += 1
+                if int(rec[2]) != threads:
+                    raise SystemExit(f"launch log out of step at dispatch {d}: log says {rec[2]} threads, trace {threads}")
+                cls = KC[int(rec[1])]
+            else:
+                cls = "conv_misc"
+        else:
+            for pat, c in BY_NAME:
+                if re.search(pat, name):
+                    cls = c
+                    break
+        if cls:
+            out.append((cls, name, threads, ctr, t1 - t0))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--key", required=True)
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--skip-frac", type=float, default=0.0, help="drop this leading fraction of every class's launches (warm-up)")
+    ap.add_argument("passes", nargs="+")
+    a = ap.parse_args()
+    acc = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(lambda: defaultdict(int))
+    for p in a.passes:
+        tag, rest = p.split("=", 1)
+        path_csv, _, path_log = rest.partition(":")
+        for cls, name, threads, ctr, dur in load(path_csv, path_log):
+            for k, v in ctr.items():
+                acc[cls][k] += v
+                cnt[cls][k] += 1
+            acc[cls]["dur_ns:" + tag] += dur
+            cnt[cls]["dur_ns:" + tag] += 1
+    res = {}
+    for cls in acc:
+        e = {}
+        n = max(cnt[cls].values())
+        e["launches_profiled"] = n
+        f = acc[cls].get("FETCH_SIZE")
+        w = acc[cls].get("WRITE_SIZE")
+        if f is not None:
+            e["fetch_KiB_per_launch"] = f / cnt[cls]["FETCH_SIZE"]
+        if w is not None:
+            e["write_KiB_per_launch"] = w / cnt[cls]["WRITE_SIZE"]
+        if f is not None and w is not None:
+            e["hbm_bytes_per_launch"] = (2 * e["fetch_KiB_per_launch"] + e["write_KiB_per_launch"]) * 1024
+        mb, bc = acc[cls].get("SQ_VALU_MFMA_BUSY_CYCLES"), acc[cls].get("SQ_BUSY_CU_CYCLES")
+        if mb is not None and bc:
+            e["mfma_busy"] = round(mb / (4.0 * bc), 4)
+            e["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] = mb / cnt[cls]["SQ_VALU_MFMA_BUSY_CYCLES"]
+            e["SQ_BUSY_CU_CYCLES_per_launch"] = bc / cnt[cls]["SQ_BUSY_CU_CYCLES"]
+        res[cls] = e
+    res["_method"] = ("rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES, kernel trace only) of the bench "
+                      "command; classes by kernel name + engine launch log (tools/pmc_classes.py); FETCH doubled per MI355X_MICROARCH.md")
+    allj = {}
+    if os.path.exists(a.out):
+        allj = json.load(open(a.out))
+    allj[a.key] = res
+    json.dump(allj, open(a.out, "w"), indent=1, sort_keys=True)
+    for cls, e in sorted(res.items()):
+        if cls.startswith("_"):
+            continue
+        print(cls, json.dumps(e))
+
+
+if __name__ == "__main__":
+    main()
