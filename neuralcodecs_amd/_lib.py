@@ -163,3 +163,19 @@ def check(status: int) -> None:
     if status == NC_EDEVICE:
         raise NcDeviceError(msg)
     raise NcError(f"status {status}: {msg}")
+
+
+class ProfileMixin:
+    """HIP-event kernel-class profile of a codec handle (nc_codec_profile_*): the numbers bench.py's `roofline` objects come from."""
+
+    def profile_enable(self, on: bool = True):
+        check(lib().nc_codec_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        check(lib().nc_codec_profile_reset(self._h))
+
+    def profile_read(self):
+        arr = (NcProfileEntry * len(NC_KC_NAMES))()
+        check(lib().nc_codec_profile_read(self._h, arr))
+        return {n: {"launches": arr[i].launches, "ms": arr[i].ms, "flops": arr[i].flops, "bytes": arr[i].bytes}
+                for i, n in enumerate(NC_KC_NAMES)}

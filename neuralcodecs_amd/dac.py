@@ -32,7 +32,7 @@ def _is_torch(x) -> bool:
     return type(x).__module__.startswith("torch")
 
 
-class DAC:
+class DAC(_lib.ProfileMixin):
     def __init__(self, config: Optional[DACConfig] = None, device_index: int = 0):
         if config is None:
             raise ValueError("config must not be null")  # ArgumentNullException.ThrowIfNull(config)
@@ -239,14 +239,3 @@ class DAC:
         return self.forward(x)["audio"].reshape(-1)
 
     # ---- profiling (bench.py) ----------------------------------------------------------------
-    def profile_enable(self, on: bool = True):
-        _lib.check(_lib.lib().nc_codec_profile_enable(self._h, 1 if on else 0))
-
-    def profile_reset(self):
-        _lib.check(_lib.lib().nc_codec_profile_reset(self._h))
-
-    def profile_read(self):
-        arr = (_lib.NcProfileEntry * len(_lib.NC_KC_NAMES))()
-        _lib.check(_lib.lib().nc_codec_profile_read(self._h, arr))
-        return {n: {"launches": arr[i].launches, "ms": arr[i].ms, "flops": arr[i].flops, "bytes": arr[i].bytes}
-                for i, n in enumerate(_lib.NC_KC_NAMES)}

@@ -39,7 +39,7 @@ class EncodedFrame:
     scale: Optional[object] = None
 
 
-class Encodec:
+class Encodec(_lib.ProfileMixin):
     def __init__(self, config: Optional[EncodecConfig] = None, device_index: int = 0):
         if config is None:
             raise ValueError("config must not be null")

@@ -32,7 +32,7 @@ def _is_torch(x) -> bool:
     return type(x).__module__.startswith("torch")
 
 
-class SNAC:
+class SNAC(_lib.ProfileMixin):
     def __init__(self, config: Optional[SNACConfig] = None, device_index: int = 0):
         if config is None:
             raise ValueError("config must not be null")
