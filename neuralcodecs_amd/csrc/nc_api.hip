@@ -135,6 +135,7 @@ nc_status nc_codec_synchronize(nc_codec* h) {
         if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");
         h->impl->use_device();
         NC_HIP(hipStreamSynchronize(h->impl->stream));
+        h->impl->check_async_errors();
     });
 }
 
@@ -401,6 +402,7 @@ nc_status nc_encodec_encode(nc_codec* h, const float* pcm, int32_t B, int64_t T,
         if (scales && m.cfg.normalize) d2h(scales, m.h_scales.p, n_sc, m.stream);
         if (emb) d2h(emb, m.h_emb.p, n_emb, m.stream);
         NC_HIP(hipStreamSynchronize(m.stream));
+        m.check_async_errors();
     });
 }
 
@@ -424,6 +426,7 @@ nc_status nc_encodec_decode(nc_codec* h, const int64_t* codes, const float* scal
         m.decode_dev(m.h_codes.as<int64_t>(), scales ? m.h_scales.as<float>() : nullptr, B, T, n_q, m.h_out.as<float>());
         d2h(pcm, m.h_out.p, n_out, m.stream);
         NC_HIP(hipStreamSynchronize(m.stream));
+        m.check_async_errors();
     });
 }
 

@@ -55,6 +55,13 @@ struct ConvArgs {
     int32_t tapoff[16];            // window slot of tap k at column 0 (phase de-interleave folded in)
     int32_t epi;
     int32_t ep_off;                // float offset in LDS of the per-row epilogue table (bias, Snake alpha, 1/alpha [, fused set])
+    // Encodec input mode (SConv1d.cs:144-173 fused into the tile load): the input is a RAW conv output whose GroupNorm(1,C) is still
+    // pending; the staged value is  pad(elu?(gn?(x)))  with the asymmetric reflect pad of SConv1d.Pad1d evaluated as an index map.
+    int32_t in_mode;               // 0 off; bit 0: GroupNorm affine ((x-mu)*r)*gamma+beta; bit 1: ELU; bit 2: reflect addressing
+    const float* in_stats;         // [B][2] (mean, rstd) per sample (bit 0)
+    const float* in_gamma;         // [Cin]
+    const float* in_beta;          // [Cin]
+    int32_t in_left, in_Lz, in_L;  // bit 2: padded position j reads q = reflect(j - left) over [0,Lz); samples q >= L are the zero extension (D9)
 };
 
 // Position of row (32*i + r) of a weight tile inside one kk row of BM = 32*TM floats.  The TM values of one matrix-core lane
@@ -118,6 +125,13 @@ struct ConvIO {
     float* rvq_res = nullptr;
     const float* noise = nullptr;  // EPI_NOISE multiplier [B,1,Tout]
     int epi = 0;
+    // Encodec input mode (see ConvArgs::in_mode): with in_L > 0 the tensor handed in is the UN-padded row of in_L samples and
+    // Tin / x_len describe the padded row the convolution runs over
+    const float* in_stats = nullptr;
+    const float* in_gamma = nullptr;
+    const float* in_beta = nullptr;
+    bool in_elu = false;
+    int64_t in_left = 0, in_Lz = 0, in_L = 0;
     const float* alpha_out2 = nullptr;          // with fuse_k1: Snake applied to the unit's output y (consumer's activation)
     const struct ConvLayer* fuse_k1 = nullptr;  // fused residual unit: the 1x1 layer applied to snake(alpha_out)(this conv) + res
 };

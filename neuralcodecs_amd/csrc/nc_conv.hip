@@ -283,8 +283,11 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
     auto al8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; };
     if (!al8(io.x) || !al8(io.y) || (io.res && !al8(io.res)) || (io.noise && !al8(io.noise))) return false;
     if ((io.epi & EPI_NOISE) && (!io.noise || !io.res)) return false;
+    const int in_mode = (io.in_stats ? 1 : 0) | (io.in_elu ? 2 : 0);
+    if (io.in_L > 0) return false;   // (reflect addressing: the windowed template)
+    if (in_mode && (io.res || io.alpha_out || io.epi || L.Cin > 512)) return false;
     const TileChoice tc = choose_tile(L, (int64_t)B * ((T + 255) / 256), true);
-    const int mode = (io.epi & EPI_NOISE) ? 4 : ((io.res ? 1 : 0) | (io.alpha_out ? 2 : 0));
+    const int mode = in_mode ? 8 : (io.epi & EPI_NOISE) ? 4 : ((io.res ? 1 : 0) | (io.alpha_out ? 2 : 0));
     conv_kernel_fn fn = conv1x1_kernel_table(tc.cfg.TM, mode);
     if (!fn) return false;
     ConvArgs a{};
@@ -293,6 +296,7 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
     a.bias = L.has_bias ? L.bias.as<float>() : nullptr;
     a.res = io.res; a.noise = io.noise; a.noise_bstride = T; a.epi = io.epi; a.alpha_out = io.alpha_out;
     a.y = io.y; a.y_bstride = io.y_bstride; a.y_cstride = io.y_cstride;
+    a.in_mode = in_mode; a.in_stats = io.in_stats; a.in_gamma = io.in_gamma; a.in_beta = io.in_beta;
     a.Cout = L.Cout; a.B = B; a.Tout = (int32_t)T;
     const int BM = tc.cfg.BM();
     a.n_co_tiles = (L.Cout + BM - 1) / BM;
@@ -311,7 +315,9 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
 
 void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream, Profiler* prof) {
     static const bool no_skinny = std::getenv("NC_NO_SKINNY") && std::getenv("NC_NO_SKINNY")[0] == '1';
-    if (L.w_skinny.p && !no_skinny && !io.alpha_in && !io.alpha_out && !io.res && io.epi == 0 && !io.fuse_k1 && io.x_len == io.Tin) {
+    const int in_mode = (io.in_stats ? 1 : 0) | (io.in_elu ? 2 : 0) | (io.in_L > 0 ? 4 : 0);
+    if (in_mode && (io.alpha_in || io.fuse_k1)) fail(NC_ESTATE, "internal: the Encodec input mode does not combine with Snake / fused units");
+    if (L.w_skinny.p && !no_skinny && !in_mode && !io.alpha_in && !io.alpha_out && !io.res && io.epi == 0 && !io.fuse_k1 && io.x_len == io.Tin) {
         if (prof && prof->on)
             prof->begin(stream, L.kclass, L.flops(B, io.Tin), 4.0 * ((double)B * L.Cin * io.Tin + (double)B * L.Cout * io.Tin + (double)L.Cin * L.Cout));
         launch_skinny_proj(io.x, io.x_bstride, io.x_cstride, L.w_skinny.as<float>(), L.has_bias ? L.bias.as<float>() : nullptr, io.y,
@@ -321,7 +327,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     }
     {   // thin-output layers (PCM heads): streaming kernel instead of a 32-row matrix tile with 1-2 live rows
         static const bool no_thin = std::getenv("NC_NO_THIN") && std::getenv("NC_NO_THIN")[0] == '1';
-        if (L.w_thin.p && !no_thin && !io.alpha_in && !io.alpha_out && !io.res && !io.fuse_k1 && (io.epi & ~EPI_TANH) == 0) {
+        if (L.w_thin.p && !no_thin && !in_mode && !io.alpha_in && !io.alpha_out && !io.res && !io.fuse_k1 && (io.epi & ~EPI_TANH) == 0) {
             const int64_t Tout = L.out_len(io.Tin);
             if (prof && prof->on)
                 prof->begin(stream, L.kclass, L.flops(B, io.Tin), 4.0 * ((double)B * L.Cin * io.Tin + (double)B * L.Cout * Tout + (double)L.Cin * L.Cout * L.K));
@@ -399,6 +405,8 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     ConvArgs a{};
     a.x = io.x; a.x_bstride = io.x_bstride; a.x_cstride = io.x_cstride; a.Cin = L.Cin; a.x_len = io.x_len;
     a.alpha_in = io.alpha_in;
+    a.in_mode = in_mode; a.in_stats = io.in_stats; a.in_gamma = io.in_gamma; a.in_beta = io.in_beta;
+    a.in_left = (int32_t)io.in_left; a.in_Lz = (int32_t)io.in_Lz; a.in_L = (int32_t)io.in_L;
     a.w = tsel.w; a.w_phase_stride = tsel.w_phase_stride;
     a.bias = L.has_bias ? L.bias.as<float>() : nullptr;
     a.alpha_out = io.alpha_out; a.res = io.res;
@@ -442,7 +450,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         const int q = k * a.dil + a.xneg;
         a.tapoff[k] = (k < L.Ktaps) ? (sx == 1 ? q : (q % sx) * a.xwp + q / sx) : 0;
     }
-    size_t lds_f = 2 * (size_t)KB * BM + 2 * (size_t)a.xbuf + (io.alpha_in ? 2 * (size_t)a.n_cb * CB : 0);
+    size_t lds_f = 2 * (size_t)KB * BM + 2 * (size_t)a.xbuf + ((io.alpha_in || (in_mode & 1)) ? 2 * (size_t)a.n_cb * CB : 0);
     if (io.fuse_k1) lds_f = std::max(lds_f, (size_t)BM * BM);   // the 1x1 weights reuse the tile buffers
     a.ep_off = (int32_t)lds_f;
     size_t lds = sizeof(float) * (lds_f + 6 * (size_t)BM);

@@ -39,7 +39,9 @@ constexpr int conv1x1_occupancy(int TM) { return TM == 1 ? 6 : TM == 2 ? 5 : 3; 
 
 // MODE: epilogue of this instantiation, chosen at launch (bit 0: residual, bit 1: Snake of the consuming layer, bit 2: noise
 // injection y = res + noise * conv): one straight-line epilogue per kernel keeps the register budget.
-template <int TM, int CB, int MODE>
+// INM: Encodec input mode (ConvArgs::in_mode bits 0/1): the B fragments are raw conv outputs with a pending GroupNorm(1,C) and ELU,
+// applied to the fragment registers right before they feed the matrix cores (a 1x1 has no padding, so no reflect map here).
+template <int TM, int CB, int MODE, bool INM = false>
 __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(const ConvArgs p) {
     constexpr int TN = 2;
     constexpr int BM = 32 * TM;
@@ -54,6 +56,7 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
 
     __shared__ __attribute__((aligned(16))) float As[2][A_FLOATS];
     __shared__ float Ep[3 * BM];   // per-row epilogue operands of this tile: bias, Snake alpha, 1/alpha
+    __shared__ float2 Gt[INM ? 512 : 1];   // INM: (gamma, beta) of the pending GroupNorm per input channel (Cin <= 512)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -82,6 +85,15 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
 
     const int T = p.Tout;
     const int n_cb = p.n_cb, Cin = p.Cin;
+    const int in_mode = INM ? p.in_mode : 0;
+    float in_mu = 0.0f, in_rs = 1.0f;
+    if constexpr (INM) {
+        if (in_mode & 1) {
+            in_mu = p.in_stats[2 * b];
+            in_rs = p.in_stats[2 * b + 1];
+            for (int i = tid; i < n_cb * CB; i += 256) Gt[i] = make_float2(p.in_gamma[min(i, Cin - 1)], p.in_beta[min(i, Cin - 1)]);
+        }
+    }
     const unsigned x_cstride = (unsigned)p.x_cstride;
     const int col = t_tile * BN + wave * BNW + TN * l31;          // first of this lane's TN columns
     const int colc = min(col, T - TN);                             // clamped (T % TN == 0, T >= TN): loads stay inside the row
@@ -134,7 +146,18 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
         for (int kp = 0; kp < KP; ++kp) {
             float a[TM];
             nc_load_a_frag<TM>(Ac + 2 * kp * BM, l31, a);
-            const f32x2 bv = bq[kp % PF];
+            f32x2 bv = bq[kp % PF];
+            if constexpr (INM) {
+                if (in_mode & 1) {
+                    const float2 gb = Gt[2 * (cb * KP + kp) + hi];
+                    bv[0] = ((bv[0] - in_mu) * in_rs) * gb.x + gb.y;
+                    bv[1] = ((bv[1] - in_mu) * in_rs) * gb.x + gb.y;
+                }
+                if (in_mode & 2) {
+                    bv[0] = nc_eluf(bv[0]);
+                    bv[1] = nc_eluf(bv[1]);
+                }
+            }
             const int g = cb * KP + kp + PF;
             bq[kp % PF] = load_b(g);   // unconditional (clamped): the step is one basic block
 #pragma unroll
@@ -326,11 +349,12 @@ static conv_kernel_fn conv1x1_by_mode(int mode) {
         case 2: return &conv1x1_kernel<TM, 16, 2>;
         case 3: return &conv1x1_kernel<TM, 16, 3>;
         case 4: return &conv1x1_kernel<TM, 16, 4>;
+        case 8: return &conv1x1_kernel<TM, 16, 0, true>;   // plain epilogue + Encodec input mode
     }
     return nullptr;
 }
 
-// mode: bit 0 residual, bit 1 Snake-out, 4 = noise injection (with residual, no Snake)
+// mode: bit 0 residual, bit 1 Snake-out, 4 = noise injection (with residual, no Snake), 8 = plain epilogue + Encodec input mode
 conv_kernel_fn conv1x1_kernel_table(int TM, int mode) {
     switch (TM) {
         case 1: return conv1x1_by_mode<1>(mode);

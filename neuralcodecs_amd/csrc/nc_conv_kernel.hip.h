@@ -179,6 +179,9 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     const int xwp = p.xwp, xrow = p.xrow, xbuf = p.xbuf, Cin = p.Cin, x_len = p.x_len, n_cb = p.n_cb;
     const unsigned x_cstride = (unsigned)p.x_cstride;
     const float* const alpha_in = p.alpha_in;
+    // Encodec input mode (ConvArgs::in_mode): pending GroupNorm + ELU + reflect pad applied while staging
+    const int in_mode = p.in_mode;
+    const float in_mu = (in_mode & 1) ? p.in_stats[2 * b] : 0.0f, in_rs = (in_mode & 1) ? p.in_stats[2 * b + 1] : 1.0f;
     int tap[K];  // window slot of tap k (wave-uniform scalars)
 #pragma unroll
     for (int k = 0; k < K; ++k) tap[k] = p.tapoff[k];
@@ -198,11 +201,20 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     // the 64 window slots starting at xj[i]; its lanes read x[clamp(xs0 + slot)] = xg[i] of that channel row
     unsigned xg[NX];
     int xc[NX];
+    unsigned okm = 0;   // reflect mode: bit i = window item i of this lane reads a real sample (else the zero extension / tile overrun)
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         const int item = swave + SW * i;
         xc[i] = (item * chunk_magic) >> 20;
-        xg[i] = (unsigned)min(max(xs0 + (item - xc[i] * nchunk) * 64 + lane, 0), x_len - 1);
+        const int gp = xs0 + (item - xc[i] * nchunk) * 64 + lane;
+        xg[i] = (unsigned)min(max(gp, 0), x_len - 1);
+        if (in_mode & 4) {   // SConv1d.Pad1d (SConv1d.cs:258-274): padded position gp -> sample |gp - left| mirrored at Lz - 1
+            int q = gp - p.in_left;
+            q = q < 0 ? -q : q;
+            if (q >= p.in_Lz) q = 2 * (p.in_Lz - 1) - q;
+            if ((gp >= 0) & (gp < x_len) & (q >= 0) & (q < p.in_L)) okm |= 1u << i;
+            xg[i] = (unsigned)min(max(q, 0), p.in_L - 1);
+        }
     }
     auto issue_group_to = [&](int cbn, auto gtag, f32x4 (&ra)[GA], float (&rx)[GX]) __attribute__((always_inline)) {
         constexpr int g = decltype(gtag)::value;
@@ -252,7 +264,8 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     auto store_group_from = [&](int cbn, float* Ad, float* Xd, auto gtag, auto snake_tag, const f32x4 (&ra)[GA],
                                 const float (&rx)[GX]) __attribute__((always_inline)) {
         constexpr int g = decltype(gtag)::value;
-        constexpr bool SNAKE = decltype(snake_tag)::value;
+        constexpr int IMODE = (int)decltype(snake_tag)::value;   // 0 plain, 1 (true_type) Snake, 2 Encodec input mode
+        constexpr bool SNAKE = IMODE == 1;
         nc_static_for<GA>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value, n = g * GA + u;
             if constexpr (n < NA) {
@@ -264,7 +277,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
             }
         });
         float2 al[GX];
-        if (SNAKE) {
+        if (SNAKE || (IMODE == 2 && (in_mode & 1))) {
             nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
                 constexpr int u = decltype(ut)::value, i = g * GX + u;
                 if constexpr (i < NX) {
@@ -283,8 +296,16 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 const int ci = cbn * CB + c;
                 const int j = (item - c * nchunk) * 64 + lane;
                 const int gp = xs0 + j;
-                const bool ok = (ci < Cin) & (gp >= 0) & (gp < x_len);  // slots past xw / items past n_items are never read
-                v[u] = ok ? rx[u] : 0.0f;
+                bool ok = (ci < Cin) & (gp >= 0) & (gp < x_len);  // slots past xw / items past n_items are never read
+                if constexpr (IMODE == 2) {
+                    if (in_mode & 4) ok = (ci < Cin) & (((okm >> i) & 1u) != 0);
+                    float t = rx[u];
+                    if (in_mode & 1) t = ((t - in_mu) * in_rs) * al[u].x + al[u].y;   // GroupNorm(1,C) apply (NormConv1d.cs:155)
+                    if (in_mode & 2) t = nc_eluf(t);
+                    v[u] = ok ? t : 0.0f;                                                // the pad zero-extends the ACTIVATED row
+                } else {
+                    v[u] = ok ? rx[u] : 0.0f;
+                }
                 if (SNAKE) v[u] = nc_snakef(v[u], al[u].x, al[u].y);
                 off[u] = item * 64 + lane;
                 if (s != 1) {
@@ -302,6 +323,9 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         store_group_from(cbn, Ad, Xd, gtag, snake_tag, ra, rx);
     };
     auto store_group_any = [&](int cbn, float* Ad, float* Xd, auto gtag) __attribute__((always_inline)) {
+        if constexpr (!FUSE && !SPEC && !DIST) {
+            if (in_mode) { store_group(cbn, Ad, Xd, gtag, std::integral_constant<int, 2>{}); return; }
+        }
 #ifdef NC_ABL_NOSNAKE
         if (false)
 #else
@@ -338,6 +362,10 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                     if (i0 + tid + u * NT < n_al) Al[i0 + tid + u * NT] = make_float2(av[u], nc_snake_inv(av[u]));
             }
         }
+        if (in_mode & 1) {   // (gamma, beta) of the pending GroupNorm, per input channel, in the Snake table's place
+            const int n_al = n_cb * CB;
+            for (int i = tid; i < n_al; i += NT) Al[i] = make_float2(p.in_gamma[min(i, Cin - 1)], p.in_beta[min(i, Cin - 1)]);
+        }
         for (int i = tid; i < BM; i += NT) {
             const int co = min(co_tile * BM + i, p.Cout - 1);
             const float ao = p.alpha_out ? p.alpha_out[co] : 0.0f;
@@ -355,6 +383,9 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         if (!SPEC || producer)
             nc_static_for<NG>([&](auto g) __attribute__((always_inline)) {
                 constexpr int gi = decltype(g)::value;
+                if constexpr (!FUSE && !SPEC && !DIST) {
+                    if (in_mode) { store_group_from(0, As0, Xs0, g, std::integral_constant<int, 2>{}, ra0[gi], rx0[gi]); return; }
+                }
 #ifdef NC_ABL_NOSNAKE
                 if (false)
 #else

@@ -27,8 +27,6 @@ struct ActView {          // [B,C,L] view of a raw conv output with its pending 
     const float* beta;
 };
 
-__device__ __forceinline__ float nc_eluf(float x) { return x > 0.0f ? x : nc_expf(x) - 1.0f; }
-__device__ __forceinline__ float nc_sigmoidf(float x) { return 1.0f / (1.0f + nc_expf(-x)); }
 
 __device__ __forceinline__ float act_value(const ActView& v, int64_t b, int c, int C, int64_t q) {
     float x = v.p[(b * C + c) * v.rs + v.off + q];
@@ -56,43 +54,48 @@ __global__ void pad_act_kernel(ActView a, ActView b2, int has_b, int elu, float*
     dst[i] = v;
 }
 
-// per 256-sample chunk of one row: binary64 sum and sum of squares, ascending t (the canonical order: one sequential chain per
-// chunk).  A workgroup of 64 threads owns 64 consecutive chunks: their samples are read coalesced (16 reads per thread in flight)
-// into an LDS tile padded to 257 words per chunk, then thread i walks chunk i from LDS (conflict-free) -- the arithmetic is the
-// plain loop's, only the memory access pattern differs.
-__global__ __launch_bounds__(64) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int64_t rows, int64_t T, int nchunk) {
-    __shared__ float tile[64 * (GN_CHUNK + 1)];
-    const int64_t i0 = (int64_t)blockIdx.x * 64, total = rows * nchunk;
-    const int tid = threadIdx.x;
-    for (int c = 0; c < 64; c += 16) {          // 16 chunks per pass: 16 x 256 samples = 64 reads per thread, in 4 batches of 16
-        for (int q = 0; q < 4; ++q) {
-            float v[16];
+// Chunk sums of the GroupNorm statistics, canonical order (identical in oracle/c/nc_ref_encodec.c chunk_sums): a chunk is 256
+// aligned samples of one row; lane i of a wavefront adds samples i, i+64, i+128, i+192 of the chunk (ascending, binary64, from +0),
+// then the 64 lane sums are combined by the xor butterfly 32,16,8,4,2,1 (p_i <- p_i + p_{i^off}; addition commutes, so every lane
+// ends with the same value).  One wavefront per chunk pair: 8 coalesced 256-byte reads in flight, no LDS -- a streaming pass
+// (the tensor was just written by the conv and is largely still in L2 / the 256 MB Infinity Cache).
+constexpr int GN_WPC = 2;   // chunks per wavefront
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int64_t rows, int64_t T, int nchunk) {
+    const int lane = threadIdx.x & 63;
+    const int64_t total = rows * nchunk;
+    const int64_t c0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GN_WPC;
+    if (c0 >= total) return;
+    float v[GN_WPC][4];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int64_t ci = min(i0 + c + u, total - 1);
-                const int64_t r = ci / nchunk, ch = ci - r * nchunk;
-                const int64_t t = min(ch * GN_CHUNK + q * 64 + tid, T - 1);
-                v[u] = x[r * T + t];
-            }
+    for (int u = 0; u < GN_WPC; ++u) {
+        const int64_t ci = min(c0 + u, total - 1);
+        const int64_t r = ci / nchunk, ch = ci - r * nchunk;
+        const float* row = x + r * T;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) tile[(c + u) * (GN_CHUNK + 1) + q * 64 + tid] = v[u];
+        for (int j = 0; j < 4; ++j) {
+            const int64_t t = ch * GN_CHUNK + j * 64 + lane;
+            v[u][j] = t < T ? row[t] : 0.0f;
         }
     }
-    __syncthreads();
-    const int64_t i = i0 + tid;
-    if (i >= total) return;
-    const int64_t r = i / nchunk, ch = i - r * nchunk;
-    const int64_t t0 = ch * GN_CHUNK, t1 = t0 + GN_CHUNK < T ? t0 + GN_CHUNK : T;
-    const float* tp = tile + tid * (GN_CHUNK + 1);
-    double s1 = 0.0, s2 = 0.0;
-    const int n = (int)(t1 - t0);
-    for (int t = 0; t < n; ++t) {
-        const double v = (double)tp[t];
-        s1 += v;
-        s2 += v * v;
+#pragma unroll
+    for (int u = 0; u < GN_WPC; ++u) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double d = (double)v[u][j];
+            s1 += d;
+            s2 += d * d;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            s1 += __shfl_xor(s1, off, 64);
+            s2 += __shfl_xor(s2, off, 64);
+        }
+        if (lane == 0 && c0 + u < total) {
+            part[2 * (c0 + u)] = s1;
+            part[2 * (c0 + u) + 1] = s2;
+        }
     }
-    part[2 * i] = s1;
-    part[2 * i + 1] = s2;
 }
 // one block per sample: row totals (chunks ascending) in parallel, then rows ascending by one thread -> (mean, rstd)
 __global__ __launch_bounds__(256) void gn_final_kernel(const double* __restrict__ part, float* __restrict__ stats, int C, int64_t T,
@@ -306,6 +309,121 @@ __global__ __launch_bounds__(256) void lstm_step_lds_kernel(const float* __restr
         hnext[(int64_t)j * B + b] = h;
         const int64_t o = ((int64_t)b * C + j) * T + t;
         out[o] = skip ? h + skip[o] : h;
+    }
+}
+
+// Persistent LSTM layer: ALL T time steps of one layer in ONE launch (SLSTM.cs:31,40-57).
+//   * W_hh stays in LDS for the whole sequence: a workgroup owns 16 hidden units (4 per wavefront x 4 gates = one 16-row matrix-core
+//     tile per wave), i.e. KS*64 floats per wave = 128 KB per workgroup at C = 512 -- one workgroup per CU, C/16 workgroups per
+//     16-clip column tile, loaded once by LDS DMA.
+//   * The cell state c and the lane's h live in registers; per step a wave runs the same k-ordered matrix-core chain as the
+//     per-step kernels above (bit-identical results), then the gate arithmetic of its 4 units x 16 clips.
+//   * h_t of a column tile is exchanged between its C/16 workgroups through global memory with the placement-independent
+//     release/acquire protocol of cdna_hip_programming.md G16 (recipe R1): write-through (sc1) payload stores -> vmcnt(0) ->
+//     workgroup barrier -> one relaxed agent-scope flag store per workgroup; consumers poll the flags of their tile (one lane per
+//     producer, relaxed), then ONE agent-scope acquire fence, a workgroup barrier, and plain coalesced loads of the 2 KB x 16 h tile
+//     (layout [unit][16 clips] = the B-fragment order, so a wave's 128 operand loads are 256-byte rows).  Double-buffered by step
+//     parity: a workgroup can only publish h_{t+1} after every workgroup of the tile has published h_t, i.e. finished reading h_{t-1}.
+//   * Every spin is bounded: a timeout sets *tmo and all workgroups leave (the host reports NC_EDEVICE at the next synchronise).
+// Grid = (C/16, column tiles <= 8): at most 256 workgroups of 128 KB LDS, all co-resident on the 256 CUs.
+struct LstmSeqArgs {
+    const float* gi;      // [N,4C,T] input projections incl. b_ih
+    const float* whhp;    // [C/4 unit blocks][KS][64] A-fragment image of W_hh
+    const float* bhh;     // [4C]
+    const float* skip;    // nullable [N,C,T]: added to the last layer's output (SLSTM.cs:50-53)
+    float* out;           // [N,C,T]
+    float* hx;            // [2][tiles][C][16] exchange buffers
+    unsigned* flags;      // [tiles][C/16] steps published per workgroup (zeroed before the launch)
+    unsigned* tmo;        // timeout word (zeroed at model creation)
+    int N, C;
+    int64_t T;
+    int tile0;            // first column tile of this launch
+};
+typedef __attribute__((address_space(1))) unsigned lstm_gu32;
+template <int KS>
+__global__ __launch_bounds__(256, 1) void lstm_seq_kernel(const LstmSeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lstm_lds[];   // [4 waves][KS][64]
+    __shared__ int dead;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int C = a.C, N = a.N;
+    const int64_t T = a.T;
+    const int nprod = C / 16;                       // workgroups per column tile
+    const int ubw = blockIdx.x, tile = blockIdx.y;  // tile: local index within this launch
+    const int ub = ubw * 4 + wave;                  // unit block of this wave: hidden units 4*ub .. 4*ub+3
+    float* Aw = lstm_lds + wave * KS * 64;
+    const float* wsrc = a.whhp + (int64_t)ub * KS * 64;
+#pragma unroll
+    for (int i = 0; i < KS / 4; ++i)
+        __builtin_amdgcn_global_load_lds((lstm_gptr)(wsrc + i * 256 + lane * 4), (lstm_lptr)(Aw + i * 256), 16, 0, 0);
+    if (threadIdx.x == 0) dead = 0;
+    const int k4 = lane >> 4, cl = lane & 15;
+    const int j = ub * 4 + k4;                      // this lane's hidden unit
+    const int b = (a.tile0 + tile) * 16 + cl;       // this lane's clip
+    const int bb = min(b, N - 1);
+    const float* g = a.gi + ((int64_t)bb * 4 * C) * T;
+    const float bh0 = a.bhh[j], bh1 = a.bhh[C + j], bh2 = a.bhh[2 * C + j], bh3 = a.bhh[3 * C + j];
+    float* const hx0 = a.hx + ((int64_t)(0 * gridDim.y + tile) * C) * 16;
+    float* const hx1 = a.hx + ((int64_t)(1 * gridDim.y + tile) * C) * 16;
+    unsigned* const flags = a.flags + (int64_t)tile * nprod;
+    const int64_t orow = ((int64_t)bb * C + j) * T;
+    float cst = 0.0f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // input-projection pre-activations (and the skip value) run one step ahead of their use: they are reads, issued before the step's
+    // stores, so they never queue behind a store acknowledgement
+    float g0 = g[(int64_t)j * T], g1 = g[(int64_t)(C + j) * T], g2 = g[(int64_t)(2 * C + j) * T], g3 = g[(int64_t)(3 * C + j) * T];
+    float sk = a.skip ? a.skip[orow] : 0.0f;
+    for (int64_t t = 0; t < T; ++t) {
+        f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float c0 = g0, c1 = g1, c2 = g2, c3 = g3, csk = sk;
+        const int64_t tn = min(t + 1, T - 1);
+        if (t > 0) {                                 // h_{-1} = 0: the chain of step 0 is +0
+            if (wave == 0) {
+                const unsigned want = (unsigned)t;
+                bool ok = false;
+                for (unsigned spins = 0; spins < (1u << 21); ++spins) {
+                    const unsigned v = lane < nprod ? __hip_atomic_load((lstm_gu32*)(flags + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+                    if (__all(v >= want)) { ok = true; break; }
+                    if ((spins & 1023) == 1023 && __hip_atomic_load((lstm_gu32*)a.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!ok && lane == 0) {
+                    __hip_atomic_store((lstm_gu32*)a.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dead = 1;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            if (dead) return;
+            const float* hp = ((t & 1) ? hx0 : hx1) + lane;   // h_{t-1} sits in buffer (t-1)&1
+            float hb[KS];
+#pragma unroll
+            for (int i = 0; i < KS; ++i) hb[i] = hp[i * 64];
+            g0 = g[(int64_t)j * T + tn]; g1 = g[(int64_t)(C + j) * T + tn]; g2 = g[(int64_t)(2 * C + j) * T + tn]; g3 = g[(int64_t)(3 * C + j) * T + tn];
+            if (a.skip) sk = a.skip[orow + tn];
+#pragma unroll
+            for (int i = 0; i < KS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[i * 64 + lane], hb[i], acc, 0, 0, 0);
+        } else {
+            g0 = g[(int64_t)j * T + tn]; g1 = g[(int64_t)(C + j) * T + tn]; g2 = g[(int64_t)(2 * C + j) * T + tn]; g3 = g[(int64_t)(3 * C + j) * T + tn];
+            if (a.skip) sk = a.skip[orow + tn];
+        }
+        const float pi = c0 + (acc[0] + bh0);
+        const float pf = c1 + (acc[1] + bh1);
+        const float pg = c2 + (acc[2] + bh2);
+        const float po = c3 + (acc[3] + bh3);
+        const float ig = nc_sigmoidf(pi), fg = nc_sigmoidf(pf), gg = nc_tanhf(pg), og = nc_sigmoidf(po);
+        cst = (fg * cst) + (ig * gg);
+        const float h = og * nc_tanhf(cst);
+        if (t + 1 < T) {
+            // publish h_t: write-through payload, drained per wave, then one flag store for the workgroup
+            float* hq = ((t & 1) ? hx1 : hx0) + ub * 64 + lane;   // [unit j][clip cl] = j*16 + cl = ub*64 + lane
+            __hip_atomic_store(hq, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store((lstm_gu32*)(flags + ubw), (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (b < N) a.out[orow + t] = a.skip ? h + csk : h;
     }
 }
 
@@ -640,8 +758,20 @@ void EncodecModel::load(const Blob& b) {
     }
     snprintf(nm, sizeof nm, "decoder.layers.%d", n + 1);
     load_sconv(b, nm, dec_out, nf, cfg.channels, cfg.last_kernel_size, 1, false);
+    lstm_sync.reserve(1 << 20);   // timeout word + exchange flags (4 bytes per workgroup of a launch group)
+    NC_HIP(hipMemset(lstm_sync.p, 0, 1 << 20));
     NC_HIP(hipDeviceSynchronize());
     loaded = true;
+}
+
+void EncodecModel::check_async_errors() {
+    if (!lstm_sync.p) return;
+    unsigned tmo = 0;
+    NC_HIP(hipMemcpy(&tmo, lstm_sync.p, 4, hipMemcpyDeviceToHost));
+    if (tmo) {
+        NC_HIP(hipMemset(lstm_sync.p, 0, 4));
+        fail(NC_EDEVICE, "persistent LSTM kernel: a workgroup exchange timed out (its workgroups were not co-resident); results of the call are invalid");
+    }
 }
 
 // ---- launch helpers --------------------------------------------------------------------------------
@@ -673,21 +803,46 @@ const float* EncodecModel::gn_stats(const float* raw, int N, int C, int64_t L) {
     const int64_t nparts = (int64_t)N * C * nchunk;
     double* part = reinterpret_cast<double*>(alloc((size_t)nparts * 4));
     float* stats = alloc((size_t)N * 2);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3((unsigned)((nparts + 63) / 64)), dim3(64), 0, stream, raw, part, (int64_t)N * C, L, nchunk);
+    {
+        ProfScope ps(&prof, stream, NC_KC_NORM, 3.0 * N * C * (double)L, 4.0 * N * C * (double)L);
+        hipLaunchKernelGGL(gn_partial_kernel, dim3((unsigned)((nparts + 4 * GN_WPC - 1) / (4 * GN_WPC))), dim3(256), 0, stream, raw, part, (int64_t)N * C, L,
+                           nchunk);
+    }
     hipLaunchKernelGGL(gn_final_kernel, dim3((unsigned)N), dim3(256), (size_t)2 * C * sizeof(double), stream, part, stats, C, L, nchunk);
     NC_HIP(hipGetLastError());
     return stats;
 }
 
-// SConv1d.forward on an activated view: returns the raw conv output with its pending GroupNorm
+// SConv1d.forward on an activated view: returns the raw conv output with its pending GroupNorm.
+// Single-input layers run with the producer's pending GroupNorm, the ELU and the asymmetric reflect pad folded into the conv's
+// tile load (ConvArgs::in_mode): no padded copy of the activation is ever written.  Two-input layers (shortcut + branch of a
+// residual block) are summed, activated and padded by pad_act_kernel first.
+static void fused_input(ConvIO& io, const EncodecModel::Act& a, bool elu, const EncodecModel::Plan* pl) {
+    io.x = a.p + a.off; io.x_bstride = (int64_t)a.C * a.rs; io.x_cstride = a.rs;
+    io.in_stats = a.stats; io.in_gamma = a.stats ? a.gamma : nullptr; io.in_beta = a.stats ? a.beta : nullptr;
+    io.in_elu = elu;
+    if (pl && (pl->left != 0 || pl->Lp != a.L)) {
+        io.in_left = pl->left; io.in_Lz = pl->Lz; io.in_L = a.L;
+        io.x_len = (int32_t)pl->Lp; io.Tin = pl->Lp;
+    } else {
+        io.x_len = (int32_t)a.L; io.Tin = a.L;
+    }
+}
+
 EncodecModel::Act EncodecModel::sconv(SConv& L, const Act& a, const Act* b2, bool elu, int N) {
     const Plan pl = plan_sconv(a.L, L.K, L.stride, 1);
-    const float* xin;
-    const bool passthrough = !b2 && !elu && !a.stats && pl.left == 0 && pl.Lp == a.L && a.off == 0 && a.rs == a.L;
-    xin = passthrough ? a.p : pad_act(a, b2, elu, N, pl);
-    float* y = alloc((size_t)N * L.Cout * pl.Lout);
+    static const bool no_fuse = std::getenv("NC_ENCODEC_NO_FUSE") && std::getenv("NC_ENCODEC_NO_FUSE")[0] == '1';
+    float* y = nullptr;
     ConvIO io{};
-    io.x = xin; io.x_bstride = (int64_t)L.Cin * pl.Lp; io.x_cstride = pl.Lp; io.x_len = (int32_t)pl.Lp; io.Tin = pl.Lp;
+    if (!b2 && !no_fuse && pl.Lp < ((int64_t)1 << 30)) {
+        fused_input(io, a, elu, &pl);
+        y = alloc((size_t)N * L.Cout * pl.Lout);
+    } else {
+        const bool passthrough = !b2 && !elu && !a.stats && pl.left == 0 && pl.Lp == a.L && a.off == 0 && a.rs == a.L;
+        const float* xin = passthrough ? a.p : pad_act(a, b2, elu, N, pl);
+        y = alloc((size_t)N * L.Cout * pl.Lout);
+        io.x = xin; io.x_bstride = (int64_t)L.Cin * pl.Lp; io.x_cstride = pl.Lp; io.x_len = (int32_t)pl.Lp; io.Tin = pl.Lp;
+    }
     io.y = y; io.y_bstride = (int64_t)L.Cout * pl.Lout; io.y_cstride = pl.Lout;
     launch_conv(L.conv, io, N, stream, &prof);
     Act o;
@@ -700,12 +855,17 @@ EncodecModel::Act EncodecModel::sconv(SConv& L, const Act& a, const Act* b2, boo
 
 // SConvTranspose1d.forward (SConvTranspose1d.cs:116-139): conv-transpose, GroupNorm over the UNTRIMMED output, then the trim
 EncodecModel::Act EncodecModel::sconvT(SConv& L, const Act& a, const Act* b2, bool elu, int N) {
-    Plan pl; pl.left = 0; pl.right = 0; pl.Lz = a.L; pl.Lp = a.L; pl.Lout = a.L;
-    const float* xin = pad_act(a, b2, elu, N, pl);
+    static const bool no_fuse = std::getenv("NC_ENCODEC_NO_FUSE") && std::getenv("NC_ENCODEC_NO_FUSE")[0] == '1';
     const int64_t Lfull = (a.L - 1) * L.stride + L.K;
-    float* y = alloc((size_t)N * L.Cout * Lfull);
     ConvIO io{};
-    io.x = xin; io.x_bstride = (int64_t)L.Cin * a.L; io.x_cstride = a.L; io.x_len = (int32_t)a.L; io.Tin = a.L;
+    if (!b2 && !no_fuse) {
+        fused_input(io, a, elu, nullptr);
+    } else {
+        Plan pl; pl.left = 0; pl.right = 0; pl.Lz = a.L; pl.Lp = a.L; pl.Lout = a.L;
+        const float* xin = pad_act(a, b2, elu, N, pl);
+        io.x = xin; io.x_bstride = (int64_t)L.Cin * a.L; io.x_cstride = a.L; io.x_len = (int32_t)a.L; io.Tin = a.L;
+    }
+    float* y = alloc((size_t)N * L.Cout * Lfull);
     io.y = y; io.y_bstride = (int64_t)L.Cout * Lfull; io.y_cstride = Lfull;
     launch_conv(L.conv, io, N, stream, &prof);
     const int64_t pt = L.K - L.stride;
@@ -752,14 +912,43 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
         io.x = in; io.x_bstride = (int64_t)C * T; io.x_cstride = T; io.x_len = (int32_t)T; io.Tin = T;
         io.y = gi; io.y_bstride = (int64_t)4 * C * T; io.y_cstride = T;
         launch_conv(y.ih, io, N, stream, &prof);
+        out = alloc((size_t)N * C * T);
+        const bool last = li + 1 == l.layers.size();
+        if (prof.on) prof.begin(stream, NC_KC_LSTM, 2.0 * 4 * C * C * (double)N * T, 4.0 * 6 * C * (double)N * T);
+        static const bool stepwise = std::getenv("NC_LSTM_STEPWISE") && std::getenv("NC_LSTM_STEPWISE")[0] == '1';
+        const int KS = C / 4;
+        if (!stepwise && C % 64 == 0 && (KS == 128 || KS == 16)) {
+            // persistent layer kernel: all T steps in one launch per group of column tiles (<= 128 co-resident workgroups)
+            const int nprod = C / 16, n_tiles = (N + 15) / 16, per_launch = std::max(1, 128 / nprod);
+            const size_t lds = (size_t)4 * KS * 64 * 4;
+            if (256 + (size_t)n_tiles * nprod * 4 > lstm_sync.cap) fail(NC_EUNSUPPORTED, "LSTM batch of %d rows exceeds the exchange flag area", N);
+            unsigned* sync = lstm_sync.as<unsigned>();
+            NC_HIP(hipMemsetAsync(sync + 64, 0, (size_t)n_tiles * nprod * 4, stream));   // flags; the timeout word [0] is zeroed at load
+            for (int t0 = 0; t0 < n_tiles; t0 += per_launch) {
+                const int nt = std::min(per_launch, n_tiles - t0);
+                LstmSeqArgs a{};
+                a.gi = gi; a.whhp = y.whhp.as<float>(); a.bhh = y.bhh.as<float>(); a.skip = last ? x : nullptr; a.out = out;
+                a.hx = alloc((size_t)2 * nt * C * 16);
+                a.flags = sync + 64 + (size_t)t0 * nprod; a.tmo = sync;
+                a.N = N; a.C = C; a.T = T; a.tile0 = t0;
+                if (KS == 128) {
+                    ensure_dynamic_lds((const void*)lstm_seq_kernel<128>, lds);
+                    hipLaunchKernelGGL(lstm_seq_kernel<128>, dim3((unsigned)nprod, (unsigned)nt), dim3(256), lds, stream, a);
+                } else {
+                    ensure_dynamic_lds((const void*)lstm_seq_kernel<16>, lds);
+                    hipLaunchKernelGGL(lstm_seq_kernel<16>, dim3((unsigned)nprod, (unsigned)nt), dim3(256), lds, stream, a);
+                }
+            }
+            NC_HIP(hipGetLastError());
+            if (prof.on) prof.end(stream);
+            in = out;
+            continue;
+        }
         float* h0 = alloc((size_t)C * N);
         float* h1 = alloc((size_t)C * N);
         float* cs = alloc((size_t)C * N);
         NC_HIP(hipMemsetAsync(h0, 0, (size_t)C * N * 4, stream));
         NC_HIP(hipMemsetAsync(cs, 0, (size_t)C * N * 4, stream));
-        out = alloc((size_t)N * C * T);
-        const bool last = li + 1 == l.layers.size();
-        if (prof.on) prof.begin(stream, NC_KC_LSTM, 2.0 * 4 * C * C * (double)N * T, 4.0 * 6 * C * (double)N * T);
         static const bool scalar_lstm = std::getenv("NC_LSTM_SCALAR") && std::getenv("NC_LSTM_SCALAR")[0] == '1';
         for (int64_t t = 0; t < T; ++t) {
             static const bool no_lds_lstm = std::getenv("NC_LSTM_CHUNKED") && std::getenv("NC_LSTM_CHUNKED")[0] == '1';
@@ -858,15 +1047,23 @@ void EncodecModel::encode_dev(const float* pcm, int B, int64_t T, int64_t* codes
     const std::vector<Seg> segs = segments(T);
     const int C = cfg.channels, D = cfg.dimension;
     int64_t code_off = 0, emb_off = 0;
-    for (size_t f = 0; f < segs.size(); ++f) {
+    // Consecutive segments of equal length run as ONE batch of G*B rows (every operator of the path is per sample: GroupNorm(1,C),
+    // RMS scale, LSTM state, RVQ), segment-major -- so the batch's codes [G*B, n_q, T'] ARE the G frames' [B, n_q, T'] tensors laid
+    // end to end, the layout the ABI emits.  Halves the number of dependent LSTM steps of a 2 s clip and doubles every grid.
+    for (size_t f = 0; f < segs.size();) {
+        size_t g = f + 1;
+        while (g < segs.size() && segs[g].len == segs[f].len && (int64_t)(g - f + 1) * B <= 4096) ++g;
+        const int G = (int)(g - f);
         const Seg& s = segs[f];
-        // slice the segment out of [B,C,T] into a dense [B,C,len] tensor
-        float* x = alloc((size_t)B * C * s.len);
-        NC_HIP(hipMemcpy2DAsync(x, (size_t)s.len * 4, pcm + s.off, (size_t)T * 4, (size_t)s.len * 4, (size_t)B * C, hipMemcpyDeviceToDevice, stream));
+        float* x = alloc((size_t)G * B * C * s.len);
+        for (int q = 0; q < G; ++q)   // slice segment f+q out of [B,C,T] into rows [q*B, (q+1)*B) of the dense [G*B,C,len] tensor
+            NC_HIP(hipMemcpy2DAsync(x + (size_t)q * B * C * s.len, (size_t)s.len * 4, pcm + segs[f + q].off, (size_t)T * 4, (size_t)s.len * 4,
+                                    (size_t)B * C, hipMemcpyDeviceToDevice, stream));
         float* sc = (cfg.normalize && scales) ? scales + (int64_t)f * B : nullptr;
-        encode_batch(x, B, s.len, s.frames, codes + code_off, sc, emb ? emb + emb_off : nullptr);
-        code_off += (int64_t)B * n_q * s.frames;
-        emb_off += (int64_t)B * D * s.frames;
+        encode_batch(x, G * B, s.len, s.frames, codes + code_off, sc, emb ? emb + emb_off : nullptr);
+        code_off += (int64_t)G * B * n_q * s.frames;
+        emb_off += (int64_t)G * B * D * s.frames;
+        f = g;
     }
 }
 
@@ -884,11 +1081,18 @@ void EncodecModel::decode_dev(const int64_t* codes, const float* scales, int B, 
     std::vector<const float*> fp((size_t)nfr);
     std::vector<int64_t> flen((size_t)nfr);
     int64_t code_off = 0;
-    for (size_t f = 0; f < segs.size(); ++f) {
+    for (size_t f = 0; f < segs.size();) {   // equal-length frames decode as one batch (see encode_dev)
+        size_t g = f + 1;
+        while (g < segs.size() && segs[g].frames == segs[f].frames && (int64_t)(g - f + 1) * B <= 4096) ++g;
+        const int G = (int)(g - f);
         int64_t Lo = 0;
-        fp[f] = decode_batch(codes + code_off, B, nq, segs[f].frames, cfg.normalize ? scales + (int64_t)f * B : nullptr, &Lo);
-        flen[f] = Lo;
-        code_off += (int64_t)B * nq * segs[f].frames;
+        const float* out = decode_batch(codes + code_off, G * B, nq, segs[f].frames, cfg.normalize ? scales + (int64_t)f * B : nullptr, &Lo);
+        for (int q = 0; q < G; ++q) {
+            fp[f + q] = out + (size_t)q * B * C * Lo;
+            flen[f + q] = Lo;
+        }
+        code_off += (int64_t)G * B * nq * segs[f].frames;
+        f = g;
     }
     if (cfg.segment_length <= 0) {                                                           // single frame: DecodeFrame output as is
         NC_HIP(hipMemcpyAsync(pcm, fp[0], (size_t)B * C * flen[0] * 4, hipMemcpyDeviceToDevice, stream));

@@ -80,3 +80,7 @@ NC_HD float nc_snakef(float x, float alpha, float inv) {
     float s = nc_sinf(alpha * x);
     return x + (s * s) * inv;
 }
+
+// ELU (alpha = 1) and the logistic function of the Encodec layers, on the canonical exp (SEANetEncoder.cs ELU, SLSTM.cs gates)
+NC_HD float nc_eluf(float x) { return x > 0.0f ? x : nc_expf(x) - 1.0f; }
+NC_HD float nc_sigmoidf(float x) { return 1.0f / (1.0f + nc_expf(-x)); }

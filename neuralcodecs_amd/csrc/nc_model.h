@@ -39,6 +39,8 @@ struct Codec {
     virtual void load(const Blob& blob) = 0;
     void init_device(int device_index);
     void use_device() const;
+    // errors raised by device code after the launch returned (bounded spins of the persistent kernels): called once the stream is idle
+    virtual void check_async_errors() {}
     // Rebind the handle to another stream.  The workspaces are shared by all calls on the handle, so work already queued on the old
     // stream is ordered before anything the new stream will launch (event record + wait; no host synchronisation).
     void switch_stream(hipStream_t s);
@@ -200,8 +202,10 @@ struct EncodecModel : Codec {
     std::vector<std::unique_ptr<DevBuf>> pool;   // per-call intermediates, same allocation order every call (grow-only)
     size_t pool_i = 0;
     DevBuf h_in, h_out, h_codes, h_scales, h_emb;
+    DevBuf lstm_sync;   // [0]: timeout word of the persistent LSTM kernel; [64..]: per-launch exchange flags
 
     explicit EncodecModel(const nc_encodec_config& c);
+    void check_async_errors() override;
     void load(const Blob& blob) override;
     void set_bandwidth(float bw);
     Plan plan_sconv(int64_t L, int k, int stride, int dil) const;
