@@ -61,6 +61,7 @@ struct ConvArgs {
     const float* in_stats;         // [B][2] (mean, rstd) per sample (bit 0)
     const float* in_gamma;         // [Cin]
     const float* in_beta;          // [Cin]
+    int32_t sub_shift;             // SUB kernels: log2(stride) of the sub-pixel transposed convolution (rows = co*stride + phase; Cout = rows)
     int32_t in_left, in_Lz, in_L;  // bit 2: padded position j reads q = reflect(j - left) over [0,Lz); samples q >= L are the zero extension (D9)
 };
 
@@ -85,6 +86,8 @@ struct ConvLayer {
     bool transposed = false;
     TileCfg cfg{};
     int n_phase = 1, Ktaps = 0;  // taps per phase (== K for conv, ceil(K/stride) for conv-transpose)
+    int sub_shift = 0;           // > 0: transposed conv packed in sub-pixel form (rows = (channel, phase) pairs, one launch, n_phase == 1)
+    int rows() const { return Cout << sub_shift; }   // GEMM rows of the packed image
     DevBuf w, bias;
     // additional row-tile heights (32*TM dividing Cout) packed at load; the launch picks the one that fills the chip best
     struct Alt {

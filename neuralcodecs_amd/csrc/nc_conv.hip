@@ -55,6 +55,8 @@ static conv_kernel_fn conv_kernel_table_spec_k7(int, int) { return nullptr; }
 static conv_kernel_fn conv_kernel_table_dist_k7(int, int) { return nullptr; }
 static int experiment_mode(const char*) { return 0; }
 #endif
+conv_kernel_fn conv_kernel_table_sub_k2(int, int);
+conv_kernel_fn conv_kernel_table_sub_narrow_k2(int);
 conv_kernel_fn conv_kernel_table_narrow_k2(int);
 conv_kernel_fn conv_kernel_table_narrow_k3(int);
 conv_kernel_fn conv_kernel_table_narrow_k7(int);
@@ -146,19 +148,27 @@ double ConvLayer::flops(int B, int64_t Tin) const {
 void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int Cout_, int K_, int stride_, int pad_, int dil_,
                       int out_pad_, bool transposed_) {
     Cin = Cin_; Cout = Cout_; K = K_; stride = stride_; pad = pad_; dil = dil_; out_pad = out_pad_; transposed = transposed_;
+    sub_shift = 0;
     if (transposed) {
         if (dil != 1) fail(NC_EUNSUPPORTED, "dilated conv_transpose1d is not on the hot path");
         n_phase = stride;
         Ktaps = (K + stride - 1) / stride;
+        // sub-pixel form (one launch, rows = (channel, phase)): power-of-two strides with two taps per phase, i.e. the k = 2s
+        // up-convolutions of DAC / SNAC (DecoderBlock.cs:27-33); other strides keep the per-phase launches
+        static const bool no_sub = std::getenv("NC_NO_SUBPIXEL") && std::getenv("NC_NO_SUBPIXEL")[0] == '1';
+        if (!no_sub && (stride == 2 || stride == 4 || stride == 8) && K == 2 * stride && (Cout * stride) % 32 == 0 && out_pad == 0) {
+            sub_shift = stride == 2 ? 1 : stride == 4 ? 2 : 3;
+            n_phase = 1;
+        }
     } else {
         if (stride > 1 && dil != 1) fail(NC_EUNSUPPORTED, "strided+dilated conv1d is not on the hot path");
         n_phase = 1;
         Ktaps = K;
     }
-    cfg = pick_tile(Cout, Ktaps);
+    cfg = pick_tile(rows(), Ktaps);
     auto pack = [&](const TileCfg& tc, DevBuf& dstbuf, int64_t& phase_stride) {
         const int BM = tc.BM(), CB = tc.CB, KB = tc.KB();
-        const int n_co = (Cout + BM - 1) / BM;
+        const int n_co = (rows() + BM - 1) / BM;
         const int n_cb = (Cin + CB - 1) / CB;
         phase_stride = (int64_t)n_co * n_cb * KB * BM;
         std::vector<float> packed((size_t)phase_stride * n_phase, 0.0f);
@@ -170,11 +180,12 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
                         const int ci = cb * CB + kk / Ktaps, k = kk % Ktaps;
                         if (ci >= Cin) continue;
                         for (int r = 0; r < BM; ++r) {
-                            const int co = ct * BM + r;
-                            if (co >= Cout) continue;
+                            int co = ct * BM + r, php = ph;
+                            if (co >= rows()) continue;
+                            if (sub_shift) { php = co & (stride - 1); co >>= sub_shift; }   // row = co*stride + phase
                             float v;
                             if (transposed) {
-                                const int kt = ph + k * stride;  // tap of this phase, ascending (canonical order)
+                                const int kt = php + k * stride;  // tap of this phase, ascending (canonical order)
                                 if (kt >= K) continue;
                                 v = dense_w[((size_t)ci * Cout + co) * K + kt];
                             } else {
@@ -190,9 +201,9 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
     pack(cfg, w, w_phase_stride);
     alts.clear();
     static const bool no_alts = std::getenv("NC_NO_TILE_ALTS") && std::getenv("NC_NO_TILE_ALTS")[0] == '1';
-    if (!no_alts && Cout >= 128)
+    if (!no_alts && rows() >= 128)
         for (int tm = 3; tm >= 2; --tm) {   // (single-row-block tiles measured slower everywhere)
-            if (tm == cfg.TM || Cout % (32 * tm) != 0) continue;
+            if (tm == cfg.TM || rows() % (32 * tm) != 0) continue;
             alts.emplace_back(new Alt());
             alts.back()->cfg = cfg;
             alts.back()->cfg.TM = tm;
@@ -246,7 +257,7 @@ struct TileChoice {
 };
 static TileChoice choose_tile(const ConvLayer& L, int64_t blocks_per_rowtile, bool pointwise_fast) {
     auto cost = [&](const TileCfg& c) {
-        const int n_co = (L.Cout + c.BM() - 1) / c.BM();
+        const int n_co = (L.rows() + c.BM() - 1) / c.BM();
         const double blocks = (double)blocks_per_rowtile * n_co;
         static const int bpc_gen[5] = {0, 4, 3, 2, 2}, bpc_pw[5] = {0, 6, 5, 3, 3};
         static const double pen[5] = {0, 1.30, 1.10, 1.05, 1.00};
@@ -414,7 +425,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     a.rvq_zq = io.rvq_zq; a.rvq_res = io.rvq_res;
     a.noise = io.noise; a.noise_bstride = L.out_len(io.Tin);
     if ((io.epi & EPI_NOISE) && (!io.noise || !io.res)) fail(NC_ESTATE, "internal: noise epilogue needs noise and residual");
-    a.Cout = L.Cout; a.B = B; a.epi = io.epi;
+    a.Cout = L.rows(); a.sub_shift = L.sub_shift; a.B = B; a.epi = io.epi;
     a.Tout = (int32_t)Tout;
     if ((int64_t)(c.BM() + 4) * io.y_cstride + Tout >= (int64_t)1 << 31)
         fail(NC_EUNSUPPORTED, "conv output rows of %lld samples exceed the 32-bit tile offsets", (long long)io.y_cstride);
@@ -423,7 +434,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         sx = 1; a.stride = 1; a.dil = -1; a.pad = 0;
         a.n_cols = (int32_t)(io.Tin + L.Ktaps - 1);
         a.y_tstride = L.stride; a.y_toff = -L.pad;
-        a.n_phase = L.n_phase;
+        a.n_phase = L.n_phase;   // 1 in sub-pixel form
     } else {
         sx = L.stride; a.stride = L.stride; a.dil = L.dil; a.pad = L.pad;
         a.n_cols = (int32_t)Tout;
@@ -436,7 +447,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     a.nchunk = (a.xw + 63) / 64;
     a.xwp = (a.nchunk * 64 + sx - 1) / sx;   // rows are padded to whole 64-slot chunks: every staging store is in-bounds
     a.xrow = sx == 1 ? a.nchunk * 64 : sx * a.xwp;
-    a.n_co_tiles = (L.Cout + BM - 1) / BM;
+    a.n_co_tiles = (L.rows() + BM - 1) / BM;
     a.n_t_tiles = (a.n_cols + BN - 1) / BN;
     a.n_cb = (L.Cin + CB - 1) / CB;
     a.n_items = CB * a.nchunk;
@@ -472,6 +483,9 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     } else if (n_prod) {
         fn = conv_kernel_table_spec_k7(c.TM, c.TN);
         if (!fn) fail(NC_EUNSUPPORTED, "no specialised conv kernel for TM=%d TN=%d", c.TM, c.TN);
+    } else if (L.sub_shift) {
+        fn = c.K != 2 ? nullptr : narrow ? conv_kernel_table_sub_narrow_k2(c.TM) : conv_kernel_table_sub_k2(c.TM, c.TN);
+        if (!fn) fail(NC_EUNSUPPORTED, "no sub-pixel conv kernel for K=%d TM=%d TN=%d", c.K, c.TM, c.TN);
     } else if (narrow) {
         fn = narrow_kernel(c.K, c.TM);
     } else if (wide) {

@@ -3,3 +3,5 @@
 #include "nc_conv_kernel.hip.h"
 NC_INSTANTIATE_CONV_K(2, 16, 20)
 NC_INSTANTIATE_CONV_NARROW(2, 16, 20)
+NC_INSTANTIATE_CONV_SUB(2, 16, 20)
+NC_INSTANTIATE_CONV_SUB_NARROW(2, 16, 20)

@@ -72,7 +72,12 @@ typedef __attribute__((address_space(3))) void* nc_lptr;
 // next reduction block are issued at the top of the step and its transform + LDS writes are dealt out over the step's matrix-core
 // steps, a unit (one weight vector or one window item) per step, in ONE basic block (no `if (more)`: the last step re-stages the
 // last block into the idle buffer).
-template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0, bool DIST = false>
+// SUB: sub-pixel form of a transposed convolution (WNConvTranspose1d.cs:142-163 with stride s = 2^sub_shift).  The s polyphase
+// sub-convolutions share their input window (taps x[q], x[q-1], ...), so they run as ONE convolution with s*Cout output rows, row
+// R = co*s + r, whose element (R, q) is output sample t = q*s + r - pad of channel co.  The 4 consecutive D rows a lane holds are
+// then consecutive samples of one channel, and the 32 columns x 2 lane halves of a store instruction cover a contiguous run of the
+// output row -- where the per-phase launches wrote every s-th sample from different workgroups (3x write amplification in HBM).
+template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0, bool DIST = false, bool SUB = false>
 __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const ConvArgs p) {
     constexpr bool SPEC = NP > 0;
     constexpr int NT = 64 * (NW + NP);             // threads per workgroup
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
             for (int i = tid; i < n_al; i += NT) Al[i] = make_float2(p.in_gamma[min(i, Cin - 1)], p.in_beta[min(i, Cin - 1)]);
         }
         for (int i = tid; i < BM; i += NT) {
-            const int co = min(co_tile * BM + i, p.Cout - 1);
+            const int co = SUB ? min((co_tile * BM + i) >> p.sub_shift, (p.Cout >> p.sub_shift) - 1) : min(co_tile * BM + i, p.Cout - 1);
             const float ao = p.alpha_out ? p.alpha_out[co] : 0.0f;
             Ep[i] = p.bias ? p.bias[co] : 0.0f;
             Ep[BM + i] = ao;
@@ -608,23 +613,44 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*hi][col = l31]
     // Element (row block ib, register r, column j) of this lane lives at tile_base + lane_off[j] + R(ib,r)*cstride with
     // R = 32*ib + (r&3) + 8*(r>>2) a compile-time row: one uniform 64-bit base, 32-bit lane offsets (the host bounds them).
-    const int64_t tile_base = (int64_t)b * p.y_bstride + (int64_t)co_tile * BM * p.y_cstride;
+    const int sh = SUB ? p.sub_shift : 0, smask = (1 << sh) - 1;
+    const int64_t tile_base = (int64_t)b * p.y_bstride + (int64_t)((co_tile * BM) >> sh) * p.y_cstride;
     const unsigned cstride = (unsigned)p.y_cstride;
     const int rows_left = p.Cout - co_tile * BM - 4 * hi;   // row R of this lane half is inside the tensor iff R < rows_left
+    // offset of tile row R (lane half 0) from the tile base; the lane half's 4 extra rows are folded into lane_off
+    auto roff = [&](int R) __attribute__((always_inline)) -> unsigned {
+        if constexpr (SUB) return (unsigned)(R >> sh) * cstride + (unsigned)(R & smask);
+        else return (unsigned)R * cstride;
+    };
     unsigned lane_off[TN];
     bool okc[TN];
     int tcol[TN];
+    bool cols_ok = true;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = col0 + wave * BNW + j * 32 + l31;
         const int t = col * p.y_tstride + p.y_toff + phase;
-        okc[j] = (col < p.n_cols) & (t >= 0) & (t < p.Tout);
-        tcol[j] = min(max(t, 0), p.Tout - 1);
-        lane_off[j] = (unsigned)(4 * hi) * cstride + (unsigned)tcol[j];
+        if constexpr (SUB) {   // t = sample of sub-row r = 0; row R adds (R + 4*hi) & smask.  Time bounds are checked per row.
+            okc[j] = col < p.n_cols;
+            tcol[j] = t;
+            lane_off[j] = (unsigned)((4 * hi) >> sh) * cstride + (unsigned)((4 * hi) & smask) + (unsigned)t;
+            cols_ok = cols_ok & okc[j] & (t >= 0) & (t + smask < p.Tout);
+        } else {
+            okc[j] = (col < p.n_cols) & (t >= 0) & (t < p.Tout);
+            tcol[j] = min(max(t, 0), p.Tout - 1);
+            lane_off[j] = (unsigned)(4 * hi) * cstride + (unsigned)tcol[j];
+            cols_ok = cols_ok & okc[j];
+        }
     }
-    bool cols_ok = true;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) cols_ok = cols_ok & okc[j];
+    // element (row R of lane half hi, column j) is inside the tensor
+    auto okrow = [&](int j, int R) __attribute__((always_inline)) -> bool {
+        if constexpr (SUB) {
+            const int tq = tcol[j] + ((R + 4 * hi) & smask);
+            return okc[j] & (R < rows_left) & (tq >= 0) & (tq < p.Tout);
+        } else {
+            return okc[j] & (R < rows_left);
+        }
+    };
     const bool tile_full = __builtin_amdgcn_ballot_w64(!cols_ok) == 0 && p.Cout - co_tile * BM >= BM;   // wave-uniform
     // Residual operands of the 32-row block `ib`, all 16*TN reads issued back to back (one memory round trip per row block).
     // full_tag: every element of this wave's part of the tile is inside the tensor (no per-element predicates: straight-line code)
@@ -637,7 +663,9 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if constexpr (FULL) {
-                    rv[r][j] = rt[lane_off[j] + (unsigned)R * cstride];
+                    rv[r][j] = rt[lane_off[j] + roff(R)];
+                } else if constexpr (SUB) {
+                    rv[r][j] = okrow(j, R) ? rt[lane_off[j] + roff(R)] : 0.0f;
                 } else {   // branch-free: the address is clamped into the tile's valid rows / columns, the value masked
                     const float val = rt[lane_off[j] + (unsigned)max(min(R, rows_left - 1), -4 * hi) * cstride];
                     rv[r][j] = (okc[j] & (R < rows_left)) ? val : 0.0f;
@@ -684,8 +712,8 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                     const int R = ib * 32 + rr + 8 * rq;
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        const bool ok = FULL || (okc[j] & (R < rows_left));
-                        const unsigned o = lane_off_s[j] + (unsigned)R * cstride;
+                        const bool ok = FULL || okrow(j, R);
+                        const unsigned o = lane_off_s[j] + roff(R);
                         zv[rr][j] = ok ? yt[o] : 0.0f;
                         sv[rr][j] = (ok && st) ? st[o] : 0.0f;
                     }
@@ -697,8 +725,8 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 const float ao = ao_t[R + 4 * hi], ao_inv = ao_t[BM + R + 4 * hi];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (!(FULL || (okc[j] & (R < rows_left)))) continue;
-                    const unsigned o = lane_off_s[j] + (unsigned)R * cstride;
+                    if (!(FULL || okrow(j, R))) continue;
+                    const unsigned o = lane_off_s[j] + roff(R);
                     float val = v[j][4 * rq + rr];
                     if (snake) val = nc_snakef(val, ao, ao_inv);
                     if (decltype(gen_tag)::value && (p.epi & EPI_TANH)) val = nc_tanhf(val);
@@ -729,8 +757,8 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 const int R = ib * 32 + rr + 8 * rq;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const bool ok = okc[j] & (R < rows_left);
-                    const unsigned o = lane_off[j] + (unsigned)R * cstride;
+                    const bool ok = okrow(j, R);
+                    const unsigned o = lane_off[j] + roff(R);
                     rv[rr][j] = (ok && rt) ? rt[o] : 0.0f;
                     zv[rr][j] = (ok && rvq) ? yt[o] : 0.0f;
                     sv[rr][j] = (ok && st) ? st[o] : 0.0f;
@@ -742,10 +770,10 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 const float bias = bias_t[R + 4 * hi], ao = ao_t[R + 4 * hi], ao_inv = ao_t[BM + R + 4 * hi];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (!(okc[j] & (R < rows_left))) continue;
-                    const unsigned o = lane_off[j] + (unsigned)R * cstride;
+                    if (!okrow(j, R)) continue;
+                    const unsigned o = lane_off[j] + roff(R);
                     float val = v[j][4 * rq + rr] + bias;
-                    if (noise) val = rv[rr][j] + p.noise[(int64_t)b * p.noise_bstride + tcol[j]] * val;
+                    if (noise) val = rv[rr][j] + p.noise[(int64_t)b * p.noise_bstride + tcol[j] + (SUB ? ((R + 4 * hi) & smask) : 0)] * val;
                     else if (rt) val = val + rv[rr][j];
                     if (snake) val = nc_snakef(val, ao, ao_inv);
                     if (p.epi & EPI_TANH) val = nc_tanhf(val);
@@ -890,9 +918,9 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
 
 typedef void (*conv_kernel_fn)(const ConvArgs);
 
-template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0, bool DIST = false>
+template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0, bool DIST = false, bool SUB = false>
 inline conv_kernel_fn get_conv_kernel() {
-    return &conv_mfma_kernel<TM, TN, K, CB, NX, FUSE, OCC, NW, NP, DIST>;
+    return &conv_mfma_kernel<TM, TN, K, CB, NX, FUSE, OCC, NW, NP, DIST, SUB>;
 }
 
 }  // namespace nc
@@ -915,6 +943,37 @@ inline conv_kernel_fn get_conv_kernel() {
     }                                                                                                      \
     int conv_kernel_cb_k##KVAL() { return CBVAL; }                                                         \
     int conv_kernel_nx_k##KVAL() { return NXVAL; }                                                         \
+    }
+
+// Sub-pixel transposed-convolution variants (stride 2 / 4 / 8 up-convolutions: rows = (channel, phase) pairs).
+#define NC_INSTANTIATE_CONV_SUB(KVAL, CBVAL, NXVAL)                                                        \
+    namespace nc {                                                                                         \
+    conv_kernel_fn conv_kernel_table_sub_k##KVAL(int TM, int TN) {                                         \
+        switch (TM * 10 + TN) {                                                                            \
+            case 11: return get_conv_kernel<1, 1, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, true>();      \
+            case 12: return get_conv_kernel<1, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, true>();      \
+            case 21: return get_conv_kernel<2, 1, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, true>();      \
+            case 22: return get_conv_kernel<2, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, true>();      \
+            case 31: return get_conv_kernel<3, 1, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, true>();      \
+            case 32: return get_conv_kernel<3, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, true>();      \
+            case 41: return get_conv_kernel<4, 1, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, true>();      \
+            case 42: return get_conv_kernel<4, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, true>();      \
+        }                                                                                                  \
+        return nullptr;                                                                                    \
+    }                                                                                                      \
+    }
+
+#define NC_INSTANTIATE_CONV_SUB_NARROW(KVAL, CBVAL, NXVAL)                                                 \
+    namespace nc {                                                                                         \
+    conv_kernel_fn conv_kernel_table_sub_narrow_k##KVAL(int TM) {                                          \
+        switch (TM) {                                                                                      \
+            case 1: return get_conv_kernel<1, 1, KVAL, CBVAL, NXVAL, false, 2, 3, 0, false, true>();       \
+            case 2: return get_conv_kernel<2, 1, KVAL, CBVAL, NXVAL, false, 2, 3, 0, false, true>();       \
+            case 3: return get_conv_kernel<3, 1, KVAL, CBVAL, NXVAL, false, 2, 3, 0, false, true>();       \
+            case 4: return get_conv_kernel<4, 1, KVAL, CBVAL, NXVAL, false, 2, 3, 0, false, true>();       \
+        }                                                                                                  \
+        return nullptr;                                                                                    \
+    }                                                                                                      \
     }
 
 // Fused residual-unit variants (k=7 conv + Snake + 1x1 conv + skip in one launch): Cin == Cout == 32*TM.

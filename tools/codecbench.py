@@ -52,6 +52,8 @@ def main():
             m.dispose()
     if not a.only or "encodec" in a.only:
         for name, cfg, B, secs in (("encodec48k_c3", EncodecConfig.encodec_48khz(), 16, 2.0), ("encodec24k", EncodecConfig.encodec_24khz(), 16, 2.0)):
+            if a.only.startswith("encodec") and len(a.only) > 7 and a.only[7:] not in name:
+                continue
             m = Encodec(cfg)
             m.load_blob(save_blob(encodec_synthetic_state_dict(cfg, seed=42)))
             T = int(secs * cfg.sampling_rate)
