@@ -261,6 +261,34 @@ NC_API nc_status nc_audio_deinterleave_dev(int device_index, const float* interl
 NC_API nc_status nc_audio_resample_linear_dev(int device_index, const float* in, int32_t B, int64_t n_in, int32_t src_rate, int32_t dst_rate,
                                               float* out, void* hip_stream);
 
+/* ------------------------------------------------------------------------------------ multi-GPU groups
+ * The reference has no multi-device code; its callers batch clips (Examples/Program.cs:228-322, Models/Dia.cs:973-1002).  The path
+ * shards over clips with no data-path exchange (every operator is per sample), so a group = one codec replica per GPU + ONE
+ * collective: the RCCL all-gather of the emitted int64 codes (DAC [B,n_q,T'], SNAC.Encode's List<Tensor> as the levels of a clip side
+ * by side: Models/SNAC.cs:129-150), issued on a side stream per device behind the encode, so the local decode overlaps it.
+ * librccl is opened at run time by these entry points only.
+ *   rank  mode: one process per GPU; rank 0 draws a unique id (nc_group_unique_id) and hands it to the others out of band.
+ *   local mode: one process drives ndev GPUs (handles[i] created on device i): the natural layout of a single C# host process. */
+typedef struct nc_group nc_group;
+#define NC_GROUP_UID_BYTES 128
+NC_API nc_status nc_group_unique_id(void* uid /* [NC_GROUP_UID_BYTES] */);
+NC_API nc_status nc_group_create_rank(int32_t world, int32_t rank, const void* uid, nc_codec* local, nc_group** out);
+NC_API nc_status nc_group_create_local(int32_t ndev, nc_codec* const* handles, nc_group** out);
+NC_API nc_status nc_group_destroy(nc_group* g);
+NC_API nc_status nc_group_info(const nc_group* g, int32_t* world, int32_t* rank /* -1 in local mode */);
+/* rank mode, device pointers, asynchronous: encode this rank's B_local clips (nc_dac_encode_dev / nc_snac_encode_dev semantics) with the
+ * codes written straight into slot `rank` of codes_all [world*B_local, ...], then the in-place all-gather on the group's side stream.
+ * nc_group_wait makes the codec's stream wait for the gather (no host synchronisation). */
+NC_API nc_status nc_group_dac_encode_allgather_dev(nc_group* g, const float* pcm, int32_t B_local, int64_t T, int32_t sample_rate, int32_t n_q,
+                                                   int64_t* codes_all, float* z_local, float* latents_local);
+NC_API nc_status nc_group_snac_encode_allgather_dev(nc_group* g, const float* pcm, int32_t B_local, int64_t T, int64_t* codes_all);
+NC_API nc_status nc_group_wait(nc_group* g);
+/* local mode, host pointers, synchronous: B_total clips split into contiguous equal blocks over the devices (B_total % ndev == 0);
+ * codes [B_total, ...] come back gathered; z nullable [B_total, latent, T'] (each device returns its block). */
+NC_API nc_status nc_group_dac_encode_allgather(nc_group* g, const float* pcm, int32_t B_total, int64_t T, int32_t sample_rate, int32_t n_q,
+                                               int64_t* codes, float* z);
+NC_API nc_status nc_group_snac_encode_allgather(nc_group* g, const float* pcm, int32_t B_total, int64_t T, int64_t* codes);
+
 /* ------------------------------------------------------------------------------------ profiling
  * Per-kernel-class timing with HIP events recorded on the handle's stream around every launch
  * (used by bench.py for the roofline object).  Classes are stable small integers. */

@@ -113,6 +113,16 @@ SYMBOLS = [
     ("nc_audio_interleave_dev", C.c_int, [C.c_int, _P, C.c_int64, C.c_int32, _P, _P]),
     ("nc_audio_deinterleave_dev", C.c_int, [C.c_int, _P, C.c_int64, C.c_int32, _P, _P]),
     ("nc_audio_resample_linear_dev", C.c_int, [C.c_int, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
+    ("nc_group_unique_id", C.c_int, [_P]),
+    ("nc_group_create_rank", C.c_int, [C.c_int32, C.c_int32, _P, _P, C.POINTER(_P)]),
+    ("nc_group_create_local", C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P)]),
+    ("nc_group_destroy", C.c_int, [_P]),
+    ("nc_group_info", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("nc_group_dac_encode_allgather_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P]),
+    ("nc_group_snac_encode_allgather_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
+    ("nc_group_wait", C.c_int, [_P]),
+    ("nc_group_dac_encode_allgather", C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
+    ("nc_group_snac_encode_allgather", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
     ("nc_codec_profile_enable", C.c_int, [_P, C.c_int32]),
     ("nc_codec_profile_reset", C.c_int, [_P]),
     ("nc_codec_profile_read", C.c_int, [_P, C.POINTER(NcProfileEntry)]),

@@ -8,10 +8,6 @@
 
 using namespace nc;
 
-struct nc_codec {
-    std::unique_ptr<Codec> impl;
-    int kind = 0;  // 0 = DAC
-};
 
 namespace {
 

@@ -97,6 +97,7 @@ struct ConvLayer {
     };
     std::vector<std::unique_ptr<Alt>> alts;
     DevBuf w_thin;   // Cout <= 2, stride 1: dense [Cout][Cin][K] image for the streaming thin-output kernel (nc_conv_thin.hip)
+    DevBuf w_stem;   // Cin == 1, K == 7, stride 1: dense [Cout][K] image for the streaming stem kernel (nc_conv_thin.hip)
     DevBuf w_skinny; // K==1, Cout<=16, Cin%64==0: [Cin/4][64 lanes] A-fragment image of skinny_proj_kernel (rows >= Cout zero)
     DevBuf w_fused;  // K==1, Cin==Cout<=128: [row block][ci][32 rows] image consumed by the fused residual-unit kernel
     bool has_bias = false;
@@ -106,7 +107,7 @@ struct ConvLayer {
     void build(const float* dense_w, const float* bias_h, int Cin, int Cout, int K, int stride, int pad, int dil, int out_pad,
                bool transposed);
     void release_all() {   // op-level hooks build throw-away layers
-        w.release(); bias.release(); w_skinny.release(); w_fused.release(); w_thin.release();
+        w.release(); bias.release(); w_skinny.release(); w_fused.release(); w_thin.release(); w_stem.release();
         for (auto& a : alts) a->w.release();
         alts.clear();
     }

@@ -73,6 +73,8 @@ static conv_kernel_fn narrow_kernel(int K, int TM) {
 conv_kernel_fn conv1x1_kernel_table(int, int);
 bool launch_conv_thin(const float* x, int64_t x_bstride, int64_t x_cstride, int Cin, int x_len, const float* w_dense, const float* bias, float* y,
                       int64_t y_bstride, int64_t y_cstride, int B, int Cout, int K, int pad, int dil, int64_t Tout, bool tanh_out, hipStream_t s);
+bool launch_conv_stem(const float* x, int64_t x_bstride, int x_len, const float* w_dense, const float* bias, const float* alpha_out, float* y,
+                      int64_t y_bstride, int64_t y_cstride, int B, int Cout, int K, int pad, int64_t Tout, hipStream_t s);
 void launch_skinny_proj(const float* x, int64_t x_bstride, int64_t x_cstride, const float* wp, const float* bias, float* y, int64_t y_bstride,
                         int64_t y_cstride, int B, int Cin, int Cout, int64_t T, hipStream_t s);
 
@@ -229,6 +231,10 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
         w_skinny.reserve(f.size() * sizeof(float));
         NC_HIP(hipMemcpy(w_skinny.p, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    if (!transposed && stride == 1 && dil == 1 && Cin == 1 && K == 7) {   // dense [Cout][1][K] image for the streaming stem kernel
+        w_stem.reserve(sizeof(float) * (size_t)Cout * K);
+        NC_HIP(hipMemcpy(w_stem.p, dense_w, sizeof(float) * (size_t)Cout * K, hipMemcpyHostToDevice));
+    }
     if (!transposed && stride == 1 && Cout <= 2 && (K == 7 || K == 3 || K == 1)) {
         w_thin.reserve(sizeof(float) * (size_t)Cout * Cin * K);
         NC_HIP(hipMemcpy(w_thin.p, dense_w, sizeof(float) * (size_t)Cout * Cin * K, hipMemcpyHostToDevice));
@@ -346,6 +352,16 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
                                                io.y, io.y_bstride, io.y_cstride, B, L.Cout, L.K, L.pad, L.dil, Tout, (io.epi & EPI_TANH) != 0, stream);
             if (prof && prof->on) prof->end(stream);
             if (done) return;
+        }
+    }
+    {   // thin-input layers (stems, Cin == 1): streaming store of Cout rows
+        static const bool no_stem = std::getenv("NC_NO_STEM") && std::getenv("NC_NO_STEM")[0] == '1';
+        if (L.w_stem.p && !no_stem && !in_mode && !io.alpha_in && !io.res && !io.fuse_k1 && io.epi == 0 && io.x_cstride >= 0) {
+            const int64_t Tout = L.out_len(io.Tin);
+            ProfScope ps(prof, stream, L.kclass, L.flops(B, io.Tin), 4.0 * ((double)B * io.Tin + (double)B * L.Cout * Tout));
+            if (launch_conv_stem(io.x, io.x_bstride, io.x_len, L.w_stem.as<float>(), L.has_bias ? L.bias.as<float>() : nullptr, io.alpha_out, io.y,
+                                 io.y_bstride, io.y_cstride, B, L.Cout, L.K, L.pad, Tout, stream))
+                return;
         }
     }
     if (launch_conv1x1(L, io, B, stream, prof)) return;

@@ -142,4 +142,78 @@ bool launch_conv_thin(const float* x, int64_t x_bstride, int64_t x_cstride, int 
     return ok;
 }
 
+// Thin-INPUT convolution: the encoders' stem Conv1d(1, C, k=7, pad 3) (Encoder.cs:31, Modules/SNAC/Encoder.cs:33).  On the matrix-core
+// template the single input channel is padded to a reduction block of 8; the work is really one streaming STORE of C rows
+// (HBM-bound: 4*Cout bytes per input step).  One workgroup = 1024 steps of one clip: each thread keeps its K+3 input samples in
+// registers (zero padding and DAC.Preprocess's right pad by predicate), walks the output channels with the K weights + bias of a
+// channel read from LDS (one 32-byte row per channel), and writes 4 consecutive samples per channel: a wavefront's store is 1 KB of
+// one output row.  Arithmetic per output = the canonical chain: fmaf over k ascending from +0, then + bias (then the next layer's
+// Snake when the consumer fused it into this store).
+template <int K>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, int64_t x_bstride, int x_len, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ alpha_out, float* __restrict__ y,
+                                                        int64_t y_bstride, int64_t y_cstride, int Cout, int Tout, int pad, int n_t_tiles, int vec_ok) {
+    extern __shared__ __attribute__((aligned(16))) float ws[];   // [Cout][8]: K weights, bias | then [Cout][2]: alpha, 1/alpha
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / n_t_tiles, tt = blockIdx.x - b * n_t_tiles;
+    const int t = tt * THIN_TILE + 4 * tid;
+    const float* xb = x + (int64_t)b * x_bstride;
+    float xw[K + 3];
+#pragma unroll
+    for (int i = 0; i < K + 3; ++i) {
+        const int g = t - pad + i;
+        const float v = xb[min(max(g, 0), x_len - 1)];
+        xw[i] = (g >= 0 && g < x_len) ? v : 0.0f;
+    }
+    for (int i = tid; i < Cout * 8; i += 256) {
+        const int co = i >> 3, k = i & 7;
+        ws[i] = k < K ? w[co * K + k] : (k == 7 && bias ? bias[co] : 0.0f);
+    }
+    float* al = ws + Cout * 8;
+    if (alpha_out)
+        for (int i = tid; i < Cout; i += 256) { const float a = alpha_out[i]; al[2 * i] = a; al[2 * i + 1] = nc_snake_inv(a); }
+    __syncthreads();
+    if (t >= Tout) return;
+    float* yr = y + (int64_t)b * y_bstride + t;
+    for (int co = 0; co < Cout; ++co) {
+        const thin_f32x4 w0 = *reinterpret_cast<const thin_f32x4*>(ws + co * 8), w1 = *reinterpret_cast<const thin_f32x4*>(ws + co * 8 + 4);
+        const float wk[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+        thin_f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float a = 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) a = fmaf(wk[k], xw[k + q], a);
+            a = a + wk[7];
+            o[q] = a;
+        }
+        if (alpha_out) {
+            const float a = al[2 * co], ai = al[2 * co + 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = nc_snakef(o[q], a, ai);
+        }
+        float* yp = yr + (int64_t)co * y_cstride;
+        if (vec_ok && t + 3 < Tout) {
+            *reinterpret_cast<thin_f32x4*>(yp) = o;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (t + q < Tout) yp[q] = o[q];
+        }
+    }
+}
+
+// Cin == 1, stride 1, dilation 1, K <= 7: dense weights [Cout][1][K]; returns false when the shape has no instantiation
+bool launch_conv_stem(const float* x, int64_t x_bstride, int x_len, const float* w_dense, const float* bias, const float* alpha_out, float* y,
+                      int64_t y_bstride, int64_t y_cstride, int B, int Cout, int K, int pad, int64_t Tout, hipStream_t s) {
+    if (K != 7 || Cout < 1 || Cout > 1024 || Tout <= 0 || x_len <= 0) return false;
+    const int ntt = (int)((Tout + THIN_TILE - 1) / THIN_TILE);
+    const size_t lds = sizeof(float) * (size_t)Cout * 10;
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (y_bstride & 3) == 0 && (y_cstride & 3) == 0) ? 1 : 0;
+    hipLaunchKernelGGL((stem_conv_kernel<7>), dim3((unsigned)(B * ntt)), dim3(256), lds, s, x, x_bstride, x_len, w_dense, bias, alpha_out, y, y_bstride,
+                       y_cstride, Cout, (int)Tout, pad, ntt, vec_ok);
+    NC_HIP(hipGetLastError());
+    return true;
+}
+
 }  // namespace nc

@@ -1,0 +1,297 @@
+// Multi-GPU groups behind the C ABI: batch sharding over the GPUs of one node + the RCCL all-gather of the emitted codes.
+//
+// The Encode/Decode path has no cross-clip dependency (no BatchNorm; GroupNorm / LayerNorm / RMS scale are per sample, RVQ per frame),
+// so every device runs the single-GPU engine on its contiguous block of clips with replicated weights; the ONE collective is the
+// all-gather of the int64 codes (DAC [B,9,87]: 200 KB per rank at BASELINE config C4; SNAC: the levels of a clip side by side, one
+// collective for all levels).  It is issued on a side stream per device, ordered after the encode by an event, so whatever the caller
+// queues next on the codec's stream (the local decode needs only local latents) overlaps it.
+//
+// librccl is opened at run time by these entry points only (dlopen, preferring a copy already mapped into the process): the engine
+// library itself keeps libamdhip64 as its only dependency.  Two modes:
+//   rank  mode: one process per GPU (the torch.distributed / MPI / C# multi-process layout); ranks share a 128-byte unique id.
+//   local mode: one process drives ndev GPUs (the natural layout of a C# host): ncclCommInitAll + grouped collectives.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+
+#include "nc_model.h"
+
+using namespace nc;
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    static std::string err;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names)
+            if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;   // a copy already in the process (e.g. PyTorch's) wins
+        if (!r.lib)
+            for (const char* n : names)
+                if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!r.lib) { err = dlerror() ? dlerror() : "librccl not found"; return; }
+        auto sym = [&](const char* s) { void* p = dlsym(r.lib, s); if (!p) err = std::string("librccl lacks ") + s; return p; };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    if (!r.lib || !err.empty()) fail(NC_EDEVICE, "RCCL is not available: %s", err.c_str());
+    return r;
+}
+
+#define NC_RCCL(expr)                                                                                     \
+    do {                                                                                                  \
+        ncclResult_t r__ = (expr);                                                                        \
+        if (r__ != ncclSuccess) fail(NC_EDEVICE, "%s failed: %s", #expr, rccl().GetErrorString(r__));      \
+    } while (0)
+
+template <class F>
+nc_status guard(F&& f) {
+    try {
+        f();
+        return NC_OK;
+    } catch (const Error& e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        set_last_error("host allocation failed");
+        return NC_ENOMEM;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return NC_ESTATE;
+    }
+}
+
+}  // namespace
+
+struct nc_group {
+    int world = 1, rank = -1;        // rank == -1: local mode (this process drives all `world` devices)
+    struct Member {
+        nc_codec* h = nullptr;
+        ncclComm_t comm = nullptr;
+        hipStream_t side = nullptr;
+        hipEvent_t ev_enc = nullptr, ev_gather = nullptr;
+        DevBuf pcm, codes_all, z;    // local mode staging
+    };
+    std::vector<Member> m;
+    ~nc_group() {
+        for (auto& x : m) {
+            if (x.h && x.h->impl) (void)hipSetDevice(x.h->impl->device);
+            if (x.comm) (void)rccl().CommDestroy(x.comm);
+            if (x.side) (void)hipStreamDestroy(x.side);
+            if (x.ev_enc) (void)hipEventDestroy(x.ev_enc);
+            if (x.ev_gather) (void)hipEventDestroy(x.ev_gather);
+            x.pcm.release(); x.codes_all.release(); x.z.release();
+        }
+    }
+};
+
+namespace {
+
+void init_member(nc_group::Member& x, nc_codec* h) {
+    if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");
+    x.h = h;
+    h->impl->use_device();
+    NC_HIP(hipStreamCreateWithFlags(&x.side, hipStreamNonBlocking));
+    NC_HIP(hipEventCreateWithFlags(&x.ev_enc, hipEventDisableTiming));
+    NC_HIP(hipEventCreateWithFlags(&x.ev_gather, hipEventDisableTiming));
+}
+
+// codes of this member -> its slot of codes_all; returns elements per rank.  The encode writes straight into the slot, so the
+// all-gather runs in place (sendbuf == recvbuf + rank * count).
+int64_t encode_into_slot(nc_group::Member& x, int kind, int slot, const float* pcm, int B, int64_t T, int sample_rate, int n_q, int64_t* codes_all,
+                         float* z, float* lat) {
+    Codec& c = *x.h->impl;
+    c.use_device();
+    int64_t per_rank = 0;
+    if (kind == 0) {
+        if (x.h->kind != 0) fail(NC_EINVAL, "handle is not a DAC codec");
+        DacModel& m = static_cast<DacModel&>(c);
+        const int nq = (n_q <= 0 || n_q > m.cfg.n_codebooks) ? m.cfg.n_codebooks : n_q;
+        per_rank = (int64_t)B * nq * m.frames(T);
+        m.encode_dev(pcm, B, T, sample_rate, n_q, codes_all + (int64_t)slot * per_rank, z, lat);
+    } else {
+        if (x.h->kind != 1) fail(NC_EINVAL, "handle is not a SNAC codec");
+        SnacModel& m = static_cast<SnacModel&>(c);
+        per_rank = (int64_t)B * m.codes_per_clip(m.padded_len(T) / m.hop);
+        m.encode_dev(pcm, B, T, codes_all + (int64_t)slot * per_rank, nullptr, nullptr, true);
+    }
+    NC_HIP(hipEventRecord(x.ev_enc, c.stream));
+    NC_HIP(hipStreamWaitEvent(x.side, x.ev_enc, 0));
+    return per_rank;
+}
+
+void rank_encode_allgather(nc_group* g, int kind, const float* pcm, int B, int64_t T, int sample_rate, int n_q, int64_t* codes_all, float* z,
+                           float* lat) {
+    if (!g || g->rank < 0) fail(NC_EINVAL, "group was not created with nc_group_create_rank");
+    if (!pcm || !codes_all || B <= 0 || T <= 0) fail(NC_EINVAL, "bad arguments");
+    nc_group::Member& x = g->m[0];
+    const int64_t per_rank = encode_into_slot(x, kind, g->rank, pcm, B, T, sample_rate, n_q, codes_all, z, lat);
+    NC_RCCL(rccl().AllGather(codes_all + (int64_t)g->rank * per_rank, codes_all, (size_t)per_rank, ncclInt64, x.comm, x.side));
+    NC_HIP(hipEventRecord(x.ev_gather, x.side));
+}
+
+void local_encode_allgather(nc_group* g, int kind, const float* pcm, int B_total, int64_t T, int sample_rate, int n_q, int64_t* codes, float* z) {
+    if (!g || g->rank >= 0) fail(NC_EINVAL, "group was not created with nc_group_create_local");
+    if (!pcm || !codes || B_total <= 0 || T <= 0) fail(NC_EINVAL, "bad arguments");
+    const int W = g->world;
+    if (B_total % W != 0) fail(NC_EINVAL, "%d clips do not split evenly over %d devices", B_total, W);
+    const int B = B_total / W;
+    int64_t per_rank = 0, z_per = 0;
+    for (int d = 0; d < W; ++d) {
+        nc_group::Member& x = g->m[d];
+        Codec& c = *x.h->impl;
+        c.use_device();
+        int64_t total = 0;
+        if (kind == 0) {
+            DacModel& m = static_cast<DacModel&>(c);
+            const int nq = (n_q <= 0 || n_q > m.cfg.n_codebooks) ? m.cfg.n_codebooks : n_q;
+            total = (int64_t)B_total * nq * m.frames(T);
+            z_per = (int64_t)B * m.latent * m.frames(T);
+        } else {
+            SnacModel& m = static_cast<SnacModel&>(c);
+            total = (int64_t)B_total * m.codes_per_clip(m.padded_len(T) / m.hop);
+        }
+        x.pcm.reserve((size_t)B * T * 4);
+        x.codes_all.reserve((size_t)total * 8);
+        if (z && kind == 0) x.z.reserve((size_t)z_per * 4);
+        NC_HIP(hipMemcpyAsync(x.pcm.p, pcm + (int64_t)d * B * T, (size_t)B * T * 4, hipMemcpyHostToDevice, c.stream));
+        per_rank = encode_into_slot(x, kind, d, x.pcm.as<float>(), B, T, sample_rate, n_q, x.codes_all.as<int64_t>(), (z && kind == 0) ? x.z.as<float>() : nullptr,
+                                    nullptr);
+        if (z && kind == 0) NC_HIP(hipMemcpyAsync(z + (int64_t)d * z_per, x.z.p, (size_t)z_per * 4, hipMemcpyDeviceToHost, c.stream));
+    }
+    NC_RCCL(rccl().GroupStart());
+    for (int d = 0; d < W; ++d) {
+        nc_group::Member& x = g->m[d];
+        int64_t* all = x.codes_all.as<int64_t>();
+        NC_RCCL(rccl().AllGather(all + (int64_t)d * per_rank, all, (size_t)per_rank, ncclInt64, x.comm, x.side));
+    }
+    NC_RCCL(rccl().GroupEnd());
+    {   // every device now holds all codes; device 0's copy goes back to the host
+        nc_group::Member& x = g->m[0];
+        x.h->impl->use_device();
+        NC_HIP(hipMemcpyAsync(codes, x.codes_all.p, (size_t)per_rank * W * 8, hipMemcpyDeviceToHost, x.side));
+    }
+    for (int d = 0; d < W; ++d) {
+        nc_group::Member& x = g->m[d];
+        x.h->impl->use_device();
+        NC_HIP(hipStreamSynchronize(x.side));
+        NC_HIP(hipStreamSynchronize(x.h->impl->stream));
+        x.h->impl->check_async_errors();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+nc_status nc_group_unique_id(void* uid) {
+    return guard([&] {
+        if (!uid) fail(NC_EINVAL, "uid must not be null");
+        static_assert(NC_GROUP_UID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+        ncclUniqueId id;
+        NC_RCCL(rccl().GetUniqueId(&id));
+        std::memcpy(uid, id.internal, NCCL_UNIQUE_ID_BYTES);
+    });
+}
+
+nc_status nc_group_create_rank(int32_t world, int32_t rank, const void* uid, nc_codec* local, nc_group** out) {
+    return guard([&] {
+        if (!out || !uid) fail(NC_EINVAL, "uid and out must not be null");
+        *out = nullptr;
+        if (world <= 0 || rank < 0 || rank >= world) fail(NC_EINVAL, "rank %d outside a group of %d", rank, world);
+        std::unique_ptr<nc_group> g(new nc_group());
+        g->world = world; g->rank = rank;
+        g->m.resize(1);
+        init_member(g->m[0], local);
+        ncclUniqueId id;
+        std::memcpy(id.internal, uid, NCCL_UNIQUE_ID_BYTES);
+        NC_RCCL(rccl().CommInitRank(&g->m[0].comm, world, id, rank));
+        *out = g.release();
+    });
+}
+
+nc_status nc_group_create_local(int32_t ndev, nc_codec* const* handles, nc_group** out) {
+    return guard([&] {
+        if (!out || !handles) fail(NC_EINVAL, "handles and out must not be null");
+        *out = nullptr;
+        if (ndev <= 0 || ndev > 64) fail(NC_EINVAL, "bad device count %d", ndev);
+        std::unique_ptr<nc_group> g(new nc_group());
+        g->world = ndev; g->rank = -1;
+        g->m.resize((size_t)ndev);
+        std::vector<int> devs((size_t)ndev);
+        for (int d = 0; d < ndev; ++d) {
+            init_member(g->m[(size_t)d], handles[d]);
+            devs[(size_t)d] = handles[d]->impl->device;
+            for (int e = 0; e < d; ++e)
+                if (devs[(size_t)e] == devs[(size_t)d]) fail(NC_EINVAL, "handles %d and %d live on the same device %d", e, d, devs[(size_t)d]);
+            if (handles[d]->kind != handles[0]->kind) fail(NC_EINVAL, "the handles of a group must be of one codec kind");
+        }
+        std::vector<ncclComm_t> comms((size_t)ndev);
+        NC_RCCL(rccl().CommInitAll(comms.data(), ndev, devs.data()));
+        for (int d = 0; d < ndev; ++d) g->m[(size_t)d].comm = comms[(size_t)d];
+        *out = g.release();
+    });
+}
+
+nc_status nc_group_destroy(nc_group* g) {
+    return guard([&] { delete g; });
+}
+
+nc_status nc_group_info(const nc_group* g, int32_t* world, int32_t* rank) {
+    return guard([&] {
+        if (!g) fail(NC_EINVAL, "null group");
+        if (world) *world = g->world;
+        if (rank) *rank = g->rank;
+    });
+}
+
+nc_status nc_group_dac_encode_allgather_dev(nc_group* g, const float* pcm, int32_t B_local, int64_t T, int32_t sample_rate, int32_t n_q,
+                                            int64_t* codes_all, float* z_local, float* latents_local) {
+    return guard([&] { rank_encode_allgather(g, 0, pcm, B_local, T, sample_rate, n_q, codes_all, z_local, latents_local); });
+}
+
+nc_status nc_group_snac_encode_allgather_dev(nc_group* g, const float* pcm, int32_t B_local, int64_t T, int64_t* codes_all) {
+    return guard([&] { rank_encode_allgather(g, 1, pcm, B_local, T, 0, 0, codes_all, nullptr, nullptr); });
+}
+
+nc_status nc_group_wait(nc_group* g) {
+    return guard([&] {
+        if (!g || g->m.empty()) fail(NC_EINVAL, "null group");
+        for (auto& x : g->m) {
+            x.h->impl->use_device();
+            NC_HIP(hipStreamWaitEvent(x.h->impl->stream, x.ev_gather, 0));
+        }
+    });
+}
+
+nc_status nc_group_dac_encode_allgather(nc_group* g, const float* pcm, int32_t B_total, int64_t T, int32_t sample_rate, int32_t n_q, int64_t* codes,
+                                        float* z) {
+    return guard([&] { local_encode_allgather(g, 0, pcm, B_total, T, sample_rate, n_q, codes, z); });
+}
+
+nc_status nc_group_snac_encode_allgather(nc_group* g, const float* pcm, int32_t B_total, int64_t T, int64_t* codes) {
+    return guard([&] { local_encode_allgather(g, 1, pcm, B_total, T, 0, 0, codes, nullptr); });
+}
+
+}  // extern "C"

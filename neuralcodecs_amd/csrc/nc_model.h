@@ -232,3 +232,9 @@ struct EncodecModel : Codec {
 };
 
 }  // namespace nc
+
+// the opaque handle of the C ABI
+struct nc_codec {
+    std::unique_ptr<nc::Codec> impl;
+    int kind = 0;  // 0 = DAC, 1 = SNAC, 2 = Encodec
+};

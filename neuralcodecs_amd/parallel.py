@@ -70,3 +70,116 @@ def split_levels(flat, widths: Sequence[int]):
         out.append(flat[:, o:o + w])
         o += w
     return out
+
+
+class Group:
+    """nc_group of the C ABI (include/nc_mi355x.h "multi-GPU groups"): the sharded encode + RCCL all-gather without torch.distributed.
+
+    rank mode  -- Group.rank(world, rank, uid, codec): one process per GPU; `uid` = Group.unique_id() drawn by rank 0 and handed to
+                  the other ranks out of band (bench.py broadcasts it over the process group it already has).
+    local mode -- Group.local([codec_dev0, codec_dev1, ...]): one process drives all devices (the layout of a single C# host).
+    """
+
+    def __init__(self, handle, world, rank, codecs):
+        self._g, self.world, self.rank_id, self._codecs = handle, world, rank, codecs
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _lib
+        buf = (C.c_char * 128)()
+        _lib.check(_lib.lib().nc_group_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def rank(cls, world: int, rank: int, uid: bytes, codec) -> "Group":
+        import ctypes as C
+        from . import _lib
+        g = C.c_void_p()
+        _lib.check(_lib.lib().nc_group_create_rank(world, rank, uid, codec._h, C.byref(g)))
+        return cls(g, world, rank, [codec])
+
+    @classmethod
+    def local(cls, codecs: Sequence) -> "Group":
+        import ctypes as C
+        from . import _lib
+        arr = (C.c_void_p * len(codecs))(*[c._h for c in codecs])
+        g = C.c_void_p()
+        _lib.check(_lib.lib().nc_group_create_local(len(codecs), arr, C.byref(g)))
+        return cls(g, len(codecs), -1, list(codecs))
+
+    def dispose(self):
+        if self._g:
+            from . import _lib
+            _lib.lib().nc_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.dispose()
+        except Exception:
+            pass
+
+    # ---- rank mode: torch CUDA tensors, asynchronous on the codec's stream + the group's side stream -----------------------------
+    def dac_encode_allgather(self, pcm, codes_all=None, n_quantizers: int = 0):
+        """pcm [B_local,1,T] (torch, cuda) -> (z_local, codes_all [world*B_local, n_q, T'], latents_local); call wait() before
+        reading codes_all on the codec's stream."""
+        import torch
+        from . import _lib
+        m = self._codecs[0]
+        B, _, T = pcm.shape
+        Tz = m.frames(T)
+        nq = n_quantizers if 0 < n_quantizers <= m.config.n_codebooks else m.config.n_codebooks
+        x = pcm.contiguous().to(torch.float32)
+        if codes_all is None:
+            codes_all = torch.empty((self.world * B, nq, Tz), dtype=torch.int64, device=x.device)
+        z = torch.empty((B, m.latent_dim, Tz), dtype=torch.float32, device=x.device)
+        lat = torch.empty((B, nq * m.config.codebook_dim, Tz), dtype=torch.float32, device=x.device)
+        m._bind_torch_stream()
+        _lib.check(_lib.lib().nc_group_dac_encode_allgather_dev(self._g, x.data_ptr(), B, T, m.config.sample_rate, n_quantizers,
+                                                                codes_all.data_ptr(), z.data_ptr(), lat.data_ptr()))
+        return z, codes_all, lat
+
+    def snac_encode_allgather(self, pcm, codes_all=None):
+        """pcm [B_local,1,T] (torch, cuda) -> codes_all [world*B_local, sum(level widths)] (split_levels restores the level list)."""
+        import torch
+        from . import _lib
+        m = self._codecs[0]
+        B, _, T = pcm.shape
+        widths = m.query(T)[2]
+        x = pcm.contiguous().to(torch.float32)
+        if codes_all is None:
+            codes_all = torch.empty((self.world * B, sum(widths)), dtype=torch.int64, device=x.device)
+        m._bind_torch_stream()
+        _lib.check(_lib.lib().nc_group_snac_encode_allgather_dev(self._g, x.data_ptr(), B, T, codes_all.data_ptr()))
+        return codes_all, widths
+
+    def wait(self):
+        from . import _lib
+        _lib.check(_lib.lib().nc_group_wait(self._g))
+
+    # ---- local mode: numpy in / numpy out, synchronous ----------------------------------------------------------------------------
+    def dac_encode_allgather_host(self, pcm, n_quantizers: int = 0, return_z: bool = False):
+        import numpy as np
+        from . import _lib
+        m = self._codecs[0]
+        x = np.ascontiguousarray(pcm, dtype=np.float32)
+        B, _, T = x.shape
+        Tz = m.frames(T)
+        nq = n_quantizers if 0 < n_quantizers <= m.config.n_codebooks else m.config.n_codebooks
+        codes = np.empty((B, nq, Tz), np.int64)
+        z = np.empty((B, m.latent_dim, Tz), np.float32) if return_z else None
+        _lib.check(_lib.lib().nc_group_dac_encode_allgather(self._g, x.ctypes.data, B, T, m.config.sample_rate, n_quantizers, codes.ctypes.data,
+                                                            z.ctypes.data if z is not None else None))
+        return (codes, z) if return_z else codes
+
+    def snac_encode_allgather_host(self, pcm):
+        import numpy as np
+        from . import _lib
+        m = self._codecs[0]
+        x = np.ascontiguousarray(pcm, dtype=np.float32)
+        B, _, T = x.shape
+        widths = m.query(T)[2]
+        codes = np.empty((B, sum(widths)), np.int64)
+        _lib.check(_lib.lib().nc_group_snac_encode_allgather(self._g, x.ctypes.data, B, T, codes.ctypes.data))
+        return split_levels(codes, widths)

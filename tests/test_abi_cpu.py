@@ -54,3 +54,40 @@ def test_no_cpu_fallback():
         DAC(DACConfig())
     with pytest.raises(_lib.NcDeviceError):
         ops.conv1d(np.zeros((1, 2, 8), np.float32), np.zeros((3, 2, 3), np.float32))
+
+
+def test_struct_layouts_agree_with_a_compiled_c_consumer(tmp_path):
+    """A C99 program built against include/nc_mi355x.h reports sizeof / offsetof of every struct that crosses the boundary; the
+    ctypes mirrors in neuralcodecs_amd/_lib.py must agree field by field (and the program links against the library and calls it)."""
+    import ctypes as C
+    import subprocess
+    structs = {"nc_dac_config": _lib.NcDacConfig, "nc_snac_config": _lib.NcSnacConfig, "nc_encodec_config": _lib.NcEncodecConfig,
+               "nc_profile_entry": _lib.NcProfileEntry, "nc_conv_desc": _lib.NcConvDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "nc_mi355x.h"', 'int main(void) {',
+             '  printf("version %s\\n", nc_version());', '  printf("devices %d\\n", nc_device_count() >= 0);',
+             '  printf("kc %d\\n", (int)NC_KC_COUNT);']
+    for cname, ct in structs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "consumer.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "consumer"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-l:libnc_mi355x.so", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe)], text=True).splitlines()
+    got = {}
+    for ln in out:
+        parts = ln.split()
+        if parts[0] == "version":
+            assert "gfx950" in ln
+        elif parts[0] == "kc":
+            assert int(parts[1]) == len(_lib.NC_KC_NAMES)
+        elif parts[0] != "devices":
+            got[(parts[0], parts[1])] = int(parts[2])
+    for cname, ct in structs.items():
+        assert got[(cname, "size")] == C.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert got[(cname, fname)] == getattr(ct, fname).offset, f"{cname}.{fname}"
