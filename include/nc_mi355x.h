@@ -112,6 +112,16 @@ NC_API nc_status nc_dac_decode_dev(nc_codec* h, const float* z, int32_t B, int64
 NC_API nc_status nc_dac_from_codes(nc_codec* h, const int64_t* codes, int32_t B, int32_t n_q, int64_t frames, float* z);
 NC_API nc_status nc_dac_from_codes_dev(nc_codec* h, const int64_t* codes, int32_t B, int32_t n_q, int64_t frames, float* z);
 
+/* replaces: Dia.Decode(Tensor audioCodes[T, n_q])  Models/Dia.cs:973-981  (FromCodes(codes.unsqueeze(0).transpose(1, 2)) -> Decode) and
+ *           AudioUtils.Decode(DAC, codes)           Modules/Dia/AudioUtils.cs:189-199, batched: codes_tq int64 [B, T', n_q] (Dia's layout)
+ *           -> pcm [B, 1, T'*hop].  The transpose to DAC's [B, n_q, T'] is a device kernel.
+ * replaces: Dia.Encode(Tensor audio[1, T])          Models/Dia.cs:989-1002 (Encode -> squeeze(0).transpose(0, 1)), batched:
+ *           pcm [B, 1, T] -> codes_tq int64 [B, T', n_q] (all codebooks) */
+NC_API nc_status nc_dac_decode_code_matrix(nc_codec* h, const int64_t* codes_tq, int32_t B, int64_t frames, int32_t n_q, float* pcm);
+NC_API nc_status nc_dac_decode_code_matrix_dev(nc_codec* h, const int64_t* codes_tq, int32_t B, int64_t frames, int32_t n_q, float* pcm);
+NC_API nc_status nc_dac_encode_code_matrix(nc_codec* h, const float* pcm, int32_t B, int64_t T, int32_t sample_rate, int64_t* codes_tq);
+NC_API nc_status nc_dac_encode_code_matrix_dev(nc_codec* h, const float* pcm, int32_t B, int64_t T, int32_t sample_rate, int64_t* codes_tq);
+
 /* ----------------------------------------------------------------------------------------- SNAC
  * replaces: new SNAC(SNACConfig)                   NeuralCodecs.Torch/Models/SNAC.cs:34-63
  *           fields consumed                        NeuralCodecs.Torch/Config/SNAC/SNACConfig.cs:40-100 */

@@ -80,6 +80,10 @@ SYMBOLS = [
     ("nc_dac_decode_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
     ("nc_dac_from_codes", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, _P]),
     ("nc_dac_from_codes_dev", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, _P]),
+    ("nc_dac_decode_code_matrix", C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
+    ("nc_dac_decode_code_matrix_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
+    ("nc_dac_encode_code_matrix", C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
+    ("nc_dac_encode_code_matrix_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
     ("nc_snac_create", C.c_int, [C.POINTER(NcSnacConfig), C.c_int, C.POINTER(_P)]),
     ("nc_snac_query", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

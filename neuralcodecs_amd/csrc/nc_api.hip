@@ -211,6 +211,43 @@ nc_status nc_dac_from_codes(nc_codec* h, const int64_t* codes, int32_t B, int32_
     });
 }
 
+nc_status nc_dac_decode_code_matrix_dev(nc_codec* h, const int64_t* codes_tq, int32_t B, int64_t frames, int32_t n_q, float* pcm) {
+    return guard([&] { as_dac(h).decode_code_matrix_dev(codes_tq, B, frames, n_q, pcm); });
+}
+nc_status nc_dac_encode_code_matrix_dev(nc_codec* h, const float* pcm, int32_t B, int64_t T, int32_t sample_rate, int64_t* codes_tq) {
+    return guard([&] { as_dac(h).encode_code_matrix_dev(pcm, B, T, sample_rate, codes_tq); });
+}
+nc_status nc_dac_decode_code_matrix(nc_codec* h, const int64_t* codes_tq, int32_t B, int64_t frames, int32_t n_q, float* pcm) {
+    return guard([&] {
+        DacModel& m = as_dac(h);
+        if (!codes_tq || !pcm) fail(NC_EINVAL, "codes and pcm must not be null");
+        if (B <= 0 || frames <= 0 || n_q <= 0) fail(NC_EINVAL, "bad code matrix shape");
+        m.use_device();
+        OwnStreamScope own(m);
+        const size_t n_codes = (size_t)B * n_q * frames * 8, n_out = (size_t)B * m.decoded_len(frames) * 4;
+        m.h_codes.reserve(n_codes); m.h_out.reserve(n_out);
+        h2d(m.h_codes.p, codes_tq, n_codes, m.stream);
+        m.decode_code_matrix_dev(m.h_codes.as<int64_t>(), B, frames, n_q, m.h_out.as<float>());
+        d2h(pcm, m.h_out.p, n_out, m.stream);
+        NC_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+nc_status nc_dac_encode_code_matrix(nc_codec* h, const float* pcm, int32_t B, int64_t T, int32_t sample_rate, int64_t* codes_tq) {
+    return guard([&] {
+        DacModel& m = as_dac(h);
+        if (!pcm || !codes_tq) fail(NC_EINVAL, "pcm and codes must not be null");
+        if (B <= 0 || T <= 0) fail(NC_EINVAL, "B and T must be positive");
+        m.use_device();
+        OwnStreamScope own(m);
+        const size_t n_in = (size_t)B * T * 4, n_codes = (size_t)B * m.cfg.n_codebooks * m.frames(T) * 8;
+        m.h_in.reserve(n_in); m.h_codes.reserve(n_codes);
+        h2d(m.h_in.p, pcm, n_in, m.stream);
+        m.encode_code_matrix_dev(m.h_in.as<float>(), B, T, sample_rate, m.h_codes.as<int64_t>());
+        d2h(codes_tq, m.h_codes.p, n_codes, m.stream);
+        NC_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
 // ---- SNAC ------------------------------------------------------------------------------------------
 nc_status nc_snac_create(const nc_snac_config* cfg, int device_index, nc_codec** out) {
     return guard([&] {

@@ -301,6 +301,43 @@ void DacModel::from_codes_dev(const int64_t* codes, int B, int n_q, int64_t Tz, 
     }
 }
 
+// Dia <-> DAC glue on the device (Models/Dia.cs:973-1002): Dia keeps codes as [T, n_q] matrices, DAC as [B, n_q, T]
+__global__ void code_matrix_transpose_kernel(const int64_t* __restrict__ src, int64_t* __restrict__ dst, int B, int R, int C) {
+    // src [B][R][C] -> dst [B][C][R]
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * R * C) return;
+    const int64_t c = i % C, r = (i / C) % R, b = i / ((int64_t)R * C);
+    dst[(b * C + c) * R + r] = src[i];
+}
+
+// Dia.Decode(audioCodes[T, n_q]) batched: FromCodes(codes.transpose(1, 2)) -> Decode -> [B, T*hop]   (Dia.cs:973-981)
+void DacModel::decode_code_matrix_dev(const int64_t* codes_tq, int B, int64_t Tz, int n_q, float* pcm) {
+    if (!codes_tq || !pcm) fail(NC_EINVAL, "codes and pcm must not be null");
+    if (B <= 0 || Tz <= 0 || n_q <= 0 || n_q > cfg.n_codebooks) fail(NC_EINVAL, "bad code matrix shape [%d,%lld,%d]", B, (long long)Tz, n_q);
+    use_device();
+    codes_ws.reserve((size_t)B * n_q * Tz * 8);
+    zq.reserve((size_t)B * latent * Tz * 4);
+    const int64_t n = (int64_t)B * Tz * n_q;
+    hipLaunchKernelGGL(code_matrix_transpose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, codes_tq, codes_ws.as<int64_t>(), B, (int)Tz, n_q);
+    NC_HIP(hipGetLastError());
+    from_codes_dev(codes_ws.as<int64_t>(), B, n_q, Tz, zq.as<float>());
+    decode_dev(zq.as<float>(), B, Tz, pcm);
+}
+
+// Dia.Encode(audio[1, T]) batched: Encode -> codes.squeeze(0).transpose(0, 1) -> [B, T', n_q]   (Dia.cs:989-1002)
+void DacModel::encode_code_matrix_dev(const float* pcm, int B, int64_t T, int sample_rate, int64_t* codes_tq) {
+    if (!pcm || !codes_tq) fail(NC_EINVAL, "pcm and codes must not be null");
+    if (B <= 0 || T <= 0) fail(NC_EINVAL, "B and T must be positive");
+    use_device();
+    const int nq = cfg.n_codebooks;
+    const int64_t Tz = frames(T);
+    codes_ws.reserve((size_t)B * nq * Tz * 8);
+    encode_dev(pcm, B, T, sample_rate, 0, codes_ws.as<int64_t>(), nullptr, nullptr);
+    const int64_t n = (int64_t)B * Tz * nq;
+    hipLaunchKernelGGL(code_matrix_transpose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, codes_ws.as<int64_t>(), codes_tq, B, nq, (int)Tz);
+    NC_HIP(hipGetLastError());
+}
+
 void DacModel::decode_dev(const float* z, int B, int64_t Tz, float* pcm) {
     if (!loaded) fail(NC_ESTATE, "weights not loaded (call nc_codec_load_weights first)");
     if (!z || !pcm) fail(NC_EINVAL, "z and pcm must not be null");

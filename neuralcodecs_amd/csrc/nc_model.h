@@ -98,6 +98,8 @@ struct DacModel : Codec {
     void encode_dev(const float* pcm, int B, int64_t T, int sample_rate, int n_q, int64_t* codes, float* z, float* latents);
     void decode_dev(const float* z, int B, int64_t frames, float* pcm);
     void from_codes_dev(const int64_t* codes, int B, int n_q, int64_t frames, float* z);
+    void decode_code_matrix_dev(const int64_t* codes_tq, int B, int64_t frames, int n_q, float* pcm);
+    void encode_code_matrix_dev(const float* pcm, int B, int64_t T, int sample_rate, int64_t* codes_tq);
 
   private:
     float* run_res_unit(ResUnit& ru, int dil, float* cur, int C, int64_t L, int B, int& cur_idx, const float* alpha_next);

@@ -196,26 +196,50 @@ class DAC(_lib.ProfileMixin):
     # ---- Dia <-> DAC glue -----------------------------------------------------------
     def decode_code_matrix(self, audio_codes):
         """Dia.Decode (Models/Dia.cs:973-981): codes [T, n_q] (or batched [B, T, n_q]) -> FromCodes -> Decode -> waveform
-        [T*hop] (or [B, T*hop]); the transpose to the engine's [B, n_q, T] happens here, batched clips decode in one launch set."""
+        [T*hop] (or [B, T*hop]).  One C-ABI call (nc_dac_decode_code_matrix[_dev]): the transpose to the engine's [B, n_q, T] is a
+        device kernel, batched clips decode in one launch set."""
         if audio_codes is None:
             raise ValueError("audio_codes must not be null")
         single = audio_codes.ndim == 2
         c = audio_codes[None] if single else audio_codes
         if c.ndim != 3:
             raise ValueError("codes must be [T, n_q] or [B, T, n_q]")
-        c = c.transpose(1, 2) if _is_torch(c) else np.transpose(c, (0, 2, 1))
-        audio = self.decode(self.from_codes(c))
-        audio = audio.reshape(audio.shape[0], -1)
+        B, Tz, nq = (int(v) for v in c.shape)
+        L = self.decoded_length(Tz)
+        if _is_torch(c):
+            import torch
+            cc = c.contiguous().to(torch.int64)
+            audio = torch.empty((B, L), dtype=torch.float32, device=cc.device)
+            self._bind_torch_stream()
+            _lib.check(_lib.lib().nc_dac_decode_code_matrix_dev(self._h, cc.data_ptr(), B, Tz, nq, audio.data_ptr()))
+        else:
+            cc = np.ascontiguousarray(c, dtype=np.int64)
+            audio = np.empty((B, L), np.float32)
+            _lib.check(_lib.lib().nc_dac_decode_code_matrix(self._h, cc.ctypes.data, B, Tz, nq, audio.ctypes.data))
         return audio[0] if single else audio
 
     def encode_to_code_matrix(self, audio, sample_rate: Optional[int] = None):
-        """Dia.Encode (Models/Dia.cs:989-1002): audio [C=1, T] (or [B, 1, T]) -> Encode -> codes [T', n_q] (or [B, T', n_q])."""
+        """Dia.Encode (Models/Dia.cs:989-1002): audio [C=1, T] (or [B, 1, T]) -> Encode -> codes [T', n_q] (or [B, T', n_q]);
+        one C-ABI call (nc_dac_encode_code_matrix[_dev])."""
         if audio is None:
             raise ValueError("audio must not be null")
         single = audio.ndim == 2
         a = audio[None] if single else audio
-        codes = self.encode(a, sample_rate=sample_rate)[1]
-        codes = codes.transpose(1, 2) if _is_torch(codes) else np.transpose(codes, (0, 2, 1))
+        if a.ndim != 3 or a.shape[1] != 1:
+            raise ValueError("audio must be [1, T] or [B, 1, T]")
+        sr = self.config.sample_rate if sample_rate is None else int(sample_rate)
+        B, _, T = (int(v) for v in a.shape)
+        Tz, nq = self.frames(T), self.config.n_codebooks
+        if _is_torch(a):
+            import torch
+            x = a.contiguous().to(torch.float32)
+            codes = torch.empty((B, Tz, nq), dtype=torch.int64, device=x.device)
+            self._bind_torch_stream()
+            _lib.check(_lib.lib().nc_dac_encode_code_matrix_dev(self._h, x.data_ptr(), B, T, sr, codes.data_ptr()))
+        else:
+            x = np.ascontiguousarray(a, dtype=np.float32)
+            codes = np.empty((B, Tz, nq), np.int64)
+            _lib.check(_lib.lib().nc_dac_encode_code_matrix(self._h, x.ctypes.data, B, T, sr, codes.ctypes.data))
         return codes[0] if single else codes
 
     @staticmethod

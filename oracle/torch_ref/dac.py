@@ -37,11 +37,16 @@ class TorchDAC:
         self.hop = cfg.hop_length
         self.taps: Dict[str, torch.Tensor] = {}
         self.record = False
+        # Deviations of the C# port that can be UNDONE to reproduce upstream (Descript / HF transformers) semantics, for the structural
+        # cross-check of tools/crosscheck_hf.py only: {"D1", "D2", "D4"}.  Empty = the reference's behaviour.
+        self.upstream = set()
 
     # ---- leaf modules -------------------------------------------------------------------
     def snake(self, x: torch.Tensor, key: str) -> torch.Tensor:
         # Snake1d.cs:52  where(alpha == 0, x, addcdiv(x, sin(alpha*x).pow_(2), alpha, 1))
         alpha = self.sd[key + ".alpha"]
+        if "D4" in self.upstream:                                              # upstream: x + sin^2(ax) / (a + 1e-9)
+            return x + (alpha + 1e-9).reciprocal() * torch.sin(alpha * x).pow(2)
         return torch.where(alpha == 0, x, torch.addcdiv(x, torch.sin(alpha * x).pow_(2), alpha, value=1))
 
     def _wn_weight(self, key: str) -> torch.Tensor:
@@ -49,6 +54,8 @@ class TorchDAC:
         v = self.sd[key + ".weight_v"]
         g = self.sd[key + ".weight_g"]
         v_norm = v.contiguous().pow(2).sum([1, 2], keepdim=True, dtype=torch.float32).sqrt()
+        if "D2" in self.upstream:                                              # upstream: v * g / ||v||
+            return torch.mul(v.div(v_norm), g.reshape(v.shape[0], 1, 1)).contiguous()
         normalized = v.div(v_norm.add(1e-7))
         return torch.mul(normalized, g.reshape(v.shape[0], 1, 1)).contiguous()
 
@@ -119,6 +126,9 @@ class TorchDAC:
         cb = self.sd[f"quantizer.quantizers.{i}.codebook.weight"].contiguous()
         shape = latents.shape
         enc = latents.transpose(1, 2).reshape(-1, cb.shape[1]).contiguous()
+        if "D1" in self.upstream:                                              # upstream: cosine-like lookup on l2-normalised vectors
+            enc = F.normalize(enc)
+            cb = F.normalize(cb)
         enc_sq = enc.pow(2).sum(1, keepdim=True)
         cb_sq = cb.pow(2).sum(1, keepdim=True)
         cross = torch.einsum("bd,nd->bn", enc, cb).mul_(2.0)

@@ -75,3 +75,151 @@ def test_missing_file_and_bad_codec(tmp_path):
     save_file({"a": np.zeros(3, np.float32)}, str(p))
     with pytest.raises(ValueError):
         checkpoint.convert_checkpoint(str(p), "wav2vec")
+
+
+# Transcribed by hand-rule from /root/reference/NeuralCodecs.Torch/Config/DAC/StateDictNameConverter.cs:273-340 (BuildKeyMap with its default
+# arguments resunitCount = 3, decoderBlockCount = 4, encoderBlockCount = 4): every entry is a literal, nothing here calls dac_key_map.
+REFERENCE_KEY_MAP = {
+    "decoder.conv1": "decoder.model.0",
+    "decoder.snake1": "decoder.model.5",
+    "decoder.conv2": "decoder.model.6",
+    "decoder.block.0.snake1": "decoder.model.1.block.0",
+    "decoder.block.0.conv_t1": "decoder.model.1.block.1",
+    "decoder.block.0.res_unit1.snake1": "decoder.model.1.block.2.block.0",
+    "decoder.block.0.res_unit1.conv1": "decoder.model.1.block.2.block.1",
+    "decoder.block.0.res_unit1.snake2": "decoder.model.1.block.2.block.2",
+    "decoder.block.0.res_unit1.conv2": "decoder.model.1.block.2.block.3",
+    "decoder.block.0.res_unit2.snake1": "decoder.model.1.block.3.block.0",
+    "decoder.block.0.res_unit2.conv1": "decoder.model.1.block.3.block.1",
+    "decoder.block.0.res_unit2.snake2": "decoder.model.1.block.3.block.2",
+    "decoder.block.0.res_unit2.conv2": "decoder.model.1.block.3.block.3",
+    "decoder.block.0.res_unit3.snake1": "decoder.model.1.block.4.block.0",
+    "decoder.block.0.res_unit3.conv1": "decoder.model.1.block.4.block.1",
+    "decoder.block.0.res_unit3.snake2": "decoder.model.1.block.4.block.2",
+    "decoder.block.0.res_unit3.conv2": "decoder.model.1.block.4.block.3",
+    "decoder.block.1.snake1": "decoder.model.2.block.0",
+    "decoder.block.1.conv_t1": "decoder.model.2.block.1",
+    "decoder.block.1.res_unit1.snake1": "decoder.model.2.block.2.block.0",
+    "decoder.block.1.res_unit1.conv1": "decoder.model.2.block.2.block.1",
+    "decoder.block.1.res_unit1.snake2": "decoder.model.2.block.2.block.2",
+    "decoder.block.1.res_unit1.conv2": "decoder.model.2.block.2.block.3",
+    "decoder.block.1.res_unit2.snake1": "decoder.model.2.block.3.block.0",
+    "decoder.block.1.res_unit2.conv1": "decoder.model.2.block.3.block.1",
+    "decoder.block.1.res_unit2.snake2": "decoder.model.2.block.3.block.2",
+    "decoder.block.1.res_unit2.conv2": "decoder.model.2.block.3.block.3",
+    "decoder.block.1.res_unit3.snake1": "decoder.model.2.block.4.block.0",
+    "decoder.block.1.res_unit3.conv1": "decoder.model.2.block.4.block.1",
+    "decoder.block.1.res_unit3.snake2": "decoder.model.2.block.4.block.2",
+    "decoder.block.1.res_unit3.conv2": "decoder.model.2.block.4.block.3",
+    "decoder.block.2.snake1": "decoder.model.3.block.0",
+    "decoder.block.2.conv_t1": "decoder.model.3.block.1",
+    "decoder.block.2.res_unit1.snake1": "decoder.model.3.block.2.block.0",
+    "decoder.block.2.res_unit1.conv1": "decoder.model.3.block.2.block.1",
+    "decoder.block.2.res_unit1.snake2": "decoder.model.3.block.2.block.2",
+    "decoder.block.2.res_unit1.conv2": "decoder.model.3.block.2.block.3",
+    "decoder.block.2.res_unit2.snake1": "decoder.model.3.block.3.block.0",
+    "decoder.block.2.res_unit2.conv1": "decoder.model.3.block.3.block.1",
+    "decoder.block.2.res_unit2.snake2": "decoder.model.3.block.3.block.2",
+    "decoder.block.2.res_unit2.conv2": "decoder.model.3.block.3.block.3",
+    "decoder.block.2.res_unit3.snake1": "decoder.model.3.block.4.block.0",
+    "decoder.block.2.res_unit3.conv1": "decoder.model.3.block.4.block.1",
+    "decoder.block.2.res_unit3.snake2": "decoder.model.3.block.4.block.2",
+    "decoder.block.2.res_unit3.conv2": "decoder.model.3.block.4.block.3",
+    "decoder.block.3.snake1": "decoder.model.4.block.0",
+    "decoder.block.3.conv_t1": "decoder.model.4.block.1",
+    "decoder.block.3.res_unit1.snake1": "decoder.model.4.block.2.block.0",
+    "decoder.block.3.res_unit1.conv1": "decoder.model.4.block.2.block.1",
+    "decoder.block.3.res_unit1.snake2": "decoder.model.4.block.2.block.2",
+    "decoder.block.3.res_unit1.conv2": "decoder.model.4.block.2.block.3",
+    "decoder.block.3.res_unit2.snake1": "decoder.model.4.block.3.block.0",
+    "decoder.block.3.res_unit2.conv1": "decoder.model.4.block.3.block.1",
+    "decoder.block.3.res_unit2.snake2": "decoder.model.4.block.3.block.2",
+    "decoder.block.3.res_unit2.conv2": "decoder.model.4.block.3.block.3",
+    "decoder.block.3.res_unit3.snake1": "decoder.model.4.block.4.block.0",
+    "decoder.block.3.res_unit3.conv1": "decoder.model.4.block.4.block.1",
+    "decoder.block.3.res_unit3.snake2": "decoder.model.4.block.4.block.2",
+    "decoder.block.3.res_unit3.conv2": "decoder.model.4.block.4.block.3",
+    "encoder.conv1": "encoder.block.0",
+    "encoder.snake1": "encoder.block.5",
+    "encoder.conv2": "encoder.block.6",
+    "encoder.block.0.snake1": "encoder.block.1.block.3",
+    "encoder.block.0.conv1": "encoder.block.1.block.4",
+    "encoder.block.0.res_unit1.snake1": "encoder.block.1.block.0.block.0",
+    "encoder.block.0.res_unit1.conv1": "encoder.block.1.block.0.block.1",
+    "encoder.block.0.res_unit1.snake2": "encoder.block.1.block.0.block.2",
+    "encoder.block.0.res_unit1.conv2": "encoder.block.1.block.0.block.3",
+    "encoder.block.0.res_unit2.snake1": "encoder.block.1.block.1.block.0",
+    "encoder.block.0.res_unit2.conv1": "encoder.block.1.block.1.block.1",
+    "encoder.block.0.res_unit2.snake2": "encoder.block.1.block.1.block.2",
+    "encoder.block.0.res_unit2.conv2": "encoder.block.1.block.1.block.3",
+    "encoder.block.0.res_unit3.snake1": "encoder.block.1.block.2.block.0",
+    "encoder.block.0.res_unit3.conv1": "encoder.block.1.block.2.block.1",
+    "encoder.block.0.res_unit3.snake2": "encoder.block.1.block.2.block.2",
+    "encoder.block.0.res_unit3.conv2": "encoder.block.1.block.2.block.3",
+    "encoder.block.1.snake1": "encoder.block.2.block.3",
+    "encoder.block.1.conv1": "encoder.block.2.block.4",
+    "encoder.block.1.res_unit1.snake1": "encoder.block.2.block.0.block.0",
+    "encoder.block.1.res_unit1.conv1": "encoder.block.2.block.0.block.1",
+    "encoder.block.1.res_unit1.snake2": "encoder.block.2.block.0.block.2",
+    "encoder.block.1.res_unit1.conv2": "encoder.block.2.block.0.block.3",
+    "encoder.block.1.res_unit2.snake1": "encoder.block.2.block.1.block.0",
+    "encoder.block.1.res_unit2.conv1": "encoder.block.2.block.1.block.1",
+    "encoder.block.1.res_unit2.snake2": "encoder.block.2.block.1.block.2",
+    "encoder.block.1.res_unit2.conv2": "encoder.block.2.block.1.block.3",
+    "encoder.block.1.res_unit3.snake1": "encoder.block.2.block.2.block.0",
+    "encoder.block.1.res_unit3.conv1": "encoder.block.2.block.2.block.1",
+    "encoder.block.1.res_unit3.snake2": "encoder.block.2.block.2.block.2",
+    "encoder.block.1.res_unit3.conv2": "encoder.block.2.block.2.block.3",
+    "encoder.block.2.snake1": "encoder.block.3.block.3",
+    "encoder.block.2.conv1": "encoder.block.3.block.4",
+    "encoder.block.2.res_unit1.snake1": "encoder.block.3.block.0.block.0",
+    "encoder.block.2.res_unit1.conv1": "encoder.block.3.block.0.block.1",
+    "encoder.block.2.res_unit1.snake2": "encoder.block.3.block.0.block.2",
+    "encoder.block.2.res_unit1.conv2": "encoder.block.3.block.0.block.3",
+    "encoder.block.2.res_unit2.snake1": "encoder.block.3.block.1.block.0",
+    "encoder.block.2.res_unit2.conv1": "encoder.block.3.block.1.block.1",
+    "encoder.block.2.res_unit2.snake2": "encoder.block.3.block.1.block.2",
+    "encoder.block.2.res_unit2.conv2": "encoder.block.3.block.1.block.3",
+    "encoder.block.2.res_unit3.snake1": "encoder.block.3.block.2.block.0",
+    "encoder.block.2.res_unit3.conv1": "encoder.block.3.block.2.block.1",
+    "encoder.block.2.res_unit3.snake2": "encoder.block.3.block.2.block.2",
+    "encoder.block.2.res_unit3.conv2": "encoder.block.3.block.2.block.3",
+    "encoder.block.3.snake1": "encoder.block.4.block.3",
+    "encoder.block.3.conv1": "encoder.block.4.block.4",
+    "encoder.block.3.res_unit1.snake1": "encoder.block.4.block.0.block.0",
+    "encoder.block.3.res_unit1.conv1": "encoder.block.4.block.0.block.1",
+    "encoder.block.3.res_unit1.snake2": "encoder.block.4.block.0.block.2",
+    "encoder.block.3.res_unit1.conv2": "encoder.block.4.block.0.block.3",
+    "encoder.block.3.res_unit2.snake1": "encoder.block.4.block.1.block.0",
+    "encoder.block.3.res_unit2.conv1": "encoder.block.4.block.1.block.1",
+    "encoder.block.3.res_unit2.snake2": "encoder.block.4.block.1.block.2",
+    "encoder.block.3.res_unit2.conv2": "encoder.block.4.block.1.block.3",
+    "encoder.block.3.res_unit3.snake1": "encoder.block.4.block.2.block.0",
+    "encoder.block.3.res_unit3.conv1": "encoder.block.4.block.2.block.1",
+    "encoder.block.3.res_unit3.snake2": "encoder.block.4.block.2.block.2",
+    "encoder.block.3.res_unit3.conv2": "encoder.block.4.block.2.block.3",
+}
+
+
+def test_key_map_equals_the_reference_table_literally():
+    assert len(REFERENCE_KEY_MAP) == 118
+    assert checkpoint.dac_key_map(3, 4, 4) == REFERENCE_KEY_MAP
+
+
+def test_translate_key_rules():
+    """TranslateKey (StateDictNameConverter.cs:342-376): conv weights become weight_v (+ weight_g = norm), Snake alphas keep .alpha,
+    in_proj / out_proj weights outside the map are split too, everything else passes through."""
+    sd = {"encoder.block.2.res_unit1.conv1.weight": np.ones((4, 4, 7), np.float32), "encoder.block.2.res_unit1.conv1.bias": np.zeros(4, np.float32),
+          "decoder.block.0.conv_t1.weight": np.full((8, 4, 16), 2.0, np.float32), "decoder.block.3.res_unit3.snake2.alpha": np.ones(4, np.float32),
+          "decoder.snake1.alpha": np.ones(4, np.float32), "encoder.conv1.weight": np.ones((4, 1, 7), np.float32),   # marks the dict as HF-named
+          "quantizer.quantizers.0.in_proj.weight": np.ones((8, 16, 1), np.float32), "quantizer.quantizers.0.in_proj.bias": np.zeros(8, np.float32),
+          "quantizer.quantizers.0.codebook.weight": np.zeros((32, 8), np.float32)}
+    out = checkpoint.convert_dac_state_dict(sd)
+    want = {"encoder.block.3.block.0.block.1.weight_v", "encoder.block.3.block.0.block.1.weight_g", "encoder.block.3.block.0.block.1.bias",
+            "decoder.model.1.block.1.weight_v", "decoder.model.1.block.1.weight_g", "decoder.model.4.block.4.block.2.alpha",
+            "decoder.model.5.alpha", "encoder.block.0.weight_v", "encoder.block.0.weight_g",
+            "quantizer.quantizers.0.in_proj.weight_v", "quantizer.quantizers.0.in_proj.weight_g", "quantizer.quantizers.0.in_proj.bias",
+            "quantizer.quantizers.0.codebook.weight"}
+    assert set(out) == want
+    assert out["decoder.model.1.block.1.weight_g"].shape == (8, 1, 1) and np.allclose(out["decoder.model.1.block.1.weight_g"], np.sqrt(4 * 16 * 4.0))
+    assert out["decoder.model.4.block.4.block.2.alpha"].shape == (1, 4, 1)

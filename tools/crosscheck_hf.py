@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Structural cross-check of the oracle's torch restatement against an INDEPENDENT implementation of the upstream models
+(SURVEY 8c "cross-check aid"): HF `transformers` DacModel / EncodecModel, random-initialised, build container only.
+
+The reference (C#/TorchSharp) cannot run here and holds no vectors, so nothing can pin the oracle to TorchSharp output bit for bit.
+What CAN be checked is that oracle/torch_ref -- which restates the C# graph op for op -- is the same network as the upstream
+model it was ported from, once the port's documented arithmetic deviations (D1 un-normalised VQ distance, D2 weight-norm
+epsilon, D4 Snake epsilon) are switched back to upstream: same layer order, dilations, paddings, transposed-conv geometry, key map
+(the reference's StateDictNameConverter table, neuralcodecs_amd/checkpoint.py), quantizer recursion.  A layout or structure error in
+the restatement shows up here as an O(1) difference; agreement is to float32 round-off.
+
+    python tools/crosscheck_hf.py            # prints the max-abs differences per stage
+Nothing of this travels to the GPU box (transformers is only imported here and in tests/test_crosscheck_hf_cpu.py).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from neuralcodecs_amd import checkpoint  # noqa: E402
+from neuralcodecs_amd.config import DACConfig, EncodecConfig  # noqa: E402
+from oracle.torch_ref.dac import TorchDAC  # noqa: E402
+from oracle.torch_ref.encodec import TorchEncodec  # noqa: E402
+
+
+def crosscheck_dac(seed=0, T=3200):
+    from transformers import DacConfig as HFDacConfig, DacModel
+    torch.manual_seed(seed)
+    hcfg = HFDacConfig(encoder_hidden_size=8, downsampling_ratios=[2, 4, 5, 8], decoder_hidden_size=48, upsampling_ratios=[8, 5, 4, 2],
+                       n_codebooks=4, codebook_size=64, codebook_dim=8, sampling_rate=16000)
+    hf = DacModel(hcfg).eval()
+    with torch.no_grad():                                     # random-init gives unit Snake alphas and tiny weights: make them generic
+        for n, p in hf.named_parameters():
+            if n.endswith("alpha"):
+                p.copy_(torch.empty_like(p).uniform_(0.5, 2.0))
+            elif n.endswith("weight") and p.dim() == 3:
+                p.copy_(torch.randn_like(p) * (0.6 / np.sqrt(p.shape[1] * p.shape[2])))
+            elif n.endswith("codebook.weight"):
+                p.copy_(torch.randn_like(p))
+            elif n.endswith("bias"):
+                p.copy_(torch.randn_like(p) * 0.05)
+    sd_hf = {k: v.detach().numpy() for k, v in hf.state_dict().items()}
+    cfg = DACConfig(sample_rate=16000, encoder_dim=8, encoder_rates=(2, 4, 5, 8), decoder_dim=48, decoder_rates=(8, 5, 4, 2), n_codebooks=4,
+                    codebook_size=64, codebook_dim=8)
+    native = checkpoint.convert_dac_state_dict(sd_hf)         # the reference's key map + weight split
+    ours = TorchDAC(cfg, native)
+    ours.upstream = {"D1", "D2", "D4"}
+    x = torch.randn(2, 1, T) * 0.3
+    out = {}
+    with torch.inference_mode():
+        z_hf = hf.encoder(x)
+        z = ours.encoder(x)
+        out["encoder_max_abs"] = float((z - z_hf).abs().max())
+        out["encoder_scale"] = float(z_hf.abs().max())
+        q_hf = hf.quantizer(z_hf)
+        zq_hf, codes_hf = q_hf[0], q_hf[1]
+        zq, codes, _ = ours.rvq_forward(z_hf.clone())
+        out["codes_equal_frac"] = float((codes == codes_hf).float().mean())
+        same = (codes == codes_hf).all(dim=1)                 # frames where no stage flipped on a near-tie
+        out["zq_max_abs_same_frames"] = float(((zq - zq_hf).abs().amax(dim=1))[same].max()) if same.any() else None
+        a_hf = hf.decoder(zq_hf)
+        a = ours.decoder(zq_hf.clone())
+        out["decoder_max_abs"] = float((a - a_hf).abs().max())
+        out["decoder_scale"] = float(a_hf.abs().max())
+        # and the reference's own behaviour differs where it should: D1 changes the codes
+        ours.upstream = set()
+        _, codes_ref, _ = ours.rvq_forward(z_hf.clone())
+        out["codes_equal_frac_with_D1_as_in_reference"] = float((codes_ref == codes_hf).float().mean())
+    return out
+
+
+def crosscheck_encodec(seed=0, T=4000):
+    """HF EncodecModel (24 kHz layout: causal, weight-norm, no segmentation) vs oracle/torch_ref/encodec.py: encoder, decoder."""
+    from transformers import EncodecConfig as HFEncodecConfig, EncodecModel
+    torch.manual_seed(seed)
+    hcfg = HFEncodecConfig(sampling_rate=16000, audio_channels=1, num_filters=4, hidden_size=32, upsampling_ratios=[4, 3, 2, 2], codebook_size=64,
+                           codebook_dim=32, target_bandwidths=[1.5, 3.0, 6.0], normalize=False, use_causal_conv=True, norm_type="weight_norm",
+                           num_lstm_layers=2, compress=2, kernel_size=7, last_kernel_size=7, residual_kernel_size=3, use_conv_shortcut=True)
+    hf = EncodecModel(hcfg).eval()
+    sd = {}
+    for k, v in hf.state_dict().items():
+        sd[k] = v.detach().numpy()
+    cfg = EncodecConfig(sampling_rate=16000, channels=1, dimension=32, norm="weight_norm", causal=True, normalize=False,
+                        target_bandwidths=(1.5, 3.0, 6.0), bandwidth=3.0, codebook_size=64, n_filters=4, ratios=(4, 3, 2, 2))
+    native = {}
+    for k, v in sd.items():                                   # HF: parametrizations.weight.original0 (g) / original1 (v) -> weight_g / weight_v
+        k2 = k.replace(".parametrizations.weight.original0", ".weight_g").replace(".parametrizations.weight.original1", ".weight_v")
+        native[k2] = v
+    ours = TorchEncodec(cfg, native)
+    x = torch.randn(2, 1, T) * 0.3
+    out = {}
+    with torch.inference_mode():
+        e_hf = hf.encoder(x)
+        e = ours.encoder(x)
+        out["encoder_max_abs"] = float((e - e_hf).abs().max())
+        out["encoder_scale"] = float(e_hf.abs().max())
+        d_hf = hf.decoder(e_hf)
+        d = ours.decoder(e_hf.clone())
+        out["decoder_max_abs"] = float((d - d_hf).abs().max())
+    return out
+
+
+if __name__ == "__main__":
+    print("dac    ", crosscheck_dac())
+    print("encodec", crosscheck_encodec())
