@@ -427,6 +427,99 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(const LstmSeqArgs a) {
     }
 }
 
+// Granule form of the persistent LSTM layer: the data IS the flag (cdna_hip_programming.md G16, recipe R2).  h_t travels as 8-byte
+// {tag = t + 1, value} granules written by ONE write-through 64-bit store per lane; a consumer wave sweeps the 128 granules it needs
+// (relaxed agent-scope 64-bit loads, 512-byte rows) until every tag matches, then feeds the values to the matrix cores.  Compared
+// with the flag form above this removes, per step, the producer's store drain + workgroup barrier + flag store and the consumer's
+// flag poll + acquire fence + second round trip: one hop instead of two.  Double-buffered by step parity as before.
+typedef __attribute__((address_space(1))) unsigned long long lstm_gu64;
+template <int KS>
+__global__ __launch_bounds__(256, 1) void lstm_seq_granule_kernel(const LstmSeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lstm_lds[];   // [4 waves][KS][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int C = a.C, N = a.N;
+    const int64_t T = a.T;
+    const int ubw = blockIdx.x, tile = blockIdx.y;
+    const int ub = ubw * 4 + wave;
+    float* Aw = lstm_lds + wave * KS * 64;
+    const float* wsrc = a.whhp + (int64_t)ub * KS * 64;
+#pragma unroll
+    for (int i = 0; i < KS / 4; ++i)
+        __builtin_amdgcn_global_load_lds((lstm_gptr)(wsrc + i * 256 + lane * 4), (lstm_lptr)(Aw + i * 256), 16, 0, 0);
+    const int k4 = lane >> 4, cl = lane & 15;
+    const int j = ub * 4 + k4;
+    const int b = (a.tile0 + tile) * 16 + cl;
+    const int bb = min(b, N - 1);
+    const float* g = a.gi + ((int64_t)bb * 4 * C) * T;
+    const float bh0 = a.bhh[j], bh1 = a.bhh[C + j], bh2 = a.bhh[2 * C + j], bh3 = a.bhh[3 * C + j];
+    unsigned long long* const hx = reinterpret_cast<unsigned long long*>(a.hx);   // [2][tiles][C][16] granules
+    unsigned long long* const hx0 = hx + ((int64_t)(0 * gridDim.y + tile) * C) * 16;
+    unsigned long long* const hx1 = hx + ((int64_t)(1 * gridDim.y + tile) * C) * 16;
+    const int64_t orow = ((int64_t)bb * C + j) * T;
+    float cst = 0.0f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float g0 = g[(int64_t)j * T], g1 = g[(int64_t)(C + j) * T], g2 = g[(int64_t)(2 * C + j) * T], g3 = g[(int64_t)(3 * C + j) * T];
+    float sk = a.skip ? a.skip[orow] : 0.0f;
+    bool dead = false;
+    for (int64_t t = 0; t < T && !dead; ++t) {
+        f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float c0 = g0, c1 = g1, c2 = g2, c3 = g3, csk = sk;
+        const int64_t tn = min(t + 1, T - 1);
+        g0 = g[(int64_t)j * T + tn]; g1 = g[(int64_t)(C + j) * T + tn]; g2 = g[(int64_t)(2 * C + j) * T + tn]; g3 = g[(int64_t)(3 * C + j) * T + tn];
+        if (a.skip) sk = a.skip[orow + tn];
+        if (t > 0) {
+            const unsigned long long* hp = ((t & 1) ? hx0 : hx1) + lane;   // h_{t-1} sits in buffer (t-1)&1, tag t
+            const unsigned want = (unsigned)t;
+            float hb[KS];
+            // sweep in 4 chunks of KS/4 granules; a chunk is re-read until all its tags match (chunks become complete in any order,
+            // the matrix-core chain consumes them in k order)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned long long gr[KS / 4];
+#pragma unroll
+                    for (int i = 0; i < KS / 4; ++i)
+                        gr[i] = __hip_atomic_load((lstm_gu64*)(hp + (c * (KS / 4) + i) * 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < KS / 4; ++i) ok &= (unsigned)(gr[i] >> 32) == want;
+                    if (__all(ok)) {
+#pragma unroll
+                        for (int i = 0; i < KS / 4; ++i) hb[c * (KS / 4) + i] = __uint_as_float((unsigned)gr[i]);
+                        break;
+                    }
+                    if (++spins > (1u << 20) || ((spins & 255) == 255 && __hip_atomic_load((lstm_gu32*)a.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        if (lane == 0) __hip_atomic_store((lstm_gu32*)a.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dead = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (dead) break;
+            }
+            if (dead) break;
+#pragma unroll
+            for (int i = 0; i < KS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[i * 64 + lane], hb[i], acc, 0, 0, 0);
+        }
+        const float pi = c0 + (acc[0] + bh0);
+        const float pf = c1 + (acc[1] + bh1);
+        const float pg = c2 + (acc[2] + bh2);
+        const float po = c3 + (acc[3] + bh3);
+        const float ig = nc_sigmoidf(pi), fg = nc_sigmoidf(pf), gg = nc_tanhf(pg), og = nc_sigmoidf(po);
+        cst = (fg * cst) + (ig * gg);
+        const float h = og * nc_tanhf(cst);
+        if (t + 1 < T) {
+            unsigned long long* hq = ((t & 1) ? hx1 : hx0) + ub * 64 + lane;
+            __hip_atomic_store((lstm_gu64*)hq, ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned long long)__float_as_uint(h), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (b < N) a.out[orow + t] = a.skip ? h + csk : h;
+    }
+}
+
 // Euclidean codebook search, D <= 128 (EuclideanCodebook.cs:155-182): per frame dist_n = (|x|^2 + |e_n|^2) - 2*(x.e_n) with fma
 // chains over d ascending, argmin with lowest-index ties; then residual -= embed[idx] (ResidualVectorQuantizer.cs:150-152).
 // Block = EQ_F frames x 256 threads; thread n scans codes n, n+256, ...; codebook transposed [D][N] streams from L2.
@@ -928,16 +1021,18 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
                 const int nt = std::min(per_launch, n_tiles - t0);
                 LstmSeqArgs a{};
                 a.gi = gi; a.whhp = y.whhp.as<float>(); a.bhh = y.bhh.as<float>(); a.skip = last ? x : nullptr; a.out = out;
-                a.hx = alloc((size_t)2 * nt * C * 16);
+                static const bool use_flags = std::getenv("NC_LSTM_FLAGS") && std::getenv("NC_LSTM_FLAGS")[0] == '1';
+                a.hx = alloc((size_t)2 * nt * C * 16 * (use_flags ? 1 : 2));
                 a.flags = sync + 64 + (size_t)t0 * nprod; a.tmo = sync;
                 a.N = N; a.C = C; a.T = T; a.tile0 = t0;
-                if (KS == 128) {
-                    ensure_dynamic_lds((const void*)lstm_seq_kernel<128>, lds);
-                    hipLaunchKernelGGL(lstm_seq_kernel<128>, dim3((unsigned)nprod, (unsigned)nt), dim3(256), lds, stream, a);
-                } else {
-                    ensure_dynamic_lds((const void*)lstm_seq_kernel<16>, lds);
-                    hipLaunchKernelGGL(lstm_seq_kernel<16>, dim3((unsigned)nprod, (unsigned)nt), dim3(256), lds, stream, a);
-                }
+                // granule form: tags of a previous call could alias this call's (same step numbers): clear the exchange buffers
+                if (!use_flags) NC_HIP(hipMemsetAsync(a.hx, 0, (size_t)2 * nt * C * 16 * 8, stream));
+                auto launch = [&](auto kern) {
+                    ensure_dynamic_lds((const void*)kern, lds);
+                    hipLaunchKernelGGL(kern, dim3((unsigned)nprod, (unsigned)nt), dim3(256), lds, stream, a);
+                };
+                if (KS == 128) { if (use_flags) launch(lstm_seq_kernel<128>); else launch(lstm_seq_granule_kernel<128>); }
+                else { if (use_flags) launch(lstm_seq_kernel<16>); else launch(lstm_seq_granule_kernel<16>); }
             }
             NC_HIP(hipGetLastError());
             if (prof.on) prof.end(stream);

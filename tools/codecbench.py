@@ -41,6 +41,8 @@ def main():
     out = {}
     if not a.only or "snac" in a.only:
         for name, cfg, B, secs in (("snac24k_c1", SNACConfig.snac_24khz(), 1, 1.0), ("snac44k_c5_share", SNACConfig.snac_44khz(), 8, 5.0)):
+            if a.only.startswith("snac") and len(a.only) > 4 and a.only[4:] not in name:
+                continue
             m = SNAC(cfg)
             m.load_blob(save_blob(snac_synthetic_state_dict(cfg, seed=42)))
             T = int(secs * cfg.sampling_rate)
