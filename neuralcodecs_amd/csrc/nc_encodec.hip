@@ -851,10 +851,25 @@ void EncodecModel::load(const Blob& b) {
     }
     snprintf(nm, sizeof nm, "decoder.layers.%d", n + 1);
     load_sconv(b, nm, dec_out, nf, cfg.channels, cfg.last_kernel_size, 1, false);
-    lstm_sync.reserve(1 << 20);   // timeout word + exchange flags (4 bytes per workgroup of a launch group)
-    NC_HIP(hipMemset(lstm_sync.p, 0, 1 << 20));
+    lstm_sync.reserve(4096);
+    NC_HIP(hipMemset(lstm_sync.p, 0, 4096));
+    if (!ev_fork) {
+        for (int i = 0; i < 2; ++i) {
+            NC_HIP(hipStreamCreateWithFlags(&side_stream[i], hipStreamNonBlocking));
+            NC_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+        }
+        NC_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    }
     NC_HIP(hipDeviceSynchronize());
     loaded = true;
+}
+
+EncodecModel::~EncodecModel() {
+    for (int i = 0; i < 2; ++i) {
+        if (side_stream[i]) (void)hipStreamDestroy(side_stream[i]);
+        if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+    }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
 }
 
 void EncodecModel::check_async_errors() {
@@ -1014,16 +1029,18 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
             // persistent layer kernel: all T steps in one launch per group of column tiles (<= 128 co-resident workgroups)
             const int nprod = C / 16, n_tiles = (N + 15) / 16, per_launch = std::max(1, 128 / nprod);
             const size_t lds = (size_t)4 * KS * 64 * 4;
-            if (256 + (size_t)n_tiles * nprod * 4 > lstm_sync.cap) fail(NC_EUNSUPPORTED, "LSTM batch of %d rows exceeds the exchange flag area", N);
-            unsigned* sync = lstm_sync.as<unsigned>();
-            NC_HIP(hipMemsetAsync(sync + 64, 0, (size_t)n_tiles * nprod * 4, stream));   // flags; the timeout word [0] is zeroed at load
+            unsigned* sync = lstm_sync.as<unsigned>();                                     // [0] = timeout word (zeroed at load)
+            unsigned* flags_all = reinterpret_cast<unsigned*>(alloc((size_t)n_tiles * nprod));   // per call + layer: groups may run concurrently
+            NC_HIP(hipMemsetAsync(flags_all, 0, (size_t)n_tiles * nprod * 4, stream));
             for (int t0 = 0; t0 < n_tiles; t0 += per_launch) {
                 const int nt = std::min(per_launch, n_tiles - t0);
                 LstmSeqArgs a{};
                 a.gi = gi; a.whhp = y.whhp.as<float>(); a.bhh = y.bhh.as<float>(); a.skip = last ? x : nullptr; a.out = out;
-                static const bool use_flags = std::getenv("NC_LSTM_FLAGS") && std::getenv("NC_LSTM_FLAGS")[0] == '1';
+                // the granule form (data-is-flag) measured slower than the flag form (18.07 vs 17.04 ms on C3: its 64-bit sc1 sweeps go to
+                // the memory side where the flag form's plain loads hit L2): kept as an experiment behind NC_LSTM_GRANULES=1
+                static const bool use_flags = !(std::getenv("NC_LSTM_GRANULES") && std::getenv("NC_LSTM_GRANULES")[0] == '1');
                 a.hx = alloc((size_t)2 * nt * C * 16 * (use_flags ? 1 : 2));
-                a.flags = sync + 64 + (size_t)t0 * nprod; a.tmo = sync;
+                a.flags = flags_all + (size_t)t0 * nprod; a.tmo = sync;
                 a.N = N; a.C = C; a.T = T; a.tile0 = t0;
                 // granule form: tags of a previous call could alias this call's (same step numbers): clear the exchange buffers
                 if (!use_flags) NC_HIP(hipMemsetAsync(a.hx, 0, (size_t)2 * nt * C * 16 * 8, stream));
@@ -1142,6 +1159,12 @@ void EncodecModel::encode_dev(const float* pcm, int B, int64_t T, int64_t* codes
     const std::vector<Seg> segs = segments(T);
     const int C = cfg.channels, D = cfg.dimension;
     int64_t code_off = 0, emb_off = 0;
+    static const bool no_overlap = std::getenv("NC_ENCODEC_NO_OVERLAP") && std::getenv("NC_ENCODEC_NO_OVERLAP")[0] == '1';
+    hipStream_t const main_stream = stream;
+    struct Restore { hipStream_t& s; hipStream_t v; ~Restore() { s = v; } } restore{stream, main_stream};   // also on an exception
+    int n_groups = 0;
+    bool side_used[2] = {false, false};
+    NC_HIP(hipEventRecord(ev_fork, main_stream));
     // Consecutive segments of equal length run as ONE batch of G*B rows (every operator of the path is per sample: GroupNorm(1,C),
     // RMS scale, LSTM state, RVQ), segment-major -- so the batch's codes [G*B, n_q, T'] ARE the G frames' [B, n_q, T'] tensors laid
     // end to end, the layout the ABI emits.  Halves the number of dependent LSTM steps of a 2 s clip and doubles every grid.
@@ -1150,6 +1173,13 @@ void EncodecModel::encode_dev(const float* pcm, int B, int64_t T, int64_t* codes
         while (g < segs.size() && segs[g].len == segs[f].len && (int64_t)(g - f + 1) * B <= 4096) ++g;
         const int G = (int)(g - f);
         const Seg& s = segs[f];
+        const int side = (n_groups > 0 && !no_overlap) ? (n_groups - 1) % 2 : -1;   // groups after the first: side streams
+        if (side >= 0) {
+            stream = side_stream[side];
+            if (!side_used[side]) NC_HIP(hipStreamWaitEvent(stream, ev_fork, 0));
+            side_used[side] = true;
+        }
+        ++n_groups;
         float* x = alloc((size_t)G * B * C * s.len);
         for (int q = 0; q < G; ++q)   // slice segment f+q out of [B,C,T] into rows [q*B, (q+1)*B) of the dense [G*B,C,len] tensor
             NC_HIP(hipMemcpy2DAsync(x + (size_t)q * B * C * s.len, (size_t)s.len * 4, pcm + segs[f + q].off, (size_t)T * 4, (size_t)s.len * 4,
@@ -1158,8 +1188,14 @@ void EncodecModel::encode_dev(const float* pcm, int B, int64_t T, int64_t* codes
         encode_batch(x, G * B, s.len, s.frames, codes + code_off, sc, emb ? emb + emb_off : nullptr);
         code_off += (int64_t)G * B * n_q * s.frames;
         emb_off += (int64_t)G * B * D * s.frames;
+        stream = main_stream;
         f = g;
     }
+    for (int i = 0; i < 2; ++i)
+        if (side_used[i]) {
+            NC_HIP(hipEventRecord(ev_join[i], side_stream[i]));
+            NC_HIP(hipStreamWaitEvent(main_stream, ev_join[i], 0));
+        }
 }
 
 void EncodecModel::decode_dev(const int64_t* codes, const float* scales, int B, int64_t T, int nq, float* pcm) {
@@ -1176,10 +1212,23 @@ void EncodecModel::decode_dev(const int64_t* codes, const float* scales, int B, 
     std::vector<const float*> fp((size_t)nfr);
     std::vector<int64_t> flen((size_t)nfr);
     int64_t code_off = 0;
+    static const bool no_overlap = std::getenv("NC_ENCODEC_NO_OVERLAP") && std::getenv("NC_ENCODEC_NO_OVERLAP")[0] == '1';
+    hipStream_t const main_stream = stream;
+    struct Restore { hipStream_t& s; hipStream_t v; ~Restore() { s = v; } } restore{stream, main_stream};   // also on an exception
+    int n_groups = 0;
+    bool side_used[2] = {false, false};
+    NC_HIP(hipEventRecord(ev_fork, main_stream));
     for (size_t f = 0; f < segs.size();) {   // equal-length frames decode as one batch (see encode_dev)
         size_t g = f + 1;
         while (g < segs.size() && segs[g].frames == segs[f].frames && (int64_t)(g - f + 1) * B <= 4096) ++g;
         const int G = (int)(g - f);
+        const int side = (n_groups > 0 && !no_overlap) ? (n_groups - 1) % 2 : -1;
+        if (side >= 0) {
+            stream = side_stream[side];
+            if (!side_used[side]) NC_HIP(hipStreamWaitEvent(stream, ev_fork, 0));
+            side_used[side] = true;
+        }
+        ++n_groups;
         int64_t Lo = 0;
         const float* out = decode_batch(codes + code_off, G * B, nq, segs[f].frames, cfg.normalize ? scales + (int64_t)f * B : nullptr, &Lo);
         for (int q = 0; q < G; ++q) {
@@ -1187,8 +1236,14 @@ void EncodecModel::decode_dev(const int64_t* codes, const float* scales, int B, 
             flen[f + q] = Lo;
         }
         code_off += (int64_t)G * B * nq * segs[f].frames;
+        stream = main_stream;
         f = g;
     }
+    for (int i = 0; i < 2; ++i)
+        if (side_used[i]) {
+            NC_HIP(hipEventRecord(ev_join[i], side_stream[i]));
+            NC_HIP(hipStreamWaitEvent(main_stream, ev_join[i], 0));
+        }
     if (cfg.segment_length <= 0) {                                                           // single frame: DecodeFrame output as is
         NC_HIP(hipMemcpyAsync(pcm, fp[0], (size_t)B * C * flen[0] * 4, hipMemcpyDeviceToDevice, stream));
         return;

@@ -204,7 +204,12 @@ struct EncodecModel : Codec {
     std::vector<std::unique_ptr<DevBuf>> pool;   // per-call intermediates, same allocation order every call (grow-only)
     size_t pool_i = 0;
     DevBuf h_in, h_out, h_codes, h_scales, h_emb;
-    DevBuf lstm_sync;   // [0]: timeout word of the persistent LSTM kernel; [64..]: per-launch exchange flags
+    DevBuf lstm_sync;   // [0]: timeout word of the persistent LSTM kernels
+    // segment groups of one call are independent until the overlap-add: the first runs on the handle's stream, the others on side
+    // streams (forked / joined with events), so the short tail segment of a clip hides behind the full-length batch
+    hipStream_t side_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    ~EncodecModel() override;
 
     explicit EncodecModel(const nc_encodec_config& c);
     void check_async_errors() override;
