@@ -80,6 +80,9 @@ NC_API nc_status nc_codec_destroy(nc_codec* h);
  * weight-norm fold w = v/(||v||+1e-7)*g (WNConv1d.cs:145-150) happens once here. */
 NC_API nc_status nc_codec_load_weights(nc_codec* h, const char* path);
 NC_API nc_status nc_codec_load_weights_mem(nc_codec* h, const void* blob, size_t nbytes);
+/* Host-only validation of an NCWB0001 image (what the two loaders run first): every index field bounds-checked, (offset, size) pairs
+ * checked without overflow, dtype / byte-count consistency.  NC_EINVAL on a truncated or crafted image; needs no device. */
+NC_API nc_status nc_blob_check(const void* blob, size_t nbytes, int32_t* n_tensors);
 
 /* Run the handle's work on a caller-owned hipStream_t.  NULL is HIP's legacy default (null) stream -- the stream PyTorch-ROCm
  * uses by default -- so device buffers produced by the caller's framework are ordered with the engine's kernels.

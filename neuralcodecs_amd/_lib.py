@@ -70,6 +70,7 @@ SYMBOLS = [
     ("nc_codec_destroy", C.c_int, [_P]),
     ("nc_codec_load_weights", C.c_int, [_P, C.c_char_p]),
     ("nc_codec_load_weights_mem", C.c_int, [_P, _P, C.c_size_t]),
+    ("nc_blob_check", C.c_int, [_P, C.c_size_t, C.POINTER(C.c_int32)]),
     ("nc_codec_set_stream", C.c_int, [_P, _P]),
     ("nc_codec_reset_stream", C.c_int, [_P]),
     ("nc_codec_synchronize", C.c_int, [_P]),

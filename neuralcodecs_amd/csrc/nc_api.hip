@@ -96,6 +96,15 @@ nc_status nc_codec_load_weights_mem(nc_codec* h, const void* blob, size_t nbytes
     });
 }
 
+nc_status nc_blob_check(const void* blob, size_t nbytes, int32_t* n_tensors) {
+    return guard([&] {
+        if (!blob) fail(NC_EINVAL, "blob must not be null");
+        Blob b;
+        b.parse(blob, nbytes);
+        if (n_tensors) *n_tensors = (int32_t)b.tensors.size();
+    });
+}
+
 nc_status nc_codec_load_weights(nc_codec* h, const char* path) {
     return guard([&] {
         if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");

@@ -91,3 +91,34 @@ def test_struct_layouts_agree_with_a_compiled_c_consumer(tmp_path):
         assert got[(cname, "size")] == C.sizeof(ct), cname
         for fname, _ in ct._fields_:
             assert got[(cname, fname)] == getattr(ct, fname).offset, f"{cname}.{fname}"
+
+
+def test_blob_parser_rejects_truncated_and_crafted_images():
+    """nc_blob_check runs the loaders' parser on the host: every prefix of a valid image, and images with corrupted index fields,
+    must come back NC_EINVAL (never a crash / out-of-bounds read); the intact image passes."""
+    import ctypes as C
+    import struct
+    from neuralcodecs_amd.weights import save_blob
+    L = _lib.lib()
+    sd = {"a.weight_v": np.arange(24, dtype=np.float32).reshape(2, 3, 4), "b.bias": np.ones(5, np.float32), "c.alpha": np.zeros((1, 7, 1), np.float32)}
+    blob = save_blob(sd)
+    n = C.c_int32()
+    assert L.nc_blob_check(blob, len(blob), C.byref(n)) == _lib.NC_OK and n.value == 3
+    ok_from = min(c for c in range(len(blob) + 1) if L.nc_blob_check(blob[:c], c, None) == _lib.NC_OK)
+    assert len(blob) - 64 < ok_from <= len(blob)                   # only the alignment padding behind the last tensor may be cut
+    for cut in range(0, ok_from):
+        assert L.nc_blob_check(blob[:cut], cut, None) == _lib.NC_EINVAL, f"prefix of {cut} bytes accepted"
+    idx_len = struct.unpack_from("<Q", blob, 16)[0]
+    bad = bytearray(blob)
+    struct.pack_into("<Q", bad, 16, 2 ** 63)                       # index length that wraps the data origin
+    assert L.nc_blob_check(bytes(bad), len(bad), None) == _lib.NC_EINVAL
+    bad = bytearray(blob)
+    struct.pack_into("<Q", bad, 8, 1000)                           # more tensors than the index holds
+    assert L.nc_blob_check(bytes(bad), len(bad), None) == _lib.NC_EINVAL
+    # corrupt every byte of the index in turn: accepted or rejected, never a crash; a changed byte count must be rejected
+    for pos in range(24, 24 + int(idx_len)):
+        bad = bytearray(blob)
+        bad[pos] ^= 0xFF
+        assert L.nc_blob_check(bytes(bad), len(bad), None) in (_lib.NC_OK, _lib.NC_EINVAL)
+    assert L.nc_blob_check(b"NCWB0001" + b"\\0" * 8, 16, None) == _lib.NC_EINVAL
+    assert L.nc_blob_check(None, 0, None) == _lib.NC_EINVAL
