@@ -136,9 +136,10 @@ __global__ void layernorm_ct_kernel(const float* __restrict__ x, const float* __
     if (i >= (int64_t)B * T) return;
     const int64_t b = i / T, t = i - b * T;
     const float* xp = x + b * C * T + t;
-    // Channel loops run in batches of 8 reads issued together (same accumulation order as a plain loop); in the output loop this
-    // also keeps the reads of a batch ahead of its stores -- a read behind a store waits for the store's acknowledgement.
-    constexpr int U = 8;
+    // Channel loops run in batches of 32 reads issued together (same accumulation order as a plain loop): the kernel has only B*T
+    // threads (4608 at the C5 share) and is bound by its memory round trips, so each thread keeps 32 in flight; in the output loop
+    // this also keeps the reads of a batch ahead of its stores -- a read behind a store waits for the store's acknowledgement.
+    constexpr int U = 32;
     double s1 = 0.0;
     for (int c0 = 0; c0 < C; c0 += U) {
         float v[U];
@@ -197,15 +198,29 @@ __global__ __launch_bounds__(64) void local_attn_kernel(const float* __restrict_
     const int64_t t = (int64_t)wdx * W + i;
     float q[ATT_D];
     if (i < W) {
+        // 16 feature rows at a time: the 5 x 16 strided reads of a batch (q, k, their rotated partners, v) are all in flight before
+        // the batch's arithmetic and LDS stores (one memory round trip per batch instead of one per feature)
 #pragma unroll
-        for (int d = 0; d < ATT_D; ++d) {
-            const int dr = d < 32 ? d + 32 : d - 32;
-            const float qv = base[(int64_t)(h * 64 + d) * T + t], qr = base[(int64_t)(h * 64 + dr) * T + t];
-            const float kv = base[(int64_t)(C + h * 64 + d) * T + t], kr = base[(int64_t)(C + h * 64 + dr) * T + t];
-            const float c = cs[i * 64 + d], s = sn[i * 64 + d];
-            q[d] = (qv * c) + ((d < 32 ? -qr : qr) * s);
-            ks[i][d] = (kv * c) + ((d < 32 ? -kr : kr) * s);
-            vs[i][d] = base[(int64_t)(2 * C + h * 64 + d) * T + t];
+        for (int d0 = 0; d0 < ATT_D; d0 += 16) {
+            float qv[16], qr[16], kv[16], kr[16], vv[16], cc[16], ss[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int d = d0 + u, dr = d < 32 ? d + 32 : d - 32;
+                qv[u] = base[(int64_t)(h * 64 + d) * T + t];
+                qr[u] = base[(int64_t)(h * 64 + dr) * T + t];
+                kv[u] = base[(int64_t)(C + h * 64 + d) * T + t];
+                kr[u] = base[(int64_t)(C + h * 64 + dr) * T + t];
+                vv[u] = base[(int64_t)(2 * C + h * 64 + d) * T + t];
+                cc[u] = cs[i * 64 + d];
+                ss[u] = sn[i * 64 + d];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int d = d0 + u;
+                q[d] = (qv[u] * cc[u]) + ((d < 32 ? -qr[u] : qr[u]) * ss[u]);
+                ks[i][d] = (kv[u] * cc[u]) + ((d < 32 ? -kr[u] : kr[u]) * ss[u]);
+                vs[i][d] = vv[u];
+            }
         }
     }
     __syncthreads();
@@ -233,13 +248,18 @@ __global__ __launch_bounds__(64) void local_attn_kernel(const float* __restrict_
     for (int j = 0; j < ATT_W; ++j)
         if (j < W) s[j] = s[j] / sum;
     float* op = out + ((int64_t)b * C + h * 64) * T + t;
-#pragma unroll 4
-    for (int d = 0; d < ATT_D; ++d) {
-        float a = 0.0f;
+#pragma unroll 2
+    for (int d0 = 0; d0 < ATT_D; d0 += 8) {
+        float a[8];
 #pragma unroll
-        for (int j = 0; j < ATT_W; ++j)
-            if (j < W) a = nc_fma(s[j], vs[j][d], a);
-        op[(int64_t)d * T] = a;
+        for (int u = 0; u < 8; ++u) {
+            a[u] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < ATT_W; ++j)
+                if (j < W) a[u] = nc_fma(s[j], vs[j][d0 + u], a[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) op[(int64_t)(d0 + u) * T] = a[u];
     }
 }
 void launch_local_attn(const float* qkv, const float* cs, const float* sn, float* out, int B, int C, int64_t T, int W,
