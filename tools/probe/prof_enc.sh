@@ -1,10 +1,10 @@
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-OUT=$R/gpurun_out/r2e
+OUT=$R/gpurun_out/r2s
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats -d $OUT/fuse -o p -- python3 $R/tools/codecbench.py --only encodec48 --steps 3 --warmup 1 > $OUT/fuse.log 2>&1
-python3 $R/tools/rocpd_summary.py $(find $OUT/fuse -name 'p_results.db' | head -1) > $OUT/fuse.kernel_stats.txt
-export NC_ENCODEC_NO_FUSE=1
-rocprofv3 --kernel-trace --stats -d $OUT/nofuse -o p -- python3 $R/tools/codecbench.py --only encodec48 --steps 3 --warmup 1 > $OUT/nofuse.log 2>&1
-python3 $R/tools/rocpd_summary.py $(find $OUT/nofuse -name 'p_results.db' | head -1) > $OUT/nofuse.kernel_stats.txt
-tail -1 $OUT/fuse.log | cut -c1-300; tail -1 $OUT/nofuse.log | cut -c1-300
+for v in small nosmall; do
+  if [ $v = nosmall ]; then export NC_NO_SMALL=1; fi
+  python3 $R/tools/codecbench.py --only encodec48 --steps 10 --warmup 3 | tail -1
+  rocprofv3 --kernel-trace --stats -d $OUT/$v -o p -- python3 $R/tools/codecbench.py --only encodec48 --steps 3 --warmup 1 > $OUT/$v.log 2>&1
+  python3 $R/tools/rocpd_summary.py $(find $OUT/$v -name 'p_results.db' | head -1) > $OUT/$v.kernel_stats.txt
+done
