@@ -392,7 +392,6 @@ def main():
                        "collective": coll if use_dist else "none"},
             "roofline": roofline, "cpu_baseline": cpu, "extra_configs": extras,
         }
-        print(json.dumps(out), flush=True)
     if use_dist and rank == 0 and not args.no_check:
         if snac_mode:
             assert torch.equal(gathered[:B], torch.cat([c.reshape(B, -1) for c in codes], dim=1)), "gathered codes differ from the local codes"
@@ -401,6 +400,15 @@ def main():
     model.dispose()
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line goes out last: RCCL writes a version banner to the C stdio buffer of stdout, push that out first
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
