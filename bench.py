@@ -29,6 +29,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the CPU-baseline legs run two OpenMP runtimes in this process (the C oracle's and PyTorch's): keep their idle workers from spinning
+# against each other on many-core hosts (must be set before either starts)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
 
 import numpy as np  # noqa: E402
 

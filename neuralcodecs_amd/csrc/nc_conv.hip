@@ -57,6 +57,8 @@ static int experiment_mode(const char*) { return 0; }
 #endif
 conv_kernel_fn conv_kernel_table_sub_k2(int, int);
 conv_kernel_fn conv_kernel_table_sub_narrow_k2(int);
+conv_kernel_fn conv_kernel_table_slim_k3(int, int);
+conv_kernel_fn conv_kernel_table_slim_k7(int, int);
 conv_kernel_fn conv_kernel_table_narrow_k2(int);
 conv_kernel_fn conv_kernel_table_narrow_k3(int);
 conv_kernel_fn conv_kernel_table_narrow_k7(int);
@@ -404,6 +406,21 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
             nx = 5;
         }
     }
+    bool slim = false;
+    conv_kernel_fn slim_fn = nullptr;
+    {   // Slim variant: half-size reduction block (half the LDS per workgroup), 4+ workgroups per CU.  The narrow long-T layers
+        // (Cout <= 64: k=3 residual-branch convolutions of the SEANet blocks, the 2-channel Encodec stem) spend their time in memory
+        // round trips -- two reduction blocks per tile never fill the software pipeline -- so more resident workgroups overlap them:
+        // 215 -> 145 us (32->16 k3, 48000 steps x 32 clips), 152 -> 118 us (64->32), 80 -> 51 us (2->32 k7).  Measured neutral or
+        // slower for the strided k=4 / k=8 layers and the sub-pixel up-convolutions, which keep the standard blocks.
+        static const bool no_slim = std::getenv("NC_NO_SLIM") && std::getenv("NC_NO_SLIM")[0] == '1';
+        if (!no_slim && !light && !narrow && !io.fuse_k1 && !L.sub_shift && !L.transposed && c.TM <= 2 && n_cols_all >= 1024) {
+            int cb2 = 0, nx2 = 0;
+            if (c.K == 3 && c.CB == 16) { slim_fn = conv_kernel_table_slim_k3(c.TM, c.TN); cb2 = 8; nx2 = 10; }
+            else if (c.K == 7 && c.CB == 8 && L.Cin <= 4 && L.stride == 1 && L.dil == 1) { slim_fn = conv_kernel_table_slim_k7(c.TM, c.TN); cb2 = 4; nx2 = 5; }
+            if (slim_fn) { slim = true; c.CB = cb2; nx = nx2; }
+        }
+    }
     bool wide = false;
     {
         static const int wide_mode = experiment_mode("NC_WIDE");
@@ -507,6 +524,8 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     } else if (wide) {
         fn = conv_kernel_table_wide_k7(c.TM, c.TN);
         if (!fn) fail(NC_EUNSUPPORTED, "no wide conv kernel for TM=%d TN=%d", c.TM, c.TN);
+    } else if (slim) {
+        fn = slim_fn;
     } else if (light) {
         fn = conv_kernel_table_light_k7(c.TM, c.TN);
         if (!fn) fail(NC_EUNSUPPORTED, "no light conv kernel for TM=%d TN=%d", c.TM, c.TN);

@@ -3,3 +3,4 @@
 #include "nc_conv_kernel.hip.h"
 NC_INSTANTIATE_CONV_K(3, 16, 20)
 NC_INSTANTIATE_CONV_NARROW(3, 16, 20)
+NC_INSTANTIATE_CONV_SLIM(3, 8, 10)

@@ -19,3 +19,4 @@ extern "C" __attribute__((visibility("default"))) int nc_dbg_trace_read(unsigned
 }
 #endif
 NC_INSTANTIATE_CONV_NARROW(7, 8, 10)
+NC_INSTANTIATE_CONV_SLIM(7, 4, 5)

@@ -1006,6 +1006,22 @@ inline conv_kernel_fn get_conv_kernel() {
     }                                                                                                      \
     }
 
+// Slim variants: half-size reduction block (half the LDS per workgroup) compiled for 4 waves per SIMD, for the narrow long-T layers
+// (Cout <= 64) whose workgroups are bound by their memory round trips: more workgroups per CU overlap them.  Same packed weight image.
+#define NC_INSTANTIATE_CONV_SLIM(KVAL, CBVAL, NXVAL) NC_INSTANTIATE_CONV_SLIM_N(slim, KVAL, CBVAL, NXVAL)
+#define NC_INSTANTIATE_CONV_SLIM_N(NAME, KVAL, CBVAL, NXVAL)                                               \
+    namespace nc {                                                                                         \
+    conv_kernel_fn conv_kernel_table_##NAME##_k##KVAL(int TM, int TN) {                                        \
+        switch (TM * 10 + TN) {                                                                            \
+            case 11: return get_conv_kernel<1, 1, KVAL, CBVAL, NXVAL, false, 4>();                         \
+            case 12: return get_conv_kernel<1, 2, KVAL, CBVAL, NXVAL, false, 4>();                         \
+            case 21: return get_conv_kernel<2, 1, KVAL, CBVAL, NXVAL, false, 4>();                         \
+            case 22: return get_conv_kernel<2, 2, KVAL, CBVAL, NXVAL, false, 4>();                         \
+        }                                                                                                  \
+        return nullptr;                                                                                    \
+    }                                                                                                      \
+    }
+
 // Wide variants: 8 waves share one weight tile (BN = 512 columns), halving the weight traffic and staging per MFMA for the
 // long-clip layers; one workgroup per CU.
 #define NC_INSTANTIATE_CONV_WIDE(KVAL, CBVAL, NXVAL)                                                       \

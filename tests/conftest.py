@@ -2,6 +2,12 @@ import json
 import os
 import sys
 
+# Two OpenMP runtimes live in the test process (the C oracle's libgomp and PyTorch's): with the default active wait policy their idle
+# worker threads spin against each other on many-core hosts (measured on a 256-thread GPU box: 8.5 s -> more than 10 minutes for two
+# test files).  Must be set before either runtime starts its first parallel region.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 import numpy as np
 import pytest
 
