@@ -70,7 +70,7 @@ def dominant(classes):
 
 def load_traffic(key):
     """HBM bytes from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per
-    MI355X_MICROARCH.md), committed under profiles/traffic.json by tools/traffic_json.py: a measured constant of the build."""
+    MI355X_MICROARCH.md), committed under profiles/traffic.json by tools/pmc_classes.py: a measured constant of the build."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(p):
         return None

@@ -34,24 +34,45 @@ __device__ __forceinline__ float act_value(const ActView& v, int64_t b, int c, i
     return x;
 }
 
-// dst[b,c,j] = pad(elu?(GN(a) [+ GN(b2)]))[j],  j in [0,Lp): reflect over the zero-extended row of length Lz (SConv1d.cs:258-274)
-__global__ void pad_act_kernel(ActView a, ActView b2, int has_b, int elu, float* __restrict__ dst, int B, int C, int64_t L, int64_t Lz,
-                               int64_t left, int64_t Lp) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)B * C * Lp) return;
-    const int64_t j = i % Lp, r = i / Lp;
-    const int c = (int)(r % C);
-    const int64_t b = r / C;
-    int64_t q = j - left;
-    if (q < 0) q = -q;
-    if (q >= Lz) q = 2 * (Lz - 1) - q;
-    float v = 0.0f;
-    if (q < L) {
-        v = act_value(a, b, c, C, q);
-        if (has_b) v = v + act_value(b2, b, c, C, q);
-        if (elu) v = nc_eluf(v);
+// dst[b,c,j] = pad(elu?(GN(a) [+ GN(b2)]))[j],  j in [0,Lp): reflect over the zero-extended row of length Lz (SConv1d.cs:258-274).
+// Grid = (row segments of 1024, channels, samples): no index division, the per-(b,c) operands are scalars, 4 elements per thread
+// with all reads ahead of the stores.
+__global__ __launch_bounds__(256) void pad_act_kernel(ActView a, ActView b2, int has_b, int elu, float* __restrict__ dst, int C, int64_t L, int64_t Lz,
+                                                      int64_t left, int64_t Lp) {
+    const int c = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const float* ra = a.p + (b * C + c) * a.rs + a.off;
+    const float* rb = b2.p + (b * C + c) * b2.rs + b2.off;
+    const bool na = a.stats != nullptr, nb = has_b && b2.stats != nullptr;
+    const float mu_a = na ? a.stats[2 * b] : 0.0f, r_a = na ? a.stats[2 * b + 1] : 1.0f, g_a = na ? a.gamma[c] : 1.0f, be_a = na ? a.beta[c] : 0.0f;
+    const float mu_b = nb ? b2.stats[2 * b] : 0.0f, r_b = nb ? b2.stats[2 * b + 1] : 1.0f, g_b = nb ? b2.gamma[c] : 1.0f, be_b = nb ? b2.beta[c] : 0.0f;
+    float* out = dst + (b * C + c) * Lp;
+    float va[4], vb[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t j = (int64_t)blockIdx.x * 1024 + u * 256 + threadIdx.x;
+        int64_t q = j - left;
+        if (q < 0) q = -q;
+        if (q >= Lz) q = 2 * (Lz - 1) - q;
+        ok[u] = j < Lp && q >= 0 && q < L;
+        const int64_t qa = ok[u] ? q : 0;
+        va[u] = ra[qa];
+        vb[u] = has_b ? rb[qa] : 0.0f;
     }
-    dst[i] = v;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t j = (int64_t)blockIdx.x * 1024 + u * 256 + threadIdx.x;
+        float v = va[u];
+        if (na) v = ((v - mu_a) * r_a) * g_a + be_a;
+        if (has_b) {
+            float w = vb[u];
+            if (nb) w = ((w - mu_b) * r_b) * g_b + be_b;
+            v = v + w;
+        }
+        if (elu) v = nc_eluf(v);
+        if (j < Lp) out[j] = ok[u] ? v : 0.0f;
+    }
 }
 
 // Chunk sums of the GroupNorm statistics, canonical order (identical in oracle/c/nc_ref_encodec.c chunk_sums): a chunk is 256
@@ -899,8 +920,12 @@ float* EncodecModel::pad_act(const Act& a, const Act* b2, bool elu, int N, const
     float* dst = alloc((size_t)N * a.C * pl.Lp);
     const int64_t n = (int64_t)N * a.C * pl.Lp;
     ActView vb = b2 ? view_of(*b2) : view_of(a);
-    hipLaunchKernelGGL(pad_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, view_of(a), vb, b2 ? 1 : 0, elu ? 1 : 0, dst, N,
-                       a.C, a.L, pl.Lz, pl.left, pl.Lp);
+    (void)n;
+    {
+        ProfScope ps(&prof, stream, NC_KC_ELEM, 0.0, 4.0 * N * a.C * ((double)a.L * (b2 ? 2 : 1) + (double)pl.Lp));
+        hipLaunchKernelGGL(pad_act_kernel, dim3((unsigned)((pl.Lp + 1023) / 1024), (unsigned)a.C, (unsigned)N), dim3(256), 0, stream, view_of(a), vb,
+                           b2 ? 1 : 0, elu ? 1 : 0, dst, a.C, a.L, pl.Lz, pl.left, pl.Lp);
+    }
     NC_HIP(hipGetLastError());
     return dst;
 }
