@@ -16,7 +16,8 @@
 
 namespace nc {
 
-constexpr int GN_CHUNK = 256;
+constexpr int GN_CHUNK = 256;    // RMS-scale chunks
+constexpr int GNS_CHUNK = 1024;  // GroupNorm chunk: 64 slots x 16 strided samples
 
 // ---------------------------------------------------------------------------------------------- kernels
 struct ActView {          // [B,C,L] view of a raw conv output with its pending GroupNorm (applied by the consumer)
@@ -75,47 +76,39 @@ __global__ __launch_bounds__(256) void pad_act_kernel(ActView a, ActView b2, int
     }
 }
 
-// Chunk sums of the GroupNorm statistics, canonical order (identical in oracle/c/nc_ref_encodec.c chunk_sums): a chunk is 256
-// aligned samples of one row; lane i of a wavefront adds samples i, i+64, i+128, i+192 of the chunk (ascending, binary64, from +0),
+// Chunk sums of the GroupNorm statistics, canonical order (identical in oracle/c/nc_ref_encodec.c chunk_sums): a chunk is 1024
+// aligned samples of one row; lane i of a wavefront adds samples i, i+64, ..., i+960 of the chunk (ascending, binary64, from +0),
 // then the 64 lane sums are combined by the xor butterfly 32,16,8,4,2,1 (p_i <- p_i + p_{i^off}; addition commutes, so every lane
-// ends with the same value).  One wavefront per chunk pair: 8 coalesced 256-byte reads in flight, no LDS -- a streaming pass
-// (the tensor was just written by the conv and is largely still in L2 / the 256 MB Infinity Cache).
-constexpr int GN_WPC = 2;   // chunks per wavefront
+// ends with the same value).  One wavefront per chunk: 16 coalesced 256-byte reads in flight, one butterfly per 4 KB, no LDS -- a
+// streaming pass (the tensor was just written by the conv and is largely still in L2 / the 256 MB Infinity Cache).
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int64_t rows, int64_t T, int nchunk) {
     const int lane = threadIdx.x & 63;
     const int64_t total = rows * nchunk;
-    const int64_t c0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GN_WPC;
-    if (c0 >= total) return;
-    float v[GN_WPC][4];
+    const int64_t ci = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ci >= total) return;
+    const int64_t r = ci / nchunk, ch = ci - r * nchunk;
+    const float* row = x + r * T;
+    float v[16];
 #pragma unroll
-    for (int u = 0; u < GN_WPC; ++u) {
-        const int64_t ci = min(c0 + u, total - 1);
-        const int64_t r = ci / nchunk, ch = ci - r * nchunk;
-        const float* row = x + r * T;
+    for (int j = 0; j < 16; ++j) {
+        const int64_t t = ch * GNS_CHUNK + j * 64 + lane;
+        v[j] = t < T ? row[t] : 0.0f;
+    }
+    double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t t = ch * GN_CHUNK + j * 64 + lane;
-            v[u][j] = t < T ? row[t] : 0.0f;
-        }
+    for (int j = 0; j < 16; ++j) {
+        const double d = (double)v[j];
+        s1 += d;
+        s2 += d * d;
     }
 #pragma unroll
-    for (int u = 0; u < GN_WPC; ++u) {
-        double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double d = (double)v[u][j];
-            s1 += d;
-            s2 += d * d;
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            s1 += __shfl_xor(s1, off, 64);
-            s2 += __shfl_xor(s2, off, 64);
-        }
-        if (lane == 0 && c0 + u < total) {
-            part[2 * (c0 + u)] = s1;
-            part[2 * (c0 + u) + 1] = s2;
-        }
+    for (int off = 32; off >= 1; off >>= 1) {
+        s1 += __shfl_xor(s1, off, 64);
+        s2 += __shfl_xor(s2, off, 64);
+    }
+    if (lane == 0) {
+        part[2 * ci] = s1;
+        part[2 * ci + 1] = s2;
     }
 }
 // one block per sample: row totals (chunks ascending) in parallel, then rows ascending by one thread -> (mean, rstd)
@@ -932,13 +925,13 @@ float* EncodecModel::pad_act(const Act& a, const Act* b2, bool elu, int N, const
 
 const float* EncodecModel::gn_stats(const float* raw, int N, int C, int64_t L) {
     if (!cfg.time_group_norm) return nullptr;
-    const int nchunk = (int)((L + GN_CHUNK - 1) / GN_CHUNK);
+    const int nchunk = (int)((L + GNS_CHUNK - 1) / GNS_CHUNK);
     const int64_t nparts = (int64_t)N * C * nchunk;
     double* part = reinterpret_cast<double*>(alloc((size_t)nparts * 4));
     float* stats = alloc((size_t)N * 2);
     {
         ProfScope ps(&prof, stream, NC_KC_NORM, 3.0 * N * C * (double)L, 4.0 * N * C * (double)L);
-        hipLaunchKernelGGL(gn_partial_kernel, dim3((unsigned)((nparts + 4 * GN_WPC - 1) / (4 * GN_WPC))), dim3(256), 0, stream, raw, part, (int64_t)N * C, L,
+        hipLaunchKernelGGL(gn_partial_kernel, dim3((unsigned)((nparts + 3) / 4)), dim3(256), 0, stream, raw, part, (int64_t)N * C, L,
                            nchunk);
     }
     hipLaunchKernelGGL(gn_final_kernel, dim3((unsigned)N), dim3(256), (size_t)2 * C * sizeof(double), stream, part, stats, C, L, nchunk);

@@ -14,7 +14,7 @@
  *   AudioTools/AudioTensorDSP.cs:161-261 (LinearOverlapAdd), Utils/TorchUtils.cs:26-30 (ELU, alpha = 1)
  *
  * Canonical definitions added here:
- *   GroupNorm(1,C):  S1 = sum x, S2 = sum x*x in binary64, summed hierarchically: 256-sample chunks of one channel row (chunk_sums:
+ *   GroupNorm(1,C):  S1 = sum x, S2 = sum x*x in binary64, summed hierarchically: 1024-sample chunks of one channel row (chunk_sums:
  *                    64 strided slot sums + xor butterfly),
  *                    chunks of a row ascending, rows ascending.  mu = S1/N, var = max(S2/N - mu*mu, 0), r = (float)(1/sqrt(var + 1e-5)),
  *                    y = ((x - (float)mu) * r) * gamma[c] + beta[c]
@@ -86,15 +86,16 @@ static const float* get_weight(ref_encodec* m, const char* key, int* d0, int* d1
 }
 
 /* ---- canonical reductions --------------------------------------------------------------------------- */
-#define GN_CHUNK 256
-/* One chunk (n <= 256 samples): slot i of 64 adds samples i, i+64, i+128, i+192 (ascending, binary64, from +0); the 64 slot sums are
+#define GN_CHUNK 256     /* RMS-scale chunks */
+#define GNS_CHUNK 1024  /* GroupNorm chunks: 64 slots x 16 strided samples */
+/* One chunk (n <= 1024 samples): slot i of 64 adds samples i, i+64, ..., i+960 (ascending, binary64, from +0); the 64 slot sums are
  * combined by the xor butterfly 32,16,8,4,2,1 (p_i <- p_i + p_{i^off}).  A fixed tree of the width of a CDNA wavefront: the device
  * kernel runs it with one lane per slot. */
 static void chunk_sums(const float* x, int64_t n, double* s1_out, double* s2_out) {
     double p1[64], p2[64], q1[64], q2[64];
     for (int i = 0; i < 64; i++) {
         double a = 0.0, b = 0.0;
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < GNS_CHUNK / 64; j++) {
             const int64_t t = i + 64 * j;
             if (t < n) { const double v = (double)x[t]; a += v; b += v * v; }
         }
@@ -112,8 +113,8 @@ static void hier_sums(const float* x, int64_t R, int64_t T, double* s1_out, doub
     double S1 = 0.0, S2 = 0.0;
     for (int64_t r = 0; r < R; r++) {
         double r1 = 0.0, r2 = 0.0;
-        for (int64_t t0 = 0; t0 < T; t0 += GN_CHUNK) {
-            const int64_t t1 = t0 + GN_CHUNK < T ? t0 + GN_CHUNK : T;
+        for (int64_t t0 = 0; t0 < T; t0 += GNS_CHUNK) {
+            const int64_t t1 = t0 + GNS_CHUNK < T ? t0 + GNS_CHUNK : T;
             double c1, c2;
             chunk_sums(x + r * T + t0, t1 - t0, &c1, &c2);
             r1 += c1; r2 += c2;
