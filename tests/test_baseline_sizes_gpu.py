@@ -137,3 +137,21 @@ def test_handles_return_their_hbm_on_dispose():
         free, total = torch.cuda.mem_get_info()
         used.append(total - free)
     assert used[-1] - used[0] < 64 << 20, f"device memory grows across create/destroy cycles: {used}"
+
+
+def test_encodec_large_batch_lstm_tile_groups_batch_invariance():
+    """B = 40 x 2 equal segments = 80 LSTM columns = 5 column tiles: the persistent LSTM layer runs as two launch groups (4 + 1
+    tiles) next to the tail segment's group on a side stream; every clip must equal its result in a 4-clip batch."""
+    g = load_golden("encodec48k_b1")
+    cfg = encodec_cfg_from_meta(g["meta"])
+    m = Encodec(cfg)
+    m.load_blob(save_blob(encodec_synthetic_state_dict(cfg, seed=42)))
+    B, T = 40, 96000
+    pcm = synthetic_pcm(B, 2, T, cfg.sampling_rate, seed=77)
+    frames = m.encode(pcm)
+    audio = m.decode(frames, T)
+    for lo in (0, 16, 36):
+        f4 = m.encode(pcm[lo:lo + 4])
+        assert all(np.array_equal(a.codes, b.codes[lo:lo + 4]) and np.array_equal(a.scale, b.scale[lo:lo + 4]) for a, b in zip(f4, frames))
+        assert np.array_equal(m.decode(f4, T), audio[lo:lo + 4])
+    m.dispose()
