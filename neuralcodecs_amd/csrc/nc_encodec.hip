@@ -189,13 +189,31 @@ __global__ __launch_bounds__(64) void lstm_step_kernel(const float* __restrict__
     __syncthreads();
     const int b = blockIdx.y * 64 + threadIdx.x;
     if (b >= B) return;
-    float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, r3 = 0.0f;
-    for (int k = 0; k < C; ++k) {
-        const float h = hprev[(int64_t)k * B + b];
-        r0 = nc_fma(wrow[k], h, r0);
-        r1 = nc_fma(wrow[C + k], h, r1);
-        r2 = nc_fma(wrow[2 * C + k], h, r2);
-        r3 = nc_fma(wrow[3 * C + k], h, r3);
+    // recurrent contraction: four quarter chains combined as (q0 + q1) + (q2 + q3) (the canonical order: oracle slstm); one chain
+    // when C is not a multiple of 4
+    float r0, r1, r2, r3;
+    {
+        const int nq = (C % 4 == 0) ? 4 : 1, qlen = C / nq;
+        float q0[4], q1[4], q2[4], q3[4];
+        for (int s4 = 0; s4 < nq; ++s4) {
+            float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+            for (int k = s4 * qlen; k < (s4 + 1) * qlen; ++k) {
+                const float h = hprev[(int64_t)k * B + b];
+                c0 = nc_fma(wrow[k], h, c0);
+                c1 = nc_fma(wrow[C + k], h, c1);
+                c2 = nc_fma(wrow[2 * C + k], h, c2);
+                c3 = nc_fma(wrow[3 * C + k], h, c3);
+            }
+            q0[s4] = c0; q1[s4] = c1; q2[s4] = c2; q3[s4] = c3;
+        }
+        if (nq == 4) {
+            r0 = (q0[0] + q0[1]) + (q0[2] + q0[3]);
+            r1 = (q1[0] + q1[1]) + (q1[2] + q1[3]);
+            r2 = (q2[0] + q2[1]) + (q2[2] + q2[3]);
+            r3 = (q3[0] + q3[1]) + (q3[2] + q3[3]);
+        } else {
+            r0 = q0[0]; r1 = q1[0]; r2 = q2[0]; r3 = q3[0];
+        }
     }
     const float* g = gi + ((int64_t)b * 4 * C) * T + t;
     const float pi = g[(int64_t)j * T] + (r0 + bhh[j]);
@@ -211,135 +229,27 @@ __global__ __launch_bounds__(64) void lstm_step_kernel(const float* __restrict__
     out[o] = skip ? h + skip[o] : h;
 }
 
-// Matrix-core version of the LSTM step.  One wavefront owns 4 hidden units x 4 gates = 16 rows of W_hh and walks the 512-long
-// reduction with v_mfma_f32_16x16x4_f32 (an exact k-ordered fma chain, like the scalar kernel above), 16 clips per column tile.
-// Row r of the tile = unit (r>>2), gate (r&3), so the D fragment of lane l holds all four gate pre-activations of unit (l>>4),
-// clip (l&15) in its four registers and the cell update needs no cross-lane traffic.  whhp is W_hh re-packed as
-// [C/4 unit blocks][C/4 k-steps][64 lanes] so every A-fragment load is one coalesced 256-B row.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <int CH>   // k-steps per register chunk; the loads of chunk c+1 are in flight while chunk c feeds the matrix core
-__global__ __launch_bounds__(256) void lstm_step_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ whhp,
-                                                             const float* __restrict__ bhh, const float* __restrict__ hprev,
-                                                             float* __restrict__ hnext, float* __restrict__ cst, const float* __restrict__ skip,
-                                                             float* __restrict__ out, int B, int C, int64_t T, int64_t t) {
-    const int lane = threadIdx.x & 63;
-    const int ub = blockIdx.x * 4 + (threadIdx.x >> 6);       // unit block: hidden units 4*ub .. 4*ub+3
-    if (ub * 4 >= C) return;
-    const int KS = C / 4;
-    const float* wp = whhp + (int64_t)ub * KS * 64 + lane;
-    const int k4 = lane >> 4, cl = lane & 15;
-    const int j = ub * 4 + k4;                                 // this lane's hidden unit in the D fragment
-    // blockIdx.y = 16-clip column tile: the tiles are independent 512-long chains, so they run side by side on different CUs
-    // instead of back to back inside one wave (the step is bound by the dependent matrix-core chain of a tile)
-    {
-        const int c0 = blockIdx.y * 16;
-        const int bcol = min(c0 + cl, B - 1);
-        const float* hp = hprev + (int64_t)k4 * B + bcol;
-        const int64_t hs = (int64_t)4 * B;
-        f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        float a0[CH], b0[CH], a1[CH], b1[CH];
-#pragma unroll
-        for (int i = 0; i < CH; ++i) { a0[i] = wp[(int64_t)i * 64]; b0[i] = hp[(int64_t)i * hs]; }
-        for (int kc = 0; kc < KS; kc += CH) {
-            const bool more = kc + CH < KS;
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < CH; ++i) { a1[i] = wp[(int64_t)(kc + CH + i) * 64]; b1[i] = hp[(int64_t)(kc + CH + i) * hs]; }
-            }
-#pragma unroll
-            for (int i = 0; i < CH; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b0[i], acc, 0, 0, 0);
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < CH; ++i) { a0[i] = a1[i]; b0[i] = b1[i]; }
-            }
-        }
-        const int b = c0 + cl;
-        if (b < B) {
-            const float* g = gi + ((int64_t)b * 4 * C) * T + t;
-            const float pi = g[(int64_t)j * T] + (acc[0] + bhh[j]);
-            const float pf = g[(int64_t)(C + j) * T] + (acc[1] + bhh[C + j]);
-            const float pg = g[(int64_t)(2 * C + j) * T] + (acc[2] + bhh[2 * C + j]);
-            const float po = g[(int64_t)(3 * C + j) * T] + (acc[3] + bhh[3 * C + j]);
-            const float ig = nc_sigmoidf(pi), fg = nc_sigmoidf(pf), gg = nc_tanhf(pg), og = nc_sigmoidf(po);
-            const float cn = (fg * cst[(int64_t)j * B + b]) + (ig * gg);
-            cst[(int64_t)j * B + b] = cn;
-            const float h = og * nc_tanhf(cn);
-            hnext[(int64_t)j * B + b] = h;
-            const int64_t o = ((int64_t)b * C + j) * T + t;
-            out[o] = skip ? h + skip[o] : h;
-        }
-    }
-}
-
-// LSTM step with the whole reduction in flight at once.  The step is latency-bound: a wave's 512-long chain is 128 dependent
-// matrix-core instructions (~2 us) and the chunked version above pays an L2 round trip per 16-step chunk on top.  Here the wave's
-// 32 KB weight slice goes global -> LDS by DMA (global_load_lds, 16 bytes per lane, no registers) and its 128 h operands into
-// registers, all issued back to back: one memory round trip, then the chain runs from LDS/registers.  C == 4*KS.
 typedef __attribute__((address_space(1))) const void* lstm_gptr;
 typedef __attribute__((address_space(3))) void* lstm_lptr;
-template <int KS>
-__global__ __launch_bounds__(256) void lstm_step_lds_kernel(const float* __restrict__ gi, const float* __restrict__ whhp,
-                                                            const float* __restrict__ bhh, const float* __restrict__ hprev,
-                                                            float* __restrict__ hnext, float* __restrict__ cst, const float* __restrict__ skip,
-                                                            float* __restrict__ out, int B, int C, int64_t T, int64_t t) {
-    extern __shared__ __attribute__((aligned(16))) float lstm_lds[];   // [4 waves][KS][64]
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ub = blockIdx.x * 4 + wave;
-    if (ub * 4 >= C) return;
-    float* Aw = lstm_lds + wave * KS * 64;
-    const float* wsrc = whhp + (int64_t)ub * KS * 64;
-#pragma unroll
-    for (int i = 0; i < KS / 4; ++i)
-        __builtin_amdgcn_global_load_lds((lstm_gptr)(wsrc + i * 256 + lane * 4), (lstm_lptr)(Aw + i * 256), 16, 0, 0);
-    const int k4 = lane >> 4, cl = lane & 15;
-    const int j = ub * 4 + k4;
-    const int c0 = blockIdx.y * 16;
-    const int bcol = min(c0 + cl, B - 1);
-    const float* hp = hprev + (int64_t)k4 * B + bcol;
-    const int64_t hs = (int64_t)4 * B;
-    float hb[KS];
-#pragma unroll
-    for (int i = 0; i < KS; ++i) hb[i] = hp[(int64_t)i * hs];
-    // gate pre-activations of the input projection: issued with the rest, used after the chain
-    const int b = c0 + cl;
-    const int bb = min(b, B - 1);
-    const float* g = gi + ((int64_t)bb * 4 * C) * T + t;
-    const float g0 = g[(int64_t)j * T], g1 = g[(int64_t)(C + j) * T], g2 = g[(int64_t)(2 * C + j) * T], g3 = g[(int64_t)(3 * C + j) * T];
-    const float cprev = cst[(int64_t)j * B + bb];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA writes and the register reads have landed
-    f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int i = 0; i < KS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[i * 64 + lane], hb[i], acc, 0, 0, 0);
-    if (b < B) {
-        const float pi = g0 + (acc[0] + bhh[j]);
-        const float pf = g1 + (acc[1] + bhh[C + j]);
-        const float pg = g2 + (acc[2] + bhh[2 * C + j]);
-        const float po = g3 + (acc[3] + bhh[3 * C + j]);
-        const float ig = nc_sigmoidf(pi), fg = nc_sigmoidf(pf), gg = nc_tanhf(pg), og = nc_sigmoidf(po);
-        const float cn = (fg * cprev) + (ig * gg);
-        cst[(int64_t)j * B + b] = cn;
-        const float h = og * nc_tanhf(cn);
-        hnext[(int64_t)j * B + b] = h;
-        const int64_t o = ((int64_t)b * C + j) * T + t;
-        out[o] = skip ? h + skip[o] : h;
-    }
-}
 
 // Persistent LSTM layer: ALL T time steps of one layer in ONE launch (SLSTM.cs:31,40-57).
-//   * W_hh stays in LDS for the whole sequence: a workgroup owns 16 hidden units (4 per wavefront x 4 gates = one 16-row matrix-core
-//     tile per wave), i.e. KS*64 floats per wave = 128 KB per workgroup at C = 512 -- one workgroup per CU, C/16 workgroups per
-//     16-clip column tile, loaded once by LDS DMA.
-//   * The cell state c and the lane's h live in registers; per step a wave runs the same k-ordered matrix-core chain as the
-//     per-step kernels above (bit-identical results), then the gate arithmetic of its 4 units x 16 clips.
+//   * W_hh stays in LDS for the whole sequence: a workgroup of 16 wavefronts owns 16 hidden units; wave (ub, q) holds the 16 gate
+//     rows of 4 units (one 16-row matrix-core tile) for quarter q of the reduction: 128 KB per workgroup at C = 512 -- one workgroup
+//     per CU, C/16 workgroups per 16-clip column tile, loaded once by LDS DMA.
+//   * Per step the recurrent contraction runs as FOUR quarter chains (the canonical order of the oracle: (q0 + q1) + (q2 + q3)) walked
+//     side by side by the four waves of a unit block: the dependent chain -- the critical path of the step -- is 32
+//     v_mfma_f32_16x16x4_f32 instead of 128 (0.5 us instead of 2.1); the partial tiles meet in LDS and the q = 0 wave applies the gates
+//     with the cell state in its registers.
 //   * h_t of a column tile is exchanged between its C/16 workgroups through global memory with the placement-independent
 //     release/acquire protocol of cdna_hip_programming.md G16 (recipe R1): write-through (sc1) payload stores -> vmcnt(0) ->
 //     workgroup barrier -> one relaxed agent-scope flag store per workgroup; consumers poll the flags of their tile (one lane per
-//     producer, relaxed), then ONE agent-scope acquire fence, a workgroup barrier, and plain coalesced loads of the 2 KB x 16 h tile
-//     (layout [unit][16 clips] = the B-fragment order, so a wave's 128 operand loads are 256-byte rows).  Double-buffered by step
-//     parity: a workgroup can only publish h_{t+1} after every workgroup of the tile has published h_t, i.e. finished reading h_{t-1}.
+//     producer, relaxed), then ONE agent-scope acquire fence, a workgroup barrier, and plain coalesced loads of the h tile
+//     (layout [unit][16 clips] = the B-fragment order: every operand load is a 256-byte row).  Double-buffered by step parity: a
+//     workgroup can only publish h_{t+1} after every workgroup of the tile has published h_t, i.e. finished reading h_{t-1}.
 //   * Every spin is bounded: a timeout sets *tmo and all workgroups leave (the host reports NC_EDEVICE at the next synchronise).
-// Grid = (C/16, column tiles <= 8): at most 256 workgroups of 128 KB LDS, all co-resident on the 256 CUs.
+// Grid = (C/16, column tiles): at most 128 workgroups of 140 KB LDS per launch, all co-resident on the 256 CUs.
+// (A granule form of the exchange -- 8-byte {tag, value} stores, data-is-flag -- measured slower: 18.1 vs 17.0 ms on C3.)
 struct LstmSeqArgs {
     const float* gi;      // [N,4C,T] input projections incl. b_ih
     const float* whhp;    // [C/4 unit blocks][KS][64] A-fragment image of W_hh
@@ -355,20 +265,23 @@ struct LstmSeqArgs {
 };
 typedef __attribute__((address_space(1))) unsigned lstm_gu32;
 template <int KS>
-__global__ __launch_bounds__(256, 1) void lstm_seq_kernel(const LstmSeqArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lstm_lds[];   // [4 waves][KS][64]
+__global__ __launch_bounds__(1024, 1) void lstm_seq_kernel(const LstmSeqArgs a) {
+    constexpr int QS = KS / 4;                                          // k-steps per quarter
+    extern __shared__ __attribute__((aligned(16))) float lstm_lds[];   // [16 waves][QS][64] weights | [3][4][64] f32x4 partial tiles
     __shared__ int dead;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ubl = wave & 3, q = wave >> 2;        // unit block within the workgroup, reduction quarter
     const int C = a.C, N = a.N;
     const int64_t T = a.T;
     const int nprod = C / 16;                       // workgroups per column tile
     const int ubw = blockIdx.x, tile = blockIdx.y;  // tile: local index within this launch
-    const int ub = ubw * 4 + wave;                  // unit block of this wave: hidden units 4*ub .. 4*ub+3
-    float* Aw = lstm_lds + wave * KS * 64;
-    const float* wsrc = a.whhp + (int64_t)ub * KS * 64;
+    const int ub = ubw * 4 + ubl;                   // unit block of this wave: hidden units 4*ub .. 4*ub+3
+    float* Aw = lstm_lds + wave * QS * 64;
+    f32x4v* const part = reinterpret_cast<f32x4v*>(lstm_lds + 16 * QS * 64);
+    const float* wsrc = a.whhp + ((int64_t)ub * KS + q * QS) * 64;
 #pragma unroll
-    for (int i = 0; i < KS / 4; ++i)
+    for (int i = 0; i < QS / 4; ++i)
         __builtin_amdgcn_global_load_lds((lstm_gptr)(wsrc + i * 256 + lane * 4), (lstm_lptr)(Aw + i * 256), 16, 0, 0);
     if (threadIdx.x == 0) dead = 0;
     const int k4 = lane >> 4, cl = lane & 15;
@@ -384,15 +297,18 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(const LstmSeqArgs a) {
     float cst = 0.0f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // input-projection pre-activations (and the skip value) run one step ahead of their use: they are reads, issued before the step's
-    // stores, so they never queue behind a store acknowledgement
-    float g0 = g[(int64_t)j * T], g1 = g[(int64_t)(C + j) * T], g2 = g[(int64_t)(2 * C + j) * T], g3 = g[(int64_t)(3 * C + j) * T];
-    float sk = a.skip ? a.skip[orow] : 0.0f;
+    // input-projection pre-activations (and the skip value) run one step ahead of their use (q = 0 waves only): they are reads,
+    // issued before the step's stores, so they never queue behind a store acknowledgement
+    float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f, sk = 0.0f;
+    if (q == 0) {
+        g0 = g[(int64_t)j * T]; g1 = g[(int64_t)(C + j) * T]; g2 = g[(int64_t)(2 * C + j) * T]; g3 = g[(int64_t)(3 * C + j) * T];
+        if (a.skip) sk = a.skip[orow];
+    }
     for (int64_t t = 0; t < T; ++t) {
         f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
         const float c0 = g0, c1 = g1, c2 = g2, c3 = g3, csk = sk;
         const int64_t tn = min(t + 1, T - 1);
-        if (t > 0) {                                 // h_{-1} = 0: the chain of step 0 is +0
+        if (t > 0) {                                 // h_{-1} = 0: every quarter chain of step 0 is +0
             if (wave == 0) {
                 const unsigned want = (unsigned)t;
                 bool ok = false;
@@ -406,131 +322,61 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(const LstmSeqArgs a) {
                     __hip_atomic_store((lstm_gu32*)a.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     dead = 1;
                 }
+#ifdef NC_LSTM_FENCE
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
             }
             __syncthreads();
             if (dead) return;
-            const float* hp = ((t & 1) ? hx0 : hx1) + lane;   // h_{t-1} sits in buffer (t-1)&1
-            float hb[KS];
+            const float* hp = ((t & 1) ? hx0 : hx1) + (int64_t)q * QS * 64 + lane;   // h_{t-1} sits in buffer (t-1)&1
+            float hb[QS];
+            // the h operands are read with agent-scope (sc1) loads: they observe the producers' write-through stores directly, so the
+            // consumer needs no acquire fence (an agent-scope L1 invalidation costs ~1.7 us, more than the loads themselves)
 #pragma unroll
-            for (int i = 0; i < KS; ++i) hb[i] = hp[i * 64];
-            g0 = g[(int64_t)j * T + tn]; g1 = g[(int64_t)(C + j) * T + tn]; g2 = g[(int64_t)(2 * C + j) * T + tn]; g3 = g[(int64_t)(3 * C + j) * T + tn];
-            if (a.skip) sk = a.skip[orow + tn];
+            for (int i = 0; i < QS; ++i) {
+#ifdef NC_LSTM_FENCE
+                hb[i] = hp[i * 64];
+#else
+                hb[i] = __hip_atomic_load(hp + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+            }
+            if (q == 0) {
+                g0 = g[(int64_t)j * T + tn]; g1 = g[(int64_t)(C + j) * T + tn]; g2 = g[(int64_t)(2 * C + j) * T + tn]; g3 = g[(int64_t)(3 * C + j) * T + tn];
+                if (a.skip) sk = a.skip[orow + tn];
+            }
 #pragma unroll
-            for (int i = 0; i < KS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[i * 64 + lane], hb[i], acc, 0, 0, 0);
-        } else {
+            for (int i = 0; i < QS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[i * 64 + lane], hb[i], acc, 0, 0, 0);
+            if (q > 0) part[((q - 1) * 4 + ubl) * 64 + lane] = acc;
+            __syncthreads();
+            if (q == 0) {
+                const f32x4v p1 = part[(0 * 4 + ubl) * 64 + lane], p2 = part[(1 * 4 + ubl) * 64 + lane], p3 = part[(2 * 4 + ubl) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = (acc[r] + p1[r]) + (p2[r] + p3[r]);
+            }
+        } else if (q == 0) {
             g0 = g[(int64_t)j * T + tn]; g1 = g[(int64_t)(C + j) * T + tn]; g2 = g[(int64_t)(2 * C + j) * T + tn]; g3 = g[(int64_t)(3 * C + j) * T + tn];
             if (a.skip) sk = a.skip[orow + tn];
         }
-        const float pi = c0 + (acc[0] + bh0);
-        const float pf = c1 + (acc[1] + bh1);
-        const float pg = c2 + (acc[2] + bh2);
-        const float po = c3 + (acc[3] + bh3);
-        const float ig = nc_sigmoidf(pi), fg = nc_sigmoidf(pf), gg = nc_tanhf(pg), og = nc_sigmoidf(po);
-        cst = (fg * cst) + (ig * gg);
-        const float h = og * nc_tanhf(cst);
+        if (q == 0) {
+            const float pi = c0 + (acc[0] + bh0);
+            const float pf = c1 + (acc[1] + bh1);
+            const float pg = c2 + (acc[2] + bh2);
+            const float po = c3 + (acc[3] + bh3);
+            const float ig = nc_sigmoidf(pi), fg = nc_sigmoidf(pf), gg = nc_tanhf(pg), og = nc_sigmoidf(po);
+            cst = (fg * cst) + (ig * gg);
+            const float h = og * nc_tanhf(cst);
+            if (t + 1 < T) {
+                // publish h_t: write-through payload, drained per wave, then one flag store for the workgroup
+                float* hq = ((t & 1) ? hx1 : hx0) + ub * 64 + lane;   // [unit j][clip cl] = j*16 + cl = ub*64 + lane
+                __hip_atomic_store(hq, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (b < N) a.out[orow + t] = a.skip ? h + csk : h;
+        }
         if (t + 1 < T) {
-            // publish h_t: write-through payload, drained per wave, then one flag store for the workgroup
-            float* hq = ((t & 1) ? hx1 : hx0) + ub * 64 + lane;   // [unit j][clip cl] = j*16 + cl = ub*64 + lane
-            __hip_atomic_store(hq, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            __syncthreads();   // the four publishing waves have drained their stores (and the partial tiles are free again)
             if (threadIdx.x == 0) __hip_atomic_store((lstm_gu32*)(flags + ubw), (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (b < N) a.out[orow + t] = a.skip ? h + csk : h;
-    }
-}
-
-// Granule form of the persistent LSTM layer: the data IS the flag (cdna_hip_programming.md G16, recipe R2).  h_t travels as 8-byte
-// {tag = t + 1, value} granules written by ONE write-through 64-bit store per lane; a consumer wave sweeps the 128 granules it needs
-// (relaxed agent-scope 64-bit loads, 512-byte rows) until every tag matches, then feeds the values to the matrix cores.  Compared
-// with the flag form above this removes, per step, the producer's store drain + workgroup barrier + flag store and the consumer's
-// flag poll + acquire fence + second round trip: one hop instead of two.  Double-buffered by step parity as before.
-typedef __attribute__((address_space(1))) unsigned long long lstm_gu64;
-template <int KS>
-__global__ __launch_bounds__(256, 1) void lstm_seq_granule_kernel(const LstmSeqArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lstm_lds[];   // [4 waves][KS][64]
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int C = a.C, N = a.N;
-    const int64_t T = a.T;
-    const int ubw = blockIdx.x, tile = blockIdx.y;
-    const int ub = ubw * 4 + wave;
-    float* Aw = lstm_lds + wave * KS * 64;
-    const float* wsrc = a.whhp + (int64_t)ub * KS * 64;
-#pragma unroll
-    for (int i = 0; i < KS / 4; ++i)
-        __builtin_amdgcn_global_load_lds((lstm_gptr)(wsrc + i * 256 + lane * 4), (lstm_lptr)(Aw + i * 256), 16, 0, 0);
-    const int k4 = lane >> 4, cl = lane & 15;
-    const int j = ub * 4 + k4;
-    const int b = (a.tile0 + tile) * 16 + cl;
-    const int bb = min(b, N - 1);
-    const float* g = a.gi + ((int64_t)bb * 4 * C) * T;
-    const float bh0 = a.bhh[j], bh1 = a.bhh[C + j], bh2 = a.bhh[2 * C + j], bh3 = a.bhh[3 * C + j];
-    unsigned long long* const hx = reinterpret_cast<unsigned long long*>(a.hx);   // [2][tiles][C][16] granules
-    unsigned long long* const hx0 = hx + ((int64_t)(0 * gridDim.y + tile) * C) * 16;
-    unsigned long long* const hx1 = hx + ((int64_t)(1 * gridDim.y + tile) * C) * 16;
-    const int64_t orow = ((int64_t)bb * C + j) * T;
-    float cst = 0.0f;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    float g0 = g[(int64_t)j * T], g1 = g[(int64_t)(C + j) * T], g2 = g[(int64_t)(2 * C + j) * T], g3 = g[(int64_t)(3 * C + j) * T];
-    float sk = a.skip ? a.skip[orow] : 0.0f;
-    bool dead = false;
-    for (int64_t t = 0; t < T && !dead; ++t) {
-        f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        const float c0 = g0, c1 = g1, c2 = g2, c3 = g3, csk = sk;
-        const int64_t tn = min(t + 1, T - 1);
-        g0 = g[(int64_t)j * T + tn]; g1 = g[(int64_t)(C + j) * T + tn]; g2 = g[(int64_t)(2 * C + j) * T + tn]; g3 = g[(int64_t)(3 * C + j) * T + tn];
-        if (a.skip) sk = a.skip[orow + tn];
-        if (t > 0) {
-            const unsigned long long* hp = ((t & 1) ? hx0 : hx1) + lane;   // h_{t-1} sits in buffer (t-1)&1, tag t
-            const unsigned want = (unsigned)t;
-            float hb[KS];
-            // sweep in 4 chunks of KS/4 granules; a chunk is re-read until all its tags match (chunks become complete in any order,
-            // the matrix-core chain consumes them in k order)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                unsigned spins = 0;
-                for (;;) {
-                    unsigned long long gr[KS / 4];
-#pragma unroll
-                    for (int i = 0; i < KS / 4; ++i)
-                        gr[i] = __hip_atomic_load((lstm_gu64*)(hp + (c * (KS / 4) + i) * 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    bool ok = true;
-#pragma unroll
-                    for (int i = 0; i < KS / 4; ++i) ok &= (unsigned)(gr[i] >> 32) == want;
-                    if (__all(ok)) {
-#pragma unroll
-                        for (int i = 0; i < KS / 4; ++i) hb[c * (KS / 4) + i] = __uint_as_float((unsigned)gr[i]);
-                        break;
-                    }
-                    if (++spins > (1u << 20) || ((spins & 255) == 255 && __hip_atomic_load((lstm_gu32*)a.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                        if (lane == 0) __hip_atomic_store((lstm_gu32*)a.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        dead = true;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (dead) break;
-            }
-            if (dead) break;
-#pragma unroll
-            for (int i = 0; i < KS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[i * 64 + lane], hb[i], acc, 0, 0, 0);
-        }
-        const float pi = c0 + (acc[0] + bh0);
-        const float pf = c1 + (acc[1] + bh1);
-        const float pg = c2 + (acc[2] + bh2);
-        const float po = c3 + (acc[3] + bh3);
-        const float ig = nc_sigmoidf(pi), fg = nc_sigmoidf(pf), gg = nc_tanhf(pg), og = nc_sigmoidf(po);
-        cst = (fg * cst) + (ig * gg);
-        const float h = og * nc_tanhf(cst);
-        if (t + 1 < T) {
-            unsigned long long* hq = ((t & 1) ? hx1 : hx0) + ub * 64 + lane;
-            __hip_atomic_store((lstm_gu64*)hq, ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned long long)__float_as_uint(h), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (b < N) a.out[orow + t] = a.skip ? h + csk : h;
     }
 }
 
@@ -1046,7 +892,7 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
         if (!stepwise && C % 64 == 0 && (KS == 128 || KS == 16)) {
             // persistent layer kernel: all T steps in one launch per group of column tiles (<= 128 co-resident workgroups)
             const int nprod = C / 16, n_tiles = (N + 15) / 16, per_launch = std::max(1, 128 / nprod);
-            const size_t lds = (size_t)4 * KS * 64 * 4;
+            const size_t lds = (size_t)4 * KS * 64 * 4 + 3 * 4 * 64 * 16;
             unsigned* sync = lstm_sync.as<unsigned>();                                     // [0] = timeout word (zeroed at load)
             unsigned* flags_all = reinterpret_cast<unsigned*>(alloc((size_t)n_tiles * nprod));   // per call + layer: groups may run concurrently
             NC_HIP(hipMemsetAsync(flags_all, 0, (size_t)n_tiles * nprod * 4, stream));
@@ -1054,48 +900,30 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
                 const int nt = std::min(per_launch, n_tiles - t0);
                 LstmSeqArgs a{};
                 a.gi = gi; a.whhp = y.whhp.as<float>(); a.bhh = y.bhh.as<float>(); a.skip = last ? x : nullptr; a.out = out;
-                // the granule form (data-is-flag) measured slower than the flag form (18.07 vs 17.04 ms on C3: its 64-bit sc1 sweeps go to
-                // the memory side where the flag form's plain loads hit L2): kept as an experiment behind NC_LSTM_GRANULES=1
-                static const bool use_flags = !(std::getenv("NC_LSTM_GRANULES") && std::getenv("NC_LSTM_GRANULES")[0] == '1');
-                a.hx = alloc((size_t)2 * nt * C * 16 * (use_flags ? 1 : 2));
+                a.hx = alloc((size_t)2 * nt * C * 16);
                 a.flags = flags_all + (size_t)t0 * nprod; a.tmo = sync;
                 a.N = N; a.C = C; a.T = T; a.tile0 = t0;
-                // granule form: tags of a previous call could alias this call's (same step numbers): clear the exchange buffers
-                if (!use_flags) NC_HIP(hipMemsetAsync(a.hx, 0, (size_t)2 * nt * C * 16 * 8, stream));
                 auto launch = [&](auto kern) {
                     ensure_dynamic_lds((const void*)kern, lds);
-                    hipLaunchKernelGGL(kern, dim3((unsigned)nprod, (unsigned)nt), dim3(256), lds, stream, a);
+                    hipLaunchKernelGGL(kern, dim3((unsigned)nprod, (unsigned)nt), dim3(1024), lds, stream, a);
                 };
-                if (KS == 128) { if (use_flags) launch(lstm_seq_kernel<128>); else launch(lstm_seq_granule_kernel<128>); }
-                else { if (use_flags) launch(lstm_seq_kernel<16>); else launch(lstm_seq_granule_kernel<16>); }
+                if (KS == 128) launch(lstm_seq_kernel<128>);
+                else launch(lstm_seq_kernel<16>);
             }
             NC_HIP(hipGetLastError());
             if (prof.on) prof.end(stream);
             in = out;
             continue;
         }
+        // generic fallback: one launch per time step (block = hidden unit with its 4 weight rows in LDS, thread = clip)
         float* h0 = alloc((size_t)C * N);
         float* h1 = alloc((size_t)C * N);
         float* cs = alloc((size_t)C * N);
         NC_HIP(hipMemsetAsync(h0, 0, (size_t)C * N * 4, stream));
         NC_HIP(hipMemsetAsync(cs, 0, (size_t)C * N * 4, stream));
-        static const bool scalar_lstm = std::getenv("NC_LSTM_SCALAR") && std::getenv("NC_LSTM_SCALAR")[0] == '1';
-        for (int64_t t = 0; t < T; ++t) {
-            static const bool no_lds_lstm = std::getenv("NC_LSTM_CHUNKED") && std::getenv("NC_LSTM_CHUNKED")[0] == '1';
-            if (C == 512 && !scalar_lstm && !no_lds_lstm) {
-                ensure_dynamic_lds((const void*)lstm_step_lds_kernel<128>, 4 * 128 * 64 * 4);
-                hipLaunchKernelGGL(lstm_step_lds_kernel<128>, dim3((unsigned)((C / 4 + 3) / 4), (unsigned)((N + 15) / 16)), dim3(256), 4 * 128 * 64 * 4, stream, gi,
-                                   y.whhp.as<float>(), y.bhh.as<float>(), (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, cs, last ? x : nullptr, out, N, C, T, t);
-            } else if (C % 64 == 0 && !scalar_lstm)
-                hipLaunchKernelGGL(lstm_step_mfma_kernel<16>, dim3((unsigned)((C / 4 + 3) / 4), (unsigned)((N + 15) / 16)), dim3(256), 0, stream, gi, y.whhp.as<float>(),
-                                   y.bhh.as<float>(), (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, cs, last ? x : nullptr, out, N, C, T, t);
-            else if (C % 16 == 0 && !scalar_lstm)
-                hipLaunchKernelGGL(lstm_step_mfma_kernel<4>, dim3((unsigned)((C / 4 + 3) / 4), (unsigned)((N + 15) / 16)), dim3(256), 0, stream, gi, y.whhp.as<float>(),
-                                   y.bhh.as<float>(), (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, cs, last ? x : nullptr, out, N, C, T, t);
-            else
-                hipLaunchKernelGGL(lstm_step_kernel, dim3((unsigned)C, (unsigned)((N + 63) / 64)), dim3(64), (size_t)4 * C * sizeof(float), stream,
-                                   gi, y.whh.as<float>(), y.bhh.as<float>(), (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, cs, last ? x : nullptr, out, N, C, T, t);
-        }
+        for (int64_t t = 0; t < T; ++t)
+            hipLaunchKernelGGL(lstm_step_kernel, dim3((unsigned)C, (unsigned)((N + 63) / 64)), dim3(64), (size_t)4 * C * sizeof(float), stream,
+                               gi, y.whh.as<float>(), y.bhh.as<float>(), (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, cs, last ? x : nullptr, out, N, C, T, t);
         NC_HIP(hipGetLastError());
         if (prof.on) prof.end(stream);
         in = out;

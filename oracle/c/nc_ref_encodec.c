@@ -19,7 +19,8 @@
  *                    chunks of a row ascending, rows ascending.  mu = S1/N, var = max(S2/N - mu*mu, 0), r = (float)(1/sqrt(var + 1e-5)),
  *                    y = ((x - (float)mu) * r) * gamma[c] + beta[c]
  *   ELU:             x > 0 ? x : exp(x) - 1
- *   LSTM cell:       pre = (chain_ih + b_ih) + (chain_hh + b_hh) (fma chains, k ascending); sigmoid(x) = 1/(1 + exp(-x));
+ *   LSTM cell:       pre = (chain_ih + b_ih) + (chain_hh + b_hh); chain_ih one fma chain (k ascending), chain_hh four quarter chains
+ *                    combined as (q0 + q1) + (q2 + q3); sigmoid(x) = 1/(1 + exp(-x));
  *                    c = (f*c) + (i*g); h = o * tanh(c); gate order i, f, g, o
  *   RMS scale:       mono = (sum_c x)/C; vol = sqrtf((float)(S/T)), S = hierarchical binary64 sum of fl32(mono*mono);
  *                    scale = vol + 1e-8f; x / scale
@@ -275,9 +276,24 @@ static float* slstm(ref_encodec* m, const char* key, float* x, int64_t B, int C,
                 for (int j = 0; j < 4 * C; j++) {
                     const float* xv = cur + (t * B + b) * C;
                     const float* hv = h + b * C;
-                    float a = 0.0f, r = 0.0f;
+                    float a = 0.0f;
                     for (int k = 0; k < C; k++) a = fmaf(wih[(int64_t)j * C + k], xv[k], a);
-                    for (int k = 0; k < C; k++) r = fmaf(whh[(int64_t)j * C + k], hv[k], r);
+                    /* recurrent contraction: FOUR quarter chains (k ascending inside a quarter, each from +0) combined as
+                     * (q0 + q1) + (q2 + q3) -- the dependent chain is the critical path of every time step on the device, and four
+                     * wavefronts walk the quarters side by side (C % 4 == 0; otherwise one chain) */
+                    float r;
+                    if (C % 4 == 0) {
+                        float q[4];
+                        for (int s4 = 0; s4 < 4; s4++) {
+                            float c = 0.0f;
+                            for (int k = s4 * (C / 4); k < (s4 + 1) * (C / 4); k++) c = fmaf(whh[(int64_t)j * C + k], hv[k], c);
+                            q[s4] = c;
+                        }
+                        r = (q[0] + q[1]) + (q[2] + q[3]);
+                    } else {
+                        r = 0.0f;
+                        for (int k = 0; k < C; k++) r = fmaf(whh[(int64_t)j * C + k], hv[k], r);
+                    }
                     gi[b * 4 * C + j] = (a + bih[j]) + (r + bhh[j]);
                 }
             for (int64_t b = 0; b < B; b++)
