@@ -62,6 +62,11 @@ struct ConvArgs {
     const float* in_gamma;         // [Cin]
     const float* in_beta;          // [Cin]
     int32_t sub_shift;             // SUB kernels: log2(stride) of the sub-pixel transposed convolution (rows = co*stride + phase; Cout = rows)
+    // flattened (clip, column) axis (see the kernel's tile map).  flat = 0: one clip per tile (B clips in the tile map, both pitches
+    // 0x1fffffff).  flat = 1: B = 1 in the tile map, n_t_tiles covers Bc*n_cols columns, flat_pc = n_cols, flat_hc = halo columns per
+    // segment, flat_px = (n_cols + flat_hc) * stride window slots per clip.  Bc = number of clips (both modes).
+    int32_t flat, flat_px, flat_pc, flat_hc, Bc;
+    int32_t co_group;              // row tiles per group of the block -> tile order (see the kernel's tile map); >= 1, divides n_co_tiles
     int32_t in_left, in_Lz, in_L;  // bit 2: padded position j reads q = reflect(j - left) over [0,Lz); samples q >= L are the zero extension (D9)
 };
 

@@ -291,6 +291,25 @@ static TileChoice choose_tile(const ConvLayer& L, int64_t blocks_per_rowtile, bo
     return best;
 }
 
+// Row tiles per group of the block -> tile order (ConvArgs::co_group).  The ~64 workgroups resident on an XCD advance through their
+// reduction blocks roughly in step, so operands they have in common are fetched from the fabric once and then hit in that XCD's L2
+// (temporal sharing: the instantaneous working set is a few tiles, far below the 4 MB).  With groups of G row tiles the resident set
+// is G row tiles x 64/G column tiles: an input window is fetched once per GROUP (x_bytes * n_co / G in all) and a weight panel once per
+// resident set that holds it (w_bytes * n_col_tiles * G / 64 in all).  Pick the divisor of n_co_tiles (<= 8) with the least traffic.
+// Measured (PMC FETCH_SIZE, DAC C2): G = 1 -> 2 on the C = 384 k = 7 layers 1156 -> 709 MiB per launch, as this model predicts.
+// NC_CO_GROUP=<n> caps the group size (1 = one panel per XCD, the round-1 order).
+static int pick_co_group(int n_co_tiles, double x_bytes, double w_bytes, double n_col_tiles) {
+    static const int cap = std::getenv("NC_CO_GROUP") ? atoi(std::getenv("NC_CO_GROUP")) : 0;
+    int best = 1;
+    double bt = 0.0;
+    for (int g = 1; g <= std::min(n_co_tiles, cap > 0 ? cap : 8); ++g) {
+        if (n_co_tiles % g) continue;
+        const double t = x_bytes * n_co_tiles / g + w_bytes * n_col_tiles * g / 64.0;
+        if (g == 1 || t < bt) { bt = t; best = g; }
+    }
+    return best;
+}
+
 // Pointwise fast path (nc_conv1x1.hip): B fragments straight from global memory, 2-wide vector loads/stores.
 static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream, Profiler* prof) {
     static const bool off = std::getenv("NC_NO_CONV1X1") && std::getenv("NC_NO_CONV1X1")[0] == '1';
@@ -321,6 +340,7 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
     a.n_co_tiles = (L.Cout + BM - 1) / BM;
     a.n_t_tiles = (int32_t)((T + 255) / 256);
     a.n_cb = (L.Cin + 15) / 16;
+    a.co_group = pick_co_group(a.n_co_tiles, 4.0 * B * L.Cin * (double)T, 4.0 * L.Cin * (double)L.Cout, (double)B * a.n_t_tiles);
     const int64_t grid = (int64_t)a.n_co_tiles * B * a.n_t_tiles;
     if (prof && prof->on) {
         const double bytes = 4.0 * ((double)B * L.Cin * T + (double)B * L.Cout * T * (io.res ? 2 : 1) + (double)L.Cin * L.Cout);
@@ -395,12 +415,51 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
             c.NW = 3;
         }
     }
+    // Flattened (clip, column) axis (kernel: "Flattened column axis"): when the rows are short or leave a good part of their last
+    // tile on padding, the columns of all clips are cut into tiles as one axis.  Needs the one-launch forms (no per-phase launches),
+    // no per-clip scalars in the kernel (Encodec input mode, noise rows), a window (tile + one halo per touched clip) that still fits
+    // the staging registers, and 32-bit offsets that reach 3 clips ahead.
+    bool flat = false;
+    int flat_S = 0, flat_hc = 0;
+    {
+        static const bool no_flat = std::getenv("NC_NO_FLAT") && std::getenv("NC_NO_FLAT")[0] == '1';
+        const int sx0 = L.transposed ? 1 : L.stride, ad0 = L.transposed ? 1 : L.dil;
+        const int hc = ((L.Ktaps - 1) * ad0) / sx0;
+        const int64_t Tq = n_cols_all;
+        auto segs = [&](int BN) { return (int)((BN - 2) / Tq) + 2; };
+        auto fits = [&](int TN) {
+            const int BN = 128 * TN, S = segs(BN);
+            if (S > 4) return false;
+            const int xw = (BN - 1 + (S - 1) * hc) * sx0 + (L.Ktaps - 1) * ad0 + 1;
+            return c.CB * ((xw + 63) / 64) <= 4 * nx_for_k(c.K);
+        };
+        const bool cand = !no_flat && B > 1 && L.n_phase == 1 && !io.fuse_k1 && !in_mode && !(io.epi & EPI_NOISE) && Tq >= 32 && L.Cin * L.Ktaps >= 64 &&
+                          3 * io.x_bstride + io.x_len < ((int64_t)1 << 32) &&
+                          (int64_t)(c.BM() + 4) * io.y_cstride + Tout + 3 * io.y_bstride < ((int64_t)1 << 31) &&
+                          (Tq + hc) * sx0 < (1 << 28);
+        int ftn = 0;
+        if (cand) ftn = ((int64_t)B * Tq >= 192 && fits(2)) ? 2 : fits(1) ? 1 : 0;
+        if (ftn < c.TN && Tq >= 192) ftn = 0;   // (dilation-9 windows: the extra halo would halve the tile width -- keep the one-clip tiles)
+        if (ftn) {
+            const int64_t bn_nf = c.BN(), cols_nf = (int64_t)B * ((Tq + bn_nf - 1) / bn_nf) * bn_nf;
+            const int64_t bn_f = 128 * ftn, cols_f = (((int64_t)B * Tq + bn_f - 1) / bn_f) * bn_f;
+            if ((double)cols_f <= 0.97 * (double)cols_nf) {
+                flat = true;
+                tsel = choose_tile(L, ((int64_t)B * Tq + 255) / 256, false);
+                c = tsel.cfg;
+                c.TN = ftn;
+                narrow = false;
+                flat_S = segs(c.BN());
+                flat_hc = hc;
+            }
+        }
+    }
     // light variant (reduction block of 4 channels, 3 workgroups per CU): same packed weights when Cin is a multiple of 8
     int nx = nx_for_k(c.K);
     bool light = false;
     {
         static const int light_mode = experiment_mode("NC_LIGHT");
-        if (light_mode == 1 && !narrow && !io.fuse_k1 && c.K == 7 && c.CB == 8 && L.Cin % 8 == 0 && c.TN == 2 && (c.TM == 2 || c.TM == 3)) {
+        if (light_mode == 1 && !narrow && !flat && !io.fuse_k1 && c.K == 7 && c.CB == 8 && L.Cin % 8 == 0 && c.TN == 2 && (c.TM == 2 || c.TM == 3)) {
             light = true;
             c.CB = 4;
             nx = 5;
@@ -414,7 +473,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         // 215 -> 145 us (32->16 k3, 48000 steps x 32 clips), 152 -> 118 us (64->32), 80 -> 51 us (2->32 k7).  Measured neutral or
         // slower for the strided k=4 / k=8 layers and the sub-pixel up-convolutions, which keep the standard blocks.
         static const bool no_slim = std::getenv("NC_NO_SLIM") && std::getenv("NC_NO_SLIM")[0] == '1';
-        if (!no_slim && !light && !narrow && !io.fuse_k1 && !L.sub_shift && !L.transposed && c.TM <= 2 && n_cols_all >= 1024) {
+        if (!no_slim && !flat && !light && !narrow && !io.fuse_k1 && !L.sub_shift && !L.transposed && c.TM <= 2 && n_cols_all >= 1024) {
             int cb2 = 0, nx2 = 0;
             if (c.K == 3 && c.CB == 16) { slim_fn = conv_kernel_table_slim_k3(c.TM, c.TN); cb2 = 8; nx2 = 10; }
             else if (c.K == 7 && c.CB == 8 && L.Cin <= 4 && L.stride == 1 && L.dil == 1) { slim_fn = conv_kernel_table_slim_k7(c.TM, c.TN); cb2 = 4; nx2 = 5; }
@@ -424,7 +483,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     bool wide = false;
     {
         static const int wide_mode = experiment_mode("NC_WIDE");
-        if (wide_mode == 1 && !light && !narrow && !io.fuse_k1 && c.K == 7 && c.TN == 2 && c.TM >= 2 && n_cols_all >= 2048) {
+        if (wide_mode == 1 && !light && !narrow && !flat && !io.fuse_k1 && c.K == 7 && c.TN == 2 && c.TM >= 2 && n_cols_all >= 2048) {
             wide = true;
             c.NW = 8;
             nx = 9;
@@ -434,7 +493,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     int n_prod = 0;
     {
         static const int spec_mode = experiment_mode("NC_SPEC");
-        if (spec_mode == 1 && !light && !narrow && !wide && !io.fuse_k1 && c.K == 7 && c.TN == 2 && (c.TM == 2 || c.TM == 3)) {
+        if (spec_mode == 1 && !light && !narrow && !flat && !wide && !io.fuse_k1 && c.K == 7 && c.TN == 2 && (c.TM == 2 || c.TM == 3)) {
             n_prod = 2;
             nx = 20;
         }
@@ -442,7 +501,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     bool dist = false;
     {
         static const int dist_mode = experiment_mode("NC_DIST");
-        if (dist_mode == 1 && !n_prod && !light && !narrow && !wide && !io.fuse_k1 && c.K == 7 && c.TN == 2 && c.TM >= 2) dist = true;
+        if (dist_mode == 1 && !n_prod && !light && !narrow && !flat && !wide && !io.fuse_k1 && c.K == 7 && c.TN == 2 && c.TM >= 2) dist = true;
     }
     const int NW = n_prod ? n_prod : c.NW;   // waves that stage the input window
     const int BM = c.BM(), BN = c.BN(), CB = c.CB, KB = c.KB();
@@ -476,13 +535,20 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     }
     const int ad = a.dil < 0 ? -a.dil : a.dil;
     a.xneg = a.dil < 0 ? (L.Ktaps - 1) * ad : 0;
-    a.xw = (BN - 1) * sx + (L.Ktaps - 1) * ad + 1;
+    a.xw = (BN - 1 + (flat ? (flat_S - 1) * flat_hc : 0)) * sx + (L.Ktaps - 1) * ad + 1;
     a.nchunk = (a.xw + 63) / 64;
     a.xwp = (a.nchunk * 64 + sx - 1) / sx;   // rows are padded to whole 64-slot chunks: every staging store is in-bounds
     a.xrow = sx == 1 ? a.nchunk * 64 : sx * a.xwp;
     a.n_co_tiles = (L.rows() + BM - 1) / BM;
     a.n_t_tiles = (a.n_cols + BN - 1) / BN;
+    a.Bc = B; a.flat = 0; a.flat_px = a.flat_pc = 0x1fffffff; a.flat_hc = 0;
+    if (flat) {   // one column axis over all clips: B = 1 in the tile map
+        a.flat = 1; a.flat_pc = a.n_cols; a.flat_hc = flat_hc; a.flat_px = (a.n_cols + flat_hc) * sx;
+        a.n_t_tiles = (int32_t)(((int64_t)B * a.n_cols + BN - 1) / BN);
+        a.B = 1;
+    }
     a.n_cb = (L.Cin + CB - 1) / CB;
+    a.co_group = 1;   // (set below, once the column tiling is known)
     a.n_items = CB * a.nchunk;
     if (a.n_items > NW * nx)
         fail(NC_EUNSUPPORTED, "conv K=%d stride=%d dil=%d: input window of %d words per channel exceeds the staging registers",
@@ -534,7 +600,9 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     }
     if (lds > 160 * 1024) fail(NC_EUNSUPPORTED, "conv tile needs %zu B of LDS", lds);
     ensure_dynamic_lds((const void*)fn, 160 * 1024);
-    const int64_t grid = (int64_t)a.n_phase * a.n_co_tiles * B * a.n_t_tiles;
+    a.co_group = pick_co_group(a.n_co_tiles, 4.0 * B * L.Cin * (double)io.Tin, 4.0 * L.Cin * (double)L.rows() * L.Ktaps,
+                               (double)a.B * a.n_t_tiles);
+    const int64_t grid = (int64_t)a.n_phase * a.n_co_tiles * a.B * a.n_t_tiles;
     if (grid <= 0) return;
     if (prof && prof->on) {
         const double bytes = 4.0 * ((double)B * L.Cin * io.Tin + (double)B * L.Cout * Tout + (double)L.Cin * L.Cout * L.K);

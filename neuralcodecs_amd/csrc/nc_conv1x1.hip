@@ -71,10 +71,12 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
+    const int co_in = __builtin_amdgcn_readfirstlane(lin % p.co_group);   // row tiles in groups: see conv_mfma_kernel's tile map
+    lin /= p.co_group;
     const int t_tile = __builtin_amdgcn_readfirstlane(lin % p.n_t_tiles);
     lin /= p.n_t_tiles;
     const int b = __builtin_amdgcn_readfirstlane(lin % p.B);
-    const int co_tile = __builtin_amdgcn_readfirstlane(lin / p.B);
+    const int co_tile = __builtin_amdgcn_readfirstlane((lin / p.B) * p.co_group + co_in);
     for (int i = tid; i < BM; i += 256) {
         const int co = min(co_tile * BM + i, p.Cout - 1);
         const float ao = p.alpha_out ? p.alpha_out[co] : 0.0f;

@@ -161,14 +161,28 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     // Polyphase (transposed) launches: the stride phases of one output tile are adjacent in the order, so they run together on
     // one XCD -- their interleaved 4-byte stores (every stride-th sample of the same lines) merge in that L2 instead of each
     // going to HBM as a partial line, and they share the input window.
+    // Row tiles in groups of p.co_group (host: as many weight panels as fit ~2 MB of an XCD's 4 MB L2): the co_group row tiles of
+    // one column tile are adjacent in the order, so they run together on one XCD and the input window is fetched from the fabric
+    // once per GROUP instead of once per row tile (C = 384: 4.4x -> 2x input traffic), while the group's panels stay L2-resident.
     const int phase = __builtin_amdgcn_readfirstlane(lin % p.n_phase);
     lin /= p.n_phase;
+    const int co_in = __builtin_amdgcn_readfirstlane(lin % p.co_group);
+    lin /= p.co_group;
     const int t_tile = __builtin_amdgcn_readfirstlane(lin % p.n_t_tiles);
     lin /= p.n_t_tiles;
-    const int b = __builtin_amdgcn_readfirstlane(lin % p.B);
-    const int co_tile = __builtin_amdgcn_readfirstlane(lin / p.B);
+    const int co_tile = __builtin_amdgcn_readfirstlane((lin / p.B) * p.co_group + co_in);
+    // Flattened column axis (p.flat, host: launch_conv): the columns of all clips form ONE axis n = clip*n_cols + column, cut into
+    // BN-wide tiles regardless of clip boundaries -- rows of 87 / 150 / 696 columns otherwise leave 6-40 % of every 96/128/256-wide tile
+    // on padding and give the deep layers one short tile per (clip, weight panel).  A tile then touches up to 4 clips ("segments"):
+    // segment m of the tile is clip b + m.  In LDS every segment keeps its own halo: column n of segment m sits at window column
+    // n + m*flat_hc, i.e. clips are laid out at a pitch of n_cols + flat_hc columns (flat_px x-slots), and the segment of a window
+    // slot / tile column is found by comparing against multiples of the pitch.  Without p.flat both pitches are huge (segment 0 always)
+    // and every formula below reduces to the one-clip tile: b = clip of the tile, col0 = its first column.
+    const int b = __builtin_amdgcn_readfirstlane(p.flat ? (t_tile * BN) / p.n_cols : lin % p.B);   // first clip of the tile
+    const int col0 = p.flat ? t_tile * BN - b * p.n_cols : t_tile * BN;                              // first column, within clip b
+    const int flat_px = p.flat_px, flat_pc = p.flat_pc;
+    auto seg_of = [&](int r, int pitch) __attribute__((always_inline)) -> int { return (int)(r >= pitch) + (int)(r >= 2 * pitch) + (int)(r >= 3 * pitch); };
 
-    const int col0 = t_tile * BN;
     const int s = p.stride;
     const int xs0 = col0 * s - p.pad - p.xneg;  // global x position of window slot 0
 
@@ -206,18 +220,21 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     // the 64 window slots starting at xj[i]; its lanes read x[clamp(xs0 + slot)] = xg[i] of that channel row
     unsigned xg[NX];
     int xc[NX];
-    unsigned okm = 0;   // reflect mode: bit i = window item i of this lane reads a real sample (else the zero extension / tile overrun)
+    unsigned okm = 0;   // bit i = window item i of this lane reads a real sample (else zero padding / the zero extension / tile overrun)
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         const int item = swave + SW * i;
         xc[i] = (item * chunk_magic) >> 20;
-        const int gp = xs0 + (item - xc[i] * nchunk) * 64 + lane;
-        xg[i] = (unsigned)min(max(gp, 0), x_len - 1);
+        const int jw = (item - xc[i] * nchunk) * 64 + lane;          // window slot of this lane
+        const int sg = seg_of(col0 * s + jw, flat_px);               // its segment (0 without p.flat)
+        const int gp = xs0 + jw - sg * flat_px;                      // x position within clip b + sg
+        xg[i] = (unsigned)min(sg, p.Bc - 1 - b) * (unsigned)p.x_bstride + (unsigned)min(max(gp, 0), x_len - 1);   // (address stays inside the tensor)
+        if ((b + sg < p.Bc) & (gp >= 0) & (gp < x_len)) okm |= 1u << i;
         if (in_mode & 4) {   // SConv1d.Pad1d (SConv1d.cs:258-274): padded position gp -> sample |gp - left| mirrored at Lz - 1
             int q = gp - p.in_left;
             q = q < 0 ? -q : q;
             if (q >= p.in_Lz) q = 2 * (p.in_Lz - 1) - q;
-            if ((gp >= 0) & (gp < x_len) & (q >= 0) & (q < p.in_L)) okm |= 1u << i;
+            if (!((q >= 0) & (q < p.in_L))) okm &= ~(1u << i);
             xg[i] = (unsigned)min(max(q, 0), p.in_L - 1);
         }
     }
@@ -300,10 +317,8 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 const int c = (item * chunk_magic) >> 20;
                 const int ci = cbn * CB + c;
                 const int j = (item - c * nchunk) * 64 + lane;
-                const int gp = xs0 + j;
-                bool ok = (ci < Cin) & (gp >= 0) & (gp < x_len);  // slots past xw / items past n_items are never read
+                const bool ok = (ci < Cin) & (((okm >> i) & 1u) != 0);  // slots past xw / items past n_items are never read
                 if constexpr (IMODE == 2) {
-                    if (in_mode & 4) ok = (ci < Cin) & (((okm >> i) & 1u) != 0);
                     float t = rx[u];
                     if (in_mode & 1) t = ((t - in_mu) * in_rs) * al[u].x + al[u].y;   // GroupNorm(1,C) apply (NormConv1d.cs:155)
                     if (in_mode & 2) t = nc_eluf(t);
@@ -405,7 +420,13 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
 #endif
     __syncthreads();
 
-    const int x_lane = wave * BNW + l31;
+    // window column of this lane's tile columns (one per 32-column block j): column + the halos of the segments before it
+    int sgc[TN], ej[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) sgc[j] = seg_of(col0 + wave * BNW + j * 32 + l31, flat_pc);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) ej[j] = (sgc[j] - sgc[0]) * p.flat_hc;
+    const int x_lane = wave * BNW + l31 + sgc[0] * p.flat_hc;
     // B-fragment addressing: MFMA step kp pairs kk = 2kp (lanes 0-31) with kk+1 (lanes 32-63), i.e. tap k0 of channel c0 with the
     // next tap (or tap 0 of the next channel).  The lane-half difference depends only on k0: one base per k0, so a step's address
     // is base[k0] + (wave-uniform offset of (c0, k0)) -- one vector add per step.
@@ -429,7 +450,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         const int o = xt[k0] + __builtin_amdgcn_readfirstlane(xsc + c0 * xrow + tap[k0]);
         nc_load_a_frag<TM>(Ac + 2 * kp * BM, l31, fa[kp % (FD + 1)]);   // Ac carries the lane part: immediate offsets only
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[kp % (FD + 1)][j] = smem[o + j * 32];
+        for (int j = 0; j < TN; ++j) fb[kp % (FD + 1)][j] = smem[(j == 0 ? o : o + ej[j]) + j * 32];
     };
 
     if constexpr (SPEC) {
@@ -480,8 +501,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 const int item = swave + SW * i;
                 const int c = xc[i];
                 const int j = (item - c * nchunk) * 64 + lane;
-                const int gp = xs0 + j;
-                const bool ok = (cbn * CB + c < Cin) & (gp >= 0) & (gp < x_len);
+                const bool ok = (cbn * CB + c < Cin) & (((okm >> i) & 1u) != 0);
                 float v = ok ? rx[i] : 0.0f;
                 if constexpr (SNAKE) {
                     const float2 al = Al[cbn * CB + c];
@@ -628,17 +648,19 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     bool cols_ok = true;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = col0 + wave * BNW + j * 32 + l31;
+        const int col = col0 + wave * BNW + j * 32 + l31 - sgc[j] * flat_pc;   // column within its clip b + sgc[j]
         const int t = col * p.y_tstride + p.y_toff + phase;
+        const bool clip_ok = (col < p.n_cols) & (b + sgc[j] < p.Bc);
+        const unsigned clip_off = (unsigned)min(sgc[j], p.Bc - 1 - b) * (unsigned)p.y_bstride;   // (clamped: masked reads stay inside the tensor)
         if constexpr (SUB) {   // t = sample of sub-row r = 0; row R adds (R + 4*hi) & smask.  Time bounds are checked per row.
-            okc[j] = col < p.n_cols;
+            okc[j] = clip_ok;
             tcol[j] = t;
-            lane_off[j] = (unsigned)((4 * hi) >> sh) * cstride + (unsigned)((4 * hi) & smask) + (unsigned)t;
+            lane_off[j] = clip_off + (unsigned)((4 * hi) >> sh) * cstride + (unsigned)((4 * hi) & smask) + (unsigned)t;
             cols_ok = cols_ok & okc[j] & (t >= 0) & (t + smask < p.Tout);
         } else {
-            okc[j] = (col < p.n_cols) & (t >= 0) & (t < p.Tout);
+            okc[j] = clip_ok & (t >= 0) & (t < p.Tout);
             tcol[j] = min(max(t, 0), p.Tout - 1);
-            lane_off[j] = (unsigned)(4 * hi) * cstride + (unsigned)tcol[j];
+            lane_off[j] = clip_off + (unsigned)(4 * hi) * cstride + (unsigned)tcol[j];
             cols_ok = cols_ok & okc[j];
         }
     }

@@ -259,8 +259,14 @@ struct LstmSeqArgs {
     float* hx;            // [2][tiles][C][16] exchange buffers
     unsigned* flags;      // [tiles][C/16] steps published per workgroup (zeroed before the launch)
     unsigned* tmo;        // timeout word (zeroed at model creation)
+    float* cstate;        // [tiles][C][16] cell state carried between the chunk launches of one layer
+    // element strides of gi / out over (clip, channel row, step): [N][rows][T] = (rows*T, T, 1) for tensors that meet the convolution
+    // stack, [rows][T][N] = (1, T*N, N) for the tensors between the layers of a pipelined call (a step range is then a contiguous
+    // column range of one 2-D matrix, which is what the chunked input-projection GEMM of the next layer wants)
+    int64_t gi_b, gi_c, gi_t, out_b, out_c, out_t;
     int N, C;
     int64_t T;
+    int64_t t0, t1;       // this launch runs steps [t0, t1) of the T-step sequence (state of step t0-1 in hx / cstate / flags)
     int tile0;            // first column tile of this launch
 };
 typedef __attribute__((address_space(1))) unsigned lstm_gu32;
@@ -288,23 +294,27 @@ __global__ __launch_bounds__(1024, 1) void lstm_seq_kernel(const LstmSeqArgs a) 
     const int j = ub * 4 + k4;                      // this lane's hidden unit
     const int b = (a.tile0 + tile) * 16 + cl;       // this lane's clip
     const int bb = min(b, N - 1);
-    const float* g = a.gi + ((int64_t)bb * 4 * C) * T;
+    const float* g = a.gi + (int64_t)bb * a.gi_b;
+    const int64_t gc = a.gi_c, gt = a.gi_t;
     const float bh0 = a.bhh[j], bh1 = a.bhh[C + j], bh2 = a.bhh[2 * C + j], bh3 = a.bhh[3 * C + j];
     float* const hx0 = a.hx + ((int64_t)(0 * gridDim.y + tile) * C) * 16;
     float* const hx1 = a.hx + ((int64_t)(1 * gridDim.y + tile) * C) * 16;
     unsigned* const flags = a.flags + (int64_t)tile * nprod;
-    const int64_t orow = ((int64_t)bb * C + j) * T;
-    float cst = 0.0f;
+    const int64_t orow = ((int64_t)bb * C + j) * T;                       // skip tensor: always [N,C,T]
+    float* const orow_out = a.out + (int64_t)bb * a.out_b + (int64_t)j * a.out_c;
+    float* const cs_slot = a.cstate + ((int64_t)tile * C) * 16 + ub * 64 + lane;
+    float cst = (q == 0 && a.t0 > 0) ? *cs_slot : 0.0f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // input-projection pre-activations (and the skip value) run one step ahead of their use (q = 0 waves only): they are reads,
     // issued before the step's stores, so they never queue behind a store acknowledgement
     float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f, sk = 0.0f;
     if (q == 0) {
-        g0 = g[(int64_t)j * T]; g1 = g[(int64_t)(C + j) * T]; g2 = g[(int64_t)(2 * C + j) * T]; g3 = g[(int64_t)(3 * C + j) * T];
-        if (a.skip) sk = a.skip[orow];
+        const int64_t ts = a.t0;
+        g0 = g[(int64_t)j * gc + ts * gt]; g1 = g[(int64_t)(C + j) * gc + ts * gt]; g2 = g[(int64_t)(2 * C + j) * gc + ts * gt]; g3 = g[(int64_t)(3 * C + j) * gc + ts * gt];
+        if (a.skip) sk = a.skip[orow + ts];
     }
-    for (int64_t t = 0; t < T; ++t) {
+    for (int64_t t = a.t0; t < a.t1; ++t) {
         f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
         const float c0 = g0, c1 = g1, c2 = g2, c3 = g3, csk = sk;
         const int64_t tn = min(t + 1, T - 1);
@@ -341,7 +351,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_seq_kernel(const LstmSeqArgs a) 
 #endif
             }
             if (q == 0) {
-                g0 = g[(int64_t)j * T + tn]; g1 = g[(int64_t)(C + j) * T + tn]; g2 = g[(int64_t)(2 * C + j) * T + tn]; g3 = g[(int64_t)(3 * C + j) * T + tn];
+                g0 = g[(int64_t)j * gc + tn * gt]; g1 = g[(int64_t)(C + j) * gc + tn * gt]; g2 = g[(int64_t)(2 * C + j) * gc + tn * gt]; g3 = g[(int64_t)(3 * C + j) * gc + tn * gt];
                 if (a.skip) sk = a.skip[orow + tn];
             }
 #pragma unroll
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_seq_kernel(const LstmSeqArgs a) 
                 for (int r = 0; r < 4; ++r) acc[r] = (acc[r] + p1[r]) + (p2[r] + p3[r]);
             }
         } else if (q == 0) {
-            g0 = g[(int64_t)j * T + tn]; g1 = g[(int64_t)(C + j) * T + tn]; g2 = g[(int64_t)(2 * C + j) * T + tn]; g3 = g[(int64_t)(3 * C + j) * T + tn];
+            g0 = g[(int64_t)j * gc + tn * gt]; g1 = g[(int64_t)(C + j) * gc + tn * gt]; g2 = g[(int64_t)(2 * C + j) * gc + tn * gt]; g3 = g[(int64_t)(3 * C + j) * gc + tn * gt];
             if (a.skip) sk = a.skip[orow + tn];
         }
         if (q == 0) {
@@ -371,13 +381,14 @@ __global__ __launch_bounds__(1024, 1) void lstm_seq_kernel(const LstmSeqArgs a) 
                 __hip_atomic_store(hq, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if (b < N) a.out[orow + t] = a.skip ? h + csk : h;
+            if (b < N) orow_out[t * a.out_t] = a.skip ? h + csk : h;
         }
         if (t + 1 < T) {
             __syncthreads();   // the four publishing waves have drained their stores (and the partial tiles are free again)
             if (threadIdx.x == 0) __hip_atomic_store((lstm_gu32*)(flags + ubw), (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (q == 0 && a.t1 < T) *cs_slot = cst;   // the next chunk launch of this layer resumes from here
 }
 
 // Euclidean codebook search, D <= 128 (EuclideanCodebook.cs:155-182): per frame dist_n = (|x|^2 + |e_n|^2) - 2*(x.e_n) with fma
@@ -730,6 +741,8 @@ EncodecModel::~EncodecModel() {
         if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
     }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (lstm_stream) (void)hipStreamDestroy(lstm_stream);
+    for (hipEvent_t e : lstm_events) (void)hipEventDestroy(e);
 }
 
 void EncodecModel::check_async_errors() {
@@ -875,47 +888,142 @@ float* EncodecModel::materialize(const Act& a, int N, const float* scale, int mo
 float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
     const int C = l.C;
     if (l.layers.empty()) return const_cast<float*>(x);
-    const float* in = x;
-    float* out = nullptr;
-    for (size_t li = 0; li < l.layers.size(); ++li) {
-        LstmLayer& y = *l.layers[li];
-        float* gi = alloc((size_t)N * 4 * C * T);
-        ConvIO io{};
+    static const bool stepwise = std::getenv("NC_LSTM_STEPWISE") && std::getenv("NC_LSTM_STEPWISE")[0] == '1';
+    const int KS = C / 4;
+    const int nl = (int)l.layers.size();
+    auto ih_gemm = [&](LstmLayer& y, const float* in, float* gi, hipStream_t s) {
+        ConvIO io{};   // W_ih * x_t + b_ih for all steps: one pointwise convolution over the [N,C,T] tensor
         io.x = in; io.x_bstride = (int64_t)C * T; io.x_cstride = T; io.x_len = (int32_t)T; io.Tin = T;
         io.y = gi; io.y_bstride = (int64_t)4 * C * T; io.y_cstride = T;
-        launch_conv(y.ih, io, N, stream, &prof);
-        out = alloc((size_t)N * C * T);
-        const bool last = li + 1 == l.layers.size();
-        if (prof.on) prof.begin(stream, NC_KC_LSTM, 2.0 * 4 * C * C * (double)N * T, 4.0 * 6 * C * (double)N * T);
-        static const bool stepwise = std::getenv("NC_LSTM_STEPWISE") && std::getenv("NC_LSTM_STEPWISE")[0] == '1';
-        const int KS = C / 4;
-        if (!stepwise && C % 64 == 0 && (KS == 128 || KS == 16)) {
-            // persistent layer kernel: all T steps in one launch per group of column tiles (<= 128 co-resident workgroups)
-            const int nprod = C / 16, n_tiles = (N + 15) / 16, per_launch = std::max(1, 128 / nprod);
-            const size_t lds = (size_t)4 * KS * 64 * 4 + 3 * 4 * 64 * 16;
-            unsigned* sync = lstm_sync.as<unsigned>();                                     // [0] = timeout word (zeroed at load)
-            unsigned* flags_all = reinterpret_cast<unsigned*>(alloc((size_t)n_tiles * nprod));   // per call + layer: groups may run concurrently
-            NC_HIP(hipMemsetAsync(flags_all, 0, (size_t)n_tiles * nprod * 4, stream));
-            for (int t0 = 0; t0 < n_tiles; t0 += per_launch) {
-                const int nt = std::min(per_launch, n_tiles - t0);
+        launch_conv(y.ih, io, N, s, &prof);
+    };
+    if (!stepwise && C % 64 == 0 && (KS == 128 || KS == 16)) {
+        // Persistent layer kernel: a launch runs a range of steps for a group of column tiles (<= 64 co-resident workgroups, so the
+        // two layers of a pipelined call plus a concurrent segment group still fit the chip's 256 CUs at one workgroup per CU).
+        // Layer pipelining: layer l+1 at step t needs only h^l_t, so the sequence is cut into chunks and chunk k of layer l+1 (with its
+        // input-projection GEMM) runs on a second stream while layer l runs chunk k+1: the dependent chain of a 2-layer LSTM shrinks
+        // from 2T steps to about T + T/chunks.  The arithmetic is untouched -- the same kernel, resumed from carried (h, c) state.
+        // The tensors BETWEEN the layers (h^l and the input projections of layer l+1) are laid out [rows][T][N]: the steps of a chunk
+        // are then one contiguous column range of a 2-D matrix, so the chunk's GEMM is a one-"clip" pointwise convolution over
+        // chunk*N columns with full 128-column tiles (cut out of [N,C,T], a chunk would fill a fifth of every tile: measured, the
+        // per-chunk GEMMs then cost as much as the full one and 6 chunks made C3 2.2 ms slower).
+        static const int want_chunks = [] { const char* e = std::getenv("NC_LSTM_CHUNKS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
+        int64_t chunk = T;
+        if (nl >= 2 && want_chunks > 1 && T >= 32 && !on_side_group && (int64_t)4 * C * T * N < ((int64_t)1 << 31)) {
+            chunk = (((T + want_chunks - 1) / want_chunks) + 1) & ~(int64_t)1;   // even: chunk starts stay 8-byte aligned for the 1x1 path
+            chunk = std::max<int64_t>(chunk, 8);
+        }
+        const int nch = (int)((T + chunk - 1) / chunk);
+        const bool piped = nch > 1;
+        const int nprod = C / 16, n_tiles = (N + 15) / 16, per_launch = std::max(1, 64 / nprod);
+        const size_t lds = (size_t)4 * KS * 64 * 4 + 3 * 4 * 64 * 16;
+        unsigned* sync = lstm_sync.as<unsigned>();                                     // [0] = timeout word (zeroed at load)
+        std::vector<float*> gi(nl), out(nl), hx(nl), cs(nl);
+        std::vector<unsigned*> flags(nl);
+        for (int li = 0; li < nl; ++li) {
+            gi[li] = alloc((size_t)N * 4 * C * T);
+            out[li] = alloc((size_t)N * C * T);
+            hx[li] = alloc((size_t)2 * n_tiles * C * 16);
+            cs[li] = alloc((size_t)n_tiles * C * 16);
+            flags[li] = reinterpret_cast<unsigned*>(alloc((size_t)n_tiles * nprod));   // per call + layer: groups may run concurrently
+            NC_HIP(hipMemsetAsync(flags[li], 0, (size_t)n_tiles * nprod * 4, stream));
+        }
+        hipStream_t sA = stream, sB = stream;
+        size_t ev_i = 0;
+        auto next_event = [&]() {
+            if (ev_i == lstm_events.size()) {
+                hipEvent_t e;
+                NC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                lstm_events.push_back(e);
+            }
+            return lstm_events[ev_i++];
+        };
+        auto layer_stream = [&](int li) { return (li & 1) ? sB : sA; };
+        // tensor of layer li that meets the convolution stack ([N][rows][T]) or sits between two pipelined layers ([rows][T][N])
+        auto between = [&](int li_out) { return piped && li_out + 1 < nl; };
+        auto lstm_chunk = [&](int li, int64_t t0, int64_t t1) {
+            LstmLayer& y = *l.layers[li];
+            hipStream_t s = layer_stream(li);
+            const bool last = li + 1 == nl;
+            const double n = (double)N * (double)(t1 - t0);
+            if (prof.on) prof.begin(s, NC_KC_LSTM, 2.0 * 4 * C * C * n, 4.0 * 6 * C * n);
+            for (int tl = 0; tl < n_tiles; tl += per_launch) {
+                const int nt = std::min(per_launch, n_tiles - tl);
                 LstmSeqArgs a{};
-                a.gi = gi; a.whhp = y.whhp.as<float>(); a.bhh = y.bhh.as<float>(); a.skip = last ? x : nullptr; a.out = out;
-                a.hx = alloc((size_t)2 * nt * C * 16);
-                a.flags = flags_all + (size_t)t0 * nprod; a.tmo = sync;
-                a.N = N; a.C = C; a.T = T; a.tile0 = t0;
+                a.gi = gi[li]; a.whhp = y.whhp.as<float>(); a.bhh = y.bhh.as<float>(); a.skip = last ? x : nullptr; a.out = out[li];
+                if (li > 0 && piped) { a.gi_b = 1; a.gi_c = T * N; a.gi_t = N; }
+                else { a.gi_b = (int64_t)4 * C * T; a.gi_c = T; a.gi_t = 1; }
+                if (between(li)) { a.out_b = 1; a.out_c = T * N; a.out_t = N; }
+                else { a.out_b = (int64_t)C * T; a.out_c = T; a.out_t = 1; }
+                a.hx = hx[li] + (size_t)2 * tl * C * 16;
+                a.cstate = cs[li] + (size_t)tl * C * 16;
+                a.flags = flags[li] + (size_t)tl * nprod; a.tmo = sync;
+                a.N = N; a.C = C; a.T = T; a.t0 = t0; a.t1 = t1; a.tile0 = tl;
                 auto launch = [&](auto kern) {
                     ensure_dynamic_lds((const void*)kern, lds);
-                    hipLaunchKernelGGL(kern, dim3((unsigned)nprod, (unsigned)nt), dim3(1024), lds, stream, a);
+                    hipLaunchKernelGGL(kern, dim3((unsigned)nprod, (unsigned)nt), dim3(1024), lds, s, a);
                 };
                 if (KS == 128) launch(lstm_seq_kernel<128>);
                 else launch(lstm_seq_kernel<16>);
             }
             NC_HIP(hipGetLastError());
-            if (prof.on) prof.end(stream);
-            in = out;
-            continue;
+            if (prof.on) prof.end(s);
+        };
+        if (!piped) {
+            for (int li = 0; li < nl; ++li) {
+                ih_gemm(*l.layers[li], li ? out[li - 1] : x, gi[li], stream);
+                lstm_chunk(li, 0, T);
+            }
+            return out[nl - 1];
         }
-        // generic fallback: one launch per time step (block = hidden unit with its 4 weight rows in LDS, thread = clip)
+        if (!lstm_stream) NC_HIP(hipStreamCreateWithFlags(&lstm_stream, hipStreamNonBlocking));
+        sB = lstm_stream;
+        // layer 0's input projections depend on x alone: one full GEMM ahead of everything
+        ih_gemm(*l.layers[0], x, gi[0], sA);
+        {
+            hipEvent_t fork = next_event();
+            NC_HIP(hipEventRecord(fork, sA));
+            NC_HIP(hipStreamWaitEvent(sB, fork, 0));
+        }
+        // the input projections of steps [t0, t0+n) of a layer above the first: columns [t0*N, (t0+n)*N) of the [rows][T*N] matrices
+        auto ih_gemm_chunk = [&](LstmLayer& y, const float* in, float* g, int64_t t0, int64_t n, hipStream_t s) {
+            ConvIO io{};
+            io.x = in + t0 * N; io.x_bstride = 0; io.x_cstride = T * N; io.x_len = (int32_t)(n * N); io.Tin = n * N;
+            io.y = g + t0 * N; io.y_bstride = 0; io.y_cstride = T * N;
+            launch_conv(y.ih, io, 1, s, &prof);
+        };
+        std::vector<hipEvent_t> prev(nch, nullptr);   // prev[k]: chunk k of the layer below is complete
+        for (int li = 0; li < nl; ++li) {
+            hipStream_t s = layer_stream(li);
+            for (int k = 0; k < nch; ++k) {
+                const int64_t t0 = (int64_t)k * chunk, t1 = std::min(T, t0 + chunk);
+                if (li > 0) {
+                    NC_HIP(hipStreamWaitEvent(s, prev[k], 0));
+                    ih_gemm_chunk(*l.layers[li], out[li - 1], gi[li], t0, t1 - t0, s);
+                }
+                lstm_chunk(li, t0, t1);
+                if (li + 1 < nl) {
+                    hipEvent_t e = next_event();
+                    NC_HIP(hipEventRecord(e, s));
+                    prev[k] = e;
+                }
+            }
+        }
+        hipEvent_t join = next_event();   // the handle's stream continues after everything issued on the second one
+        NC_HIP(hipEventRecord(join, sB));
+        NC_HIP(hipStreamWaitEvent(sA, join, 0));
+        return out[nl - 1];
+    }
+    // generic fallback: one launch per time step (block = hidden unit with its 4 weight rows in LDS, thread = clip)
+    const float* in = x;
+    float* out = nullptr;
+    for (int li = 0; li < nl; ++li) {
+        LstmLayer& y = *l.layers[li];
+        float* gi = alloc((size_t)N * 4 * C * T);
+        ih_gemm(y, in, gi, stream);
+        out = alloc((size_t)N * C * T);
+        const bool last = li + 1 == nl;
+        if (prof.on) prof.begin(stream, NC_KC_LSTM, 2.0 * 4 * C * C * (double)N * T, 4.0 * 6 * C * (double)N * T);
         float* h0 = alloc((size_t)C * N);
         float* h1 = alloc((size_t)C * N);
         float* cs = alloc((size_t)C * N);
@@ -1020,6 +1128,7 @@ void EncodecModel::encode_dev(const float* pcm, int B, int64_t T, int64_t* codes
         const int G = (int)(g - f);
         const Seg& s = segs[f];
         const int side = (n_groups > 0 && !no_overlap) ? (n_groups - 1) % 2 : -1;   // groups after the first: side streams
+        on_side_group = side >= 0;
         if (side >= 0) {
             stream = side_stream[side];
             if (!side_used[side]) NC_HIP(hipStreamWaitEvent(stream, ev_fork, 0));
@@ -1035,6 +1144,7 @@ void EncodecModel::encode_dev(const float* pcm, int B, int64_t T, int64_t* codes
         code_off += (int64_t)G * B * n_q * s.frames;
         emb_off += (int64_t)G * B * D * s.frames;
         stream = main_stream;
+        on_side_group = false;
         f = g;
     }
     for (int i = 0; i < 2; ++i)
@@ -1069,6 +1179,7 @@ void EncodecModel::decode_dev(const int64_t* codes, const float* scales, int B, 
         while (g < segs.size() && segs[g].frames == segs[f].frames && (int64_t)(g - f + 1) * B <= 4096) ++g;
         const int G = (int)(g - f);
         const int side = (n_groups > 0 && !no_overlap) ? (n_groups - 1) % 2 : -1;
+        on_side_group = side >= 0;
         if (side >= 0) {
             stream = side_stream[side];
             if (!side_used[side]) NC_HIP(hipStreamWaitEvent(stream, ev_fork, 0));
@@ -1083,6 +1194,7 @@ void EncodecModel::decode_dev(const int64_t* codes, const float* scales, int B, 
         }
         code_off += (int64_t)G * B * nq * segs[f].frames;
         stream = main_stream;
+        on_side_group = false;
         f = g;
     }
     for (int i = 0; i < 2; ++i)

@@ -209,6 +209,10 @@ struct EncodecModel : Codec {
     // streams (forked / joined with events), so the short tail segment of a clip hides behind the full-length batch
     hipStream_t side_stream[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    // layer-pipelined LSTM (run_lstm): second stream for layer 1 and the chunk events; only the primary segment group pipelines
+    hipStream_t lstm_stream = nullptr;
+    std::vector<hipEvent_t> lstm_events;
+    bool on_side_group = false;
     ~EncodecModel() override;
 
     explicit EncodecModel(const nc_encodec_config& c);
