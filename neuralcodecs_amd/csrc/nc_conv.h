@@ -74,7 +74,9 @@ struct ConvArgs {
 // (rows r, 32+r, ...) sit next to each other, so a lane fetches its A fragments with one wide LDS read (b64 / b128; TM = 3:
 // b64 + b32) whose address is lane base + immediate.
 __host__ __device__ constexpr int a_tile_pos(int TM, int i, int r) {
-    return TM == 1 ? r : TM == 2 ? 2 * r + i : TM == 4 ? 4 * r + i : (i < 2 ? 2 * r + i : 64 + r);
+    // (TM = 6 / 8, the whole-channel tiles of the wide fused residual units: two TM = 3 / 4 images side by side)
+    return TM == 6 ? (i / 3) * 96 + (i % 3 < 2 ? 2 * r + i % 3 : 64 + r) : TM == 8 ? (i / 4) * 128 + 4 * r + i % 4 :
+           TM == 1 ? r : TM == 2 ? 2 * r + i : TM == 4 ? 4 * r + i : (i < 2 ? 2 * r + i : 64 + r);
 }
 
 struct TileCfg {

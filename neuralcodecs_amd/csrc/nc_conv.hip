@@ -57,6 +57,7 @@ static int experiment_mode(const char*) { return 0; }
 #endif
 conv_kernel_fn conv_kernel_table_sub_k2(int, int);
 conv_kernel_fn conv_kernel_table_sub_narrow_k2(int);
+conv_kernel_fn conv_kernel_table_fusedw_k7(int, int);
 conv_kernel_fn conv_kernel_table_slim_k3(int, int);
 conv_kernel_fn conv_kernel_table_slim_k7(int, int);
 conv_kernel_fn conv_kernel_table_narrow_k2(int);
@@ -213,7 +214,15 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
             alts.back()->cfg.TM = tm;
             pack(alts.back()->cfg, alts.back()->w, alts.back()->w_phase_stride);
         }
-    if (!transposed && K == 1 && Cin == Cout && Cin % 32 == 0 && Cin <= 128) {
+    // whole-channel tile of the wide fused residual units (C = 192 / 256 -> TM = 6 / 8; launched only through ConvIO::fuse_k1)
+    static const bool no_wide_fuse = std::getenv("NC_NO_WIDE_FUSE") && std::getenv("NC_NO_WIDE_FUSE")[0] == '1';
+    if (!no_alts && !no_wide_fuse && !transposed && K == 7 && stride == 1 && Cin == Cout && (Cout == 192 || Cout == 256)) {
+        alts.emplace_back(new Alt());
+        alts.back()->cfg = cfg;
+        alts.back()->cfg.TM = Cout / 32;
+        pack(alts.back()->cfg, alts.back()->w, alts.back()->w_phase_stride);
+    }
+    if (!transposed && K == 1 && Cin == Cout && Cin % 32 == 0 && (Cin <= 128 || ((Cin == 192 || Cin == 256) && !no_wide_fuse))) {
         // image for the fused residual-unit tail: [row block][ci][32 rows]
         std::vector<float> f((size_t)Cin * Cout);
         for (int i2 = 0; i2 < Cout / 32; ++i2)
@@ -249,8 +258,10 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
 }
 
 bool can_fuse_res_unit(const ConvLayer& k7, const ConvLayer& k1) {
-    return !k7.transposed && k7.K == 7 && k7.stride == 1 && k7.Cin == k7.Cout && k7.Cout % 32 == 0 && k7.Cout >= 64 && k7.Cout <= 128 &&
-           k7.Cout % 32 == 0 && k1.K == 1 && k1.Cin == k7.Cout && k1.Cout == k7.Cout && k1.w_fused.p != nullptr &&
+    bool tile = k7.Cout <= 128;
+    for (const auto& a : k7.alts) tile = tile || a->cfg.BM() == k7.Cout;   // wide units: the whole-channel tile was packed at load
+    return !k7.transposed && k7.K == 7 && k7.stride == 1 && k7.Cin == k7.Cout && k7.Cout % 32 == 0 && k7.Cout >= 64 && tile &&
+           k1.K == 1 && k1.Cin == k7.Cout && k1.Cout == k7.Cout && k1.w_fused.p != nullptr &&
            k7.has_bias && k1.has_bias;
 }
 
@@ -271,17 +282,19 @@ static TileChoice choose_tile(const ConvLayer& L, int64_t blocks_per_rowtile, bo
         static const double pen[5] = {0, 1.30, 1.10, 1.05, 1.00};
         const int bpc = pointwise_fast ? bpc_pw[c.TM] : bpc_gen[c.TM];
         const double rounds = std::ceil(blocks / (256.0 * bpc));
-        return rounds * bpc * c.TM * pen[c.TM];
+        // (k = 7 at 128 rows x 256 columns runs out of registers -- 212 B of scratch per lane; C = 256: 1.80 ms against 1.65 ms with 64-row tiles)
+        return rounds * bpc * c.TM * pen[c.TM] * ((c.TM == 4 && c.K == 7 && !pointwise_fast) ? 1.12 : 1.0);
     };
     TileChoice best{L.cfg, L.w.as<float>(), L.w_phase_stride};
     double bc = cost(L.cfg);
     static const int tm_pick = std::getenv("NC_TM_PICK") ? atoi(std::getenv("NC_TM_PICK")) : 0;   // experiment: force a packed variant
     if (tm_pick) {
         for (const auto& a : L.alts)
-            if (a->cfg.TM == tm_pick) return TileChoice{a->cfg, a->w.as<float>(), a->w_phase_stride};
+            if (a->cfg.TM == tm_pick && tm_pick <= 4) return TileChoice{a->cfg, a->w.as<float>(), a->w_phase_stride};
         return best;
     }
     for (const auto& a : L.alts) {
+        if (a->cfg.TM > 4) continue;   // whole-channel tiles of the wide fused units
         const double c = cost(a->cfg);
         if (c < bc) {
             bc = c;
@@ -417,7 +430,8 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     }
     // Flattened (clip, column) axis (kernel: "Flattened column axis"): when the rows are short or leave a good part of their last
     // tile on padding, the columns of all clips are cut into tiles as one axis.  Needs the one-launch forms (no per-phase launches),
-    // no per-clip scalars in the kernel (Encodec input mode, noise rows), a window (tile + one halo per touched clip) that still fits
+    // no per-clip scalars in the kernel (Encodec input mode -- measured: per-segment statistics through an LDS table made every
+    // instance of the template ~5 % slower for 0.07 ms on C3 -- and noise rows), a window (tile + one halo per touched clip) that still fits
     // the staging registers, and 32-bit offsets that reach 3 clips ahead.
     bool flat = false;
     int flat_S = 0, flat_hc = 0;
@@ -465,6 +479,8 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
             nx = 5;
         }
     }
+    const bool fused_wide = io.fuse_k1 && c.TM > 4;   // C = 192 / 256 residual unit: whole-channel tile, 128 columns, 4-channel blocks
+    if (fused_wide) { c.TN = 1; c.CB = 4; nx = 5; }
     bool slim = false;
     conv_kernel_fn slim_fn = nullptr;
     {   // Slim variant: half-size reduction block (half the LDS per workgroup), 4+ workgroups per CU.  The narrow long-T layers
@@ -561,7 +577,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         a.tapoff[k] = (k < L.Ktaps) ? (sx == 1 ? q : (q % sx) * a.xwp + q / sx) : 0;
     }
     size_t lds_f = 2 * (size_t)KB * BM + 2 * (size_t)a.xbuf + ((io.alpha_in || (in_mode & 1)) ? 2 * (size_t)a.n_cb * CB : 0);
-    if (io.fuse_k1) lds_f = std::max(lds_f, (size_t)BM * BM);   // the 1x1 weights reuse the tile buffers
+    if (io.fuse_k1) lds_f = std::max(lds_f, fused_wide ? (size_t)2 * BM * 32 : (size_t)BM * BM);   // the 1x1 weights reuse the tile buffers
     a.ep_off = (int32_t)lds_f;
     size_t lds = sizeof(float) * (lds_f + 6 * (size_t)BM);
 #ifdef NC_DBG_TRACE
@@ -574,7 +590,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         a.w2 = io.fuse_k1->w_fused.as<float>();
         a.bias2 = io.fuse_k1->bias.as<float>();
         a.alpha_out2 = io.alpha_out2;
-        fn = conv_kernel_table_fused_k7(c.TM, c.TN);
+        fn = fused_wide ? conv_kernel_table_fusedw_k7(c.TM, c.TN) : conv_kernel_table_fused_k7(c.TM, c.TN);
         if (!fn) fail(NC_EUNSUPPORTED, "no fused residual-unit kernel for TM=%d TN=%d", c.TM, c.TN);
     } else if (dist) {
         fn = conv_kernel_table_dist_k7(c.TM, c.TN);

@@ -876,6 +876,61 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                     acc[i][j][r0] = __uint_as_float(sw[0]);      // rows (2m, 2m+1) of the low half : k-step m = 4q+e
                     acc[i][j][r0 + 1] = __uint_as_float(sw[1]);  // rows of the high half           : k-step m+2
                 }
+        // Wide units (TM > 4: C = 192 / 256, one 128-column tile per workgroup): W1 does not fit the LDS at two workgroups per CU, so
+        // its 32-row blocks are streamed through two LDS buffers, one block ahead: the global reads of block i2+1 (weights and skip
+        // operand) are issued BEFORE the stores of block i2 and land under the matrix-core chain of block i2 + 1's predecessor.
+        if constexpr (TM > 4) {
+            constexpr int W1V = BM * 32 / 4;                    // float4 words per row block
+            constexpr int NW1 = (W1V + NT - 1) / NT;
+            const f32x4* w2 = reinterpret_cast<const f32x4*>(p.w2);
+            f32x4 wr[NW1];
+            auto w1_issue = [&](int i2) __attribute__((always_inline)) {
+#pragma unroll
+                for (int n = 0; n < NW1; ++n) wr[n] = w2[(size_t)i2 * W1V + min(tid + NT * n, W1V - 1)];
+            };
+            auto w1_store = [&](float* dstf) __attribute__((always_inline)) {
+                f32x4* dst = reinterpret_cast<f32x4*>(dstf);
+#pragma unroll
+                for (int n = 0; n < NW1; ++n)
+                    if (W1V % NT == 0 || tid + NT * n < W1V) dst[tid + NT * n] = wr[n];
+            };
+            float rv2[2][16][TN];
+            w1_issue(0);
+            if (tile_full) load_res(0, rv2[0], p.res, std::true_type{});
+            w1_store(smem);
+            __syncthreads();
+            nc_static_for<TM>([&](auto i2t) __attribute__((always_inline)) {
+                constexpr int i2 = decltype(i2t)::value;
+                if constexpr (i2 + 1 < TM) {
+                    w1_issue(i2 + 1);
+                    if (tile_full) load_res(i2 + 1, rv2[(i2 + 1) & 1], p.res, std::true_type{});
+                }
+                f32x16 acc2[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[j][r] = 0.0f;
+                const float* W1s = smem + (i2 & 1) * (BM * 32) + hi * 32 + l31;
+                nc_static_for<BM / 2>([&](auto kpt) __attribute__((always_inline)) {
+                    constexpr int kp = decltype(kpt)::value;
+                    constexpr int i = kp / 16, m = kp % 16;
+                    constexpr int reg = 4 * (m >> 2) + 2 * (m & 1) + ((m >> 1) & 1);
+                    const float a = W1s[2 * kp * 32];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[i][j][reg], acc2[j], 0, 0, 0);
+                });
+                if constexpr (i2 + 1 < TM) w1_store(smem + ((i2 + 1) & 1) * (BM * 32));   // the other buffer: its readers passed the last barrier
+                const float nz0[TN] = {};
+                if (!tile_full) {
+                    emit_rows_quad(i2, acc2, Ep + 3 * BM, Ep + 4 * BM, p.alpha_out2 != nullptr, p.res);
+                } else {
+                    add_rows(i2, acc2, rv2[i2 & 1], nz0, Ep + 3 * BM, std::true_type{}, std::false_type{});
+                    if (p.alpha_out2 != nullptr) store_rows(i2, acc2, Ep + 4 * BM, std::true_type{}, std::false_type{}, std::true_type{});
+                    else store_rows(i2, acc2, Ep + 4 * BM, std::false_type{}, std::false_type{}, std::true_type{});
+                }
+                if constexpr (i2 + 1 < TM) __syncthreads();
+            });
+        } else {
         // 3) W1 (packed [row block][ci][32 rows]) -> LDS; the main loop's last barrier freed the tile buffers
         {
             const f32x4* w2 = reinterpret_cast<const f32x4*>(p.w2);
@@ -925,6 +980,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 else store_rows(i2, acc2, Ep + 4 * BM, std::false_type{}, std::false_type{}, std::true_type{});
             }
         });
+        }
     }
     NC_TR();
 #ifdef NC_DBG_TRACE
@@ -1009,6 +1065,19 @@ inline conv_kernel_fn get_conv_kernel() {
             case 32: return get_conv_kernel<3, 2, KVAL, CBVAL, NXVAL, true>();                             \
             case 41: return get_conv_kernel<4, 1, KVAL, CBVAL, NXVAL, true>();                             \
             case 42: return get_conv_kernel<4, 2, KVAL, CBVAL, NXVAL, true>();                             \
+        }                                                                                                  \
+        return nullptr;                                                                                    \
+    }                                                                                                      \
+    }
+
+// Wide fused residual units (C = 192 / 256): the tile spans all channels at 128 columns (TM = 6 / 8, TN = 1), reduction block of 4
+// channels so two workgroups share a CU; W1 streamed through LDS by row block.
+#define NC_INSTANTIATE_CONV_FUSED_WIDE(KVAL, CBVAL, NXVAL)                                                 \
+    namespace nc {                                                                                         \
+    conv_kernel_fn conv_kernel_table_fusedw_k##KVAL(int TM, int TN) {                                      \
+        switch (TM * 10 + TN) {                                                                            \
+            case 61: return get_conv_kernel<6, 1, KVAL, CBVAL, NXVAL, true>();                             \
+            case 81: return get_conv_kernel<8, 1, KVAL, CBVAL, NXVAL, true>();                             \
         }                                                                                                  \
         return nullptr;                                                                                    \
     }                                                                                                      \

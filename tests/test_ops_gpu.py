@@ -65,7 +65,8 @@ def test_conv1d_fused_snake_residual_bit_exact():
     assert np.array_equal(y, y_ref)
 
 
-@pytest.mark.parametrize("C,T,d,B", [(64, 700, 1, 2), (96, 523, 3, 1), (128, 300, 9, 2), (64, 40, 9, 1)])
+@pytest.mark.parametrize("C,T,d,B", [(64, 700, 1, 2), (96, 523, 3, 1), (128, 300, 9, 2), (64, 40, 9, 1),
+                                     (192, 300, 1, 2), (192, 131, 9, 1), (256, 257, 3, 2), (256, 90, 9, 1)])   # wide units: W1 streamed
 def test_fused_res_unit_bit_exact(C, T, d, B):
     """Single-launch ResidualUnit (conv7 + Snake + 1x1 on the accumulators + skip) == oracle == two-launch path."""
     rng = np.random.default_rng(C + d)

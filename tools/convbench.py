@@ -67,8 +67,7 @@ def main():
         import numpy as np
         from neuralcodecs_amd import ops
         rng = np.random.default_rng(0)
-        for Cc, T in ((64, 44544), (128, 22272), (96, 44544)):
-            B = 8
+        for Cc, T, B in ((64, 44544, 8), (128, 22272, 8), (96, 44544, 8), (192, 22272, 16), (256, 5568, 32)):
             x = rng.standard_normal((B, Cc, T)).astype(np.float32)
             w7 = (rng.standard_normal((Cc, Cc, 7)) / np.sqrt(Cc * 7)).astype(np.float32); b7 = np.zeros(Cc, np.float32)
             w1 = (rng.standard_normal((Cc, Cc, 1)) / np.sqrt(Cc)).astype(np.float32); b1 = np.zeros(Cc, np.float32)
