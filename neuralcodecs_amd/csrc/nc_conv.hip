@@ -216,13 +216,14 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
         }
     // whole-channel tile of the wide fused residual units (C = 192 / 256 -> TM = 6 / 8; launched only through ConvIO::fuse_k1)
     static const bool no_wide_fuse = std::getenv("NC_NO_WIDE_FUSE") && std::getenv("NC_NO_WIDE_FUSE")[0] == '1';
-    if (!no_alts && !no_wide_fuse && !transposed && K == 7 && stride == 1 && Cin == Cout && (Cout == 192 || Cout == 256)) {
+    const bool wide_c = Cin == Cout && (Cout == 256 || Cout == 192);
+    if (!no_alts && !no_wide_fuse && !transposed && K == 7 && stride == 1 && wide_c) {
         alts.emplace_back(new Alt());
         alts.back()->cfg = cfg;
         alts.back()->cfg.TM = Cout / 32;
         pack(alts.back()->cfg, alts.back()->w, alts.back()->w_phase_stride);
     }
-    if (!transposed && K == 1 && Cin == Cout && Cin % 32 == 0 && (Cin <= 128 || ((Cin == 192 || Cin == 256) && !no_wide_fuse))) {
+    if (!transposed && K == 1 && Cin == Cout && Cin % 32 == 0 && (Cin <= 128 || (wide_c && !no_wide_fuse))) {
         // image for the fused residual-unit tail: [row block][ci][32 rows]
         std::vector<float> f((size_t)Cin * Cout);
         for (int i2 = 0; i2 < Cout / 32; ++i2)
@@ -430,7 +431,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     }
     // Flattened (clip, column) axis (kernel: "Flattened column axis"): when the rows are short or leave a good part of their last
     // tile on padding, the columns of all clips are cut into tiles as one axis.  Needs the one-launch forms (no per-phase launches),
-    // no per-clip scalars in the kernel (Encodec input mode -- measured: per-segment statistics through an LDS table made every
+    // no per-clip scalars in the kernel (a pending GroupNorm of the Encodec input mode -- measured: per-segment statistics through an LDS table made every
     // instance of the template ~5 % slower for 0.07 ms on C3 -- and noise rows), a window (tile + one halo per touched clip) that still fits
     // the staging registers, and 32-bit offsets that reach 3 clips ahead.
     bool flat = false;
@@ -447,7 +448,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
             const int xw = (BN - 1 + (S - 1) * hc) * sx0 + (L.Ktaps - 1) * ad0 + 1;
             return c.CB * ((xw + 63) / 64) <= 4 * nx_for_k(c.K);
         };
-        const bool cand = !no_flat && B > 1 && L.n_phase == 1 && !io.fuse_k1 && !in_mode && !(io.epi & EPI_NOISE) && Tq >= 32 && L.Cin * L.Ktaps >= 64 &&
+        const bool cand = !no_flat && B > 1 && L.n_phase == 1 && !io.fuse_k1 && !(in_mode & 1) && !(io.epi & EPI_NOISE) && Tq >= 32 && L.Cin * L.Ktaps >= 64 &&
                           3 * io.x_bstride + io.x_len < ((int64_t)1 << 32) &&
                           (int64_t)(c.BM() + 4) * io.y_cstride + Tout + 3 * io.y_bstride < ((int64_t)1 << 31) &&
                           (Tq + hc) * sx0 < (1 << 28);

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
             q = q < 0 ? -q : q;
             if (q >= p.in_Lz) q = 2 * (p.in_Lz - 1) - q;
             if (!((q >= 0) & (q < p.in_L))) okm &= ~(1u << i);
-            xg[i] = (unsigned)min(max(q, 0), p.in_L - 1);
+            xg[i] = (unsigned)min(sg, p.Bc - 1 - b) * (unsigned)p.x_bstride + (unsigned)min(max(q, 0), p.in_L - 1);
         }
     }
     auto issue_group_to = [&](int cbn, auto gtag, f32x4 (&ra)[GA], float (&rx)[GX]) __attribute__((always_inline)) {

@@ -182,7 +182,12 @@ float* DacModel::run_res_unit(ResUnit& ru, int dil, float* cur, int C, int64_t L
     ConvIO io{};
     io.x = cur; io.x_bstride = (int64_t)C * L; io.x_cstride = L; io.x_len = (int32_t)L; io.Tin = L;
     io.alpha_in = ru.a1.as<float>(); io.alpha_out = ru.a2.as<float>();
-    if (fuse_res_units && can_fuse_res_unit(ru.c7, ru.c1)) {
+    // Which units run as one launch: C <= 128 (the 1x1 weights stay in LDS) and C = 256 (whole-channel 128-column tile, W1 streamed:
+    // 1.79 ms against 1.88 ms in two launches).  At C = 192 the fused form only breaks even (2.00 against 2.02 ms per unit: the
+    // 96-row x 256-column tiles of the two-launch form are the most efficient instances of the template, 124 TFLOP/s), so it keeps
+    // the two launches unless NC_WIDE_FUSE_192=1.
+    static const bool wide_192 = std::getenv("NC_WIDE_FUSE_192") && std::getenv("NC_WIDE_FUSE_192")[0] == '1';
+    if (fuse_res_units && can_fuse_res_unit(ru.c7, ru.c1) && (C != 192 || wide_192)) {
         // one launch: y = x + W1.snake(conv7(snake(x)) + b7) + b1 ; h never reaches HBM
         io.res = cur; io.fuse_k1 = &ru.c1; io.alpha_out2 = alpha_next;
         io.y = o; io.y_bstride = (int64_t)C * L; io.y_cstride = L;

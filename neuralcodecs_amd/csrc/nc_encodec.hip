@@ -743,6 +743,9 @@ EncodecModel::~EncodecModel() {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (lstm_stream) (void)hipStreamDestroy(lstm_stream);
     for (hipEvent_t e : lstm_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ola_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ola_pin) (void)hipHostFree(ola_pin);
 }
 
 void EncodecModel::check_async_errors() {
@@ -1210,25 +1213,52 @@ void EncodecModel::decode_dev(const int64_t* codes, const float* scales, int B, 
     const int64_t stride = cfg.segment_stride, total = stride * (nfr - 1) + flen[(size_t)nfr - 1], L0 = flen[0];
     for (int f = 0; f < nfr; ++f)
         if (flen[(size_t)f] > L0) fail(NC_EINVAL, "a later frame is longer than the first one");
-    std::vector<float> w((size_t)L0), sw((size_t)total, 0.0f);
-    for (int64_t i = 0; i < L0; ++i) {
-        const float t = (float)((double)(i + 1) / (double)(L0 + 1));
-        w[(size_t)i] = 0.5f - std::fabs(t - 0.5f);
+    // window and weight sum: a function of the frame geometry alone -- computed once per geometry, kept on the device
+    std::vector<int64_t> key{L0, stride, (int64_t)nfr};
+    key.insert(key.end(), flen.begin(), flen.end());
+    if (key != ola_key) {
+        std::vector<float> w((size_t)L0), sw((size_t)total, 0.0f);
+        for (int64_t i = 0; i < L0; ++i) {
+            const float t = (float)((double)(i + 1) / (double)(L0 + 1));
+            w[(size_t)i] = 0.5f - std::fabs(t - 0.5f);
+        }
+        for (int f = 0; f < nfr; ++f)
+            for (int64_t i = 0; i < flen[(size_t)f]; ++i) sw[(size_t)(f * stride + i)] = sw[(size_t)(f * stride + i)] + w[(size_t)i];
+        float mn = INFINITY;
+        for (float v : sw) mn = std::min(mn, v);
+        if (mn <= 1e-10f) for (float& v : sw) v = v + 1e-10f;
+        NC_HIP(hipStreamSynchronize(stream));   // an earlier call may still read the old tables
+        ola_w.reserve((size_t)L0 * 4);
+        ola_sw.reserve((size_t)total * 4);
+        NC_HIP(hipMemcpy(ola_w.p, w.data(), (size_t)L0 * 4, hipMemcpyHostToDevice));
+        NC_HIP(hipMemcpy(ola_sw.p, sw.data(), (size_t)total * 4, hipMemcpyHostToDevice));
+        ola_key = key;
     }
-    for (int f = 0; f < nfr; ++f)
-        for (int64_t i = 0; i < flen[(size_t)f]; ++i) sw[(size_t)(f * stride + i)] = sw[(size_t)(f * stride + i)] + w[(size_t)i];
-    float mn = INFINITY;
-    for (float v : sw) mn = std::min(mn, v);
-    if (mn <= 1e-10f) for (float& v : sw) v = v + 1e-10f;
-    float* dw = alloc((size_t)L0);
-    float* dsw = alloc((size_t)total);
-    const float** dfp = reinterpret_cast<const float**>(alloc((size_t)nfr * 2));
-    int64_t* dfl = reinterpret_cast<int64_t*>(alloc((size_t)nfr * 2));
-    NC_HIP(hipMemcpyAsync(dw, w.data(), (size_t)L0 * 4, hipMemcpyHostToDevice, stream));
-    NC_HIP(hipMemcpyAsync(dsw, sw.data(), (size_t)total * 4, hipMemcpyHostToDevice, stream));
-    NC_HIP(hipMemcpyAsync(dfp, fp.data(), (size_t)nfr * sizeof(float*), hipMemcpyHostToDevice, stream));
-    NC_HIP(hipMemcpyAsync(dfl, flen.data(), (size_t)nfr * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-    NC_HIP(hipStreamSynchronize(stream));   // w / sw / fp / flen are stack-owned host vectors
+    const float* dw = ola_w.as<float>();
+    const float* dsw = ola_sw.as<float>();
+    // frame pointers / lengths of THIS call: pinned slot -> device arrays, asynchronously on the stream
+    const size_t need = (size_t)nfr * (sizeof(float*) + sizeof(int64_t));
+    if (need > ola_slot_bytes) {
+        NC_HIP(hipStreamSynchronize(stream));
+        if (ola_pin) NC_HIP(hipHostFree(ola_pin));
+        ola_pin = nullptr;
+        ola_slot_bytes = std::max<size_t>(1024, 2 * need);
+        NC_HIP(hipHostMalloc(&ola_pin, 4 * ola_slot_bytes, hipHostMallocDefault));
+        for (bool& u : ola_ev_used) u = false;
+    }
+    const int slot = ola_next;
+    ola_next = (ola_next + 1) & 3;
+    if (!ola_ev[slot]) NC_HIP(hipEventCreateWithFlags(&ola_ev[slot], hipEventDisableTiming));
+    if (ola_ev_used[slot]) NC_HIP(hipEventSynchronize(ola_ev[slot]));   // the copy that last read this slot (4 calls ago) is done
+    char* hs = static_cast<char*>(ola_pin) + (size_t)slot * ola_slot_bytes;
+    std::memcpy(hs, fp.data(), (size_t)nfr * sizeof(float*));
+    std::memcpy(hs + (size_t)nfr * sizeof(float*), flen.data(), (size_t)nfr * sizeof(int64_t));
+    char* dslot = reinterpret_cast<char*>(alloc((need + 3) / 4 + 4));
+    NC_HIP(hipMemcpyAsync(dslot, hs, need, hipMemcpyHostToDevice, stream));
+    NC_HIP(hipEventRecord(ola_ev[slot], stream));
+    ola_ev_used[slot] = true;
+    const float** dfp = reinterpret_cast<const float**>(dslot);
+    int64_t* dfl = reinterpret_cast<int64_t*>(dslot + (size_t)nfr * sizeof(float*));
     const int64_t n = (int64_t)B * C * total;
     hipLaunchKernelGGL(overlap_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dfp, dfl, nfr, L0, dw, dsw, (int64_t)B * C, stride,
                        total, pcm);

@@ -212,6 +212,15 @@ struct EncodecModel : Codec {
     // layer-pipelined LSTM (run_lstm): second stream for layer 1 and the chunk events; only the primary segment group pipelines
     hipStream_t lstm_stream = nullptr;
     std::vector<hipEvent_t> lstm_events;
+    // overlap-add operands (decode_dev): the window and the weight sum depend on the frame geometry only and stay on the device;
+    // the per-call frame pointers travel through a small ring of pinned host slots, so decode_dev never synchronises the stream
+    std::vector<int64_t> ola_key;
+    DevBuf ola_w, ola_sw;
+    void* ola_pin = nullptr;
+    size_t ola_slot_bytes = 0;
+    int ola_next = 0;
+    hipEvent_t ola_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ola_ev_used[4] = {false, false, false, false};
     bool on_side_group = false;
     ~EncodecModel() override;
 

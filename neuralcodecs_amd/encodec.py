@@ -208,11 +208,17 @@ class Encodec(_lib.ProfileMixin):
         if self.segment_length is None:
             return int(frames[0].codes.shape[-1]) * hop
         n = len(frames)
+        memo = self.__dict__.setdefault("_infer_memo", {})     # (frame count, tail frames) -> clip length: geometry only
+        mk = (n, int(frames[-1].codes.shape[-1]))
+        if mk in memo:
+            return memo[mk]
         # smallest clip length that yields n segments with the observed tail frame count
         base = (n - 1) * self.segment_stride
         want = int(frames[-1].codes.shape[-1])
         for tail in range(1, self.segment_length + 1):
-            if self.query(base + tail)[2][-1] == want and self.query(base + tail)[0] == n:
+            q = self.query(base + tail)
+            if q[2][-1] == want and q[0] == n:
+                memo[mk] = base + tail
                 return base + tail
         raise ValueError("cannot infer the clip length from the frames; pass length=")
 

@@ -106,6 +106,58 @@ def test_conv_transpose1d_bit_exact(cin, cout, s, T, B):
     assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
 
 
+# Flattened (clip, column) tile axis (launch_conv: short rows are cut into tiles as ONE axis over all clips, a tile touching up to 4
+# clips, each with its own halo in LDS).  Shapes whose rows are shorter than / not a multiple of the tile width, with enough clips that
+# tiles straddle 2, 3 and 4 clips, the last tile ends inside the last clip, and the clip count is not a multiple of anything.
+FLAT_CASES = [
+    # (Cin, Cout, K, stride, pad, dil, T, B, transposed)
+    (64, 96, 7, 1, 3, 1, 87, 9, False),       # 87-column rows: 256-wide tiles over 4 clips
+    (64, 64, 7, 1, 9, 3, 87, 5, False),       # dilation 3: halo 18 per segment
+    (32, 64, 7, 1, 27, 9, 150, 7, False),     # dilation 9 at 150 columns (128-wide tiles, 3 segments)
+    (48, 64, 3, 1, 1, 1, 50, 11, False),      # 50-column rows (4 segments per 128-wide tile)
+    (64, 128, 7, 1, 3, 1, 696, 3, False),     # 696 = 2.7 tiles of 256
+    (32, 64, 16, 8, 4, 1, 696, 5, False),     # strided down-conv: 87 output columns, phase-de-interleaved window per segment
+    (32, 64, 8, 4, 2, 1, 600, 6, False),      # stride 4, 150 columns
+    (64, 48, 16, 8, 4, 1, 87, 6, True),       # sub-pixel up-conv: 88 input columns per clip
+    (96, 32, 4, 2, 1, 1, 150, 7, True),       # stride 2
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,d,T,B,tr", FLAT_CASES)
+def test_flattened_column_axis_bit_exact(cin, cout, k, s, p, d, T, B, tr):
+    rng = np.random.default_rng(cin * 31 + cout + k + T)
+    x = _rand(rng, B, cin, T)
+    a = _alpha(rng, cin)
+    b = _rand(rng, cout, scale=0.1)
+    if tr:
+        w = _rand(rng, cin, cout, k, scale=1.0 / np.sqrt(cin * 2))
+        want = c_oracle.conv_transpose1d(c_oracle.snake(x, a), w, b, s, p)
+        got = ops.conv1d(x, w, b, s, p, 1, alpha_in=a, transposed=True)
+    else:
+        w = _rand(rng, cout, cin, k, scale=1.0 / np.sqrt(cin * k))
+        want = c_oracle.conv1d(c_oracle.snake(x, a), w, b, s, p, d)
+        got = ops.conv1d(x, w, b, s, p, d, alpha_in=a)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+    # every clip is computed independently of its neighbours in the tile: permuting the clips permutes the output
+    perm = rng.permutation(B)
+    got_p = ops.conv1d(x[perm], w, b, s, p, 1 if tr else d, alpha_in=a, transposed=tr)
+    assert np.array_equal(got_p, want[perm])
+
+
+def test_flattened_column_axis_residual_and_snake_epilogues():
+    """Stride-1 k=7 over 87-column rows with the residual / next-Snake epilogues (the full-tile straight-line path and edge tiles)."""
+    rng = np.random.default_rng(77)
+    B, C, T, d = 10, 96, 87, 3
+    x = _rand(rng, B, C, T, scale=1.5)
+    a1, a2 = _alpha(rng, C), _alpha(rng, C)
+    w = _rand(rng, C, C, 7, scale=1.0 / np.sqrt(C * 7)); b = _rand(rng, C, scale=0.1)
+    res = _rand(rng, B, C, T)
+    want = c_oracle.snake(c_oracle.conv1d(c_oracle.snake(x, a1), w, b, 1, 3 * d, d, residual=res), a2)
+    got = ops.conv1d(x, w, b, 1, 3 * d, d, alpha_in=a1, alpha_out=a2, residual=res)
+    assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+
+
 @pytest.mark.parametrize("N,D,T,B", [(1024, 8, 87, 4), (64, 8, 7, 2), (4096, 8, 100, 1)])
 def test_vq_argmin_bit_exact(N, D, T, B):
     rng = np.random.default_rng(N)
