@@ -4,6 +4,7 @@
 // one workgroup = 1024 output steps of one clip, CC input channels at a time staged in LDS (coalesced 16-byte reads, zero padding by
 // predicate), each thread 4 consecutive outputs x all output channels with the weights in scalar registers.
 // Arithmetic per output = the canonical chain: fmaf over kk = ci*K + k ascending from +0, then + bias, then tanh.
+#include <cstdlib>
 #include <type_traits>
 
 #include "nc_conv.h"
@@ -16,7 +17,9 @@ typedef float thin_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int THIN_TILE = 1024;   // output steps per workgroup
 constexpr int THIN_CC = 8;        // input channels staged per round
 
-template <int COUT, int K>
+// VEC: the window starts at a 16-byte boundary of the row (sh = 0..3 slots before position t0 - pad) and is read with 16-byte
+// vector loads (2 per thread and channel instead of 5 dword reads); needs 16-byte aligned rows whose length is a multiple of 4.
+template <int COUT, int K, bool VEC>
 __global__ __launch_bounds__(256) void conv_thin_kernel(const float* __restrict__ x, int64_t x_bstride, int64_t x_cstride, int Cin, int x_len,
                                                         const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
                                                         int64_t y_bstride, int64_t y_cstride, int Tout, int pad, int dil, int n_t_tiles, int tanh_out) {
@@ -27,7 +30,8 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const float* __restrict_
     const int halo = (K - 1) * dil;
     const int row = (THIN_TILE + halo + 3 + 4) & ~3;
     const float* xb = x + (int64_t)b * x_bstride;
-    const int g0 = t0 - pad;              // input position of window slot 0
+    const int sh = VEC ? ((4 - (pad & 3)) & 3) : 0;
+    const int g0 = t0 - pad - sh;         // input position of window slot 0 (VEC: a multiple of 4)
 
     float acc[COUT][4];
 #pragma unroll
@@ -36,8 +40,47 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const float* __restrict_
         for (int o = 0; o < 4; ++o) acc[c][o] = 0.0f;
 
     constexpr int NJ = 5;                 // window slots per thread per channel row (row <= 1280)
+    // VEC: the reads of round r+1 are issued before the arithmetic of round r and land under it (registers carry them across)
+    constexpr int NQ = 2;
+    thin_f32x4 rq[VEC ? THIN_CC : 1][NQ];
+    const int nwords = row >> 2, xw4 = x_len >> 2;
+    auto issue_round = [&](int c0) __attribute__((always_inline)) {
+        if constexpr (VEC) {
+            // 16-byte words: word tid and (lanes 0..3: the halo) word 256 + tid of every channel row, all in flight together
+#pragma unroll
+            for (int c = 0; c < THIN_CC; ++c) {
+                const thin_f32x4* xr = reinterpret_cast<const thin_f32x4*>(xb + (int64_t)min(c0 + c, Cin - 1) * x_cstride);
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) {
+                    const int wq = (g0 >> 2) + tid + 256 * u;        // g0 is a multiple of 4 (arithmetic shift: floor)
+                    rq[c][u] = thin_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    if (u == 0 || tid + 256 * u < nwords) rq[c][u] = xr[min(max(wq, 0), xw4 - 1)];   // clamped: always in bounds
+                }
+            }
+        }
+    };
+    issue_round(0);
     for (int c0 = 0; c0 < Cin; c0 += THIN_CC) {
         const int nc = min(THIN_CC, Cin - c0);
+        if constexpr (VEC) {
+#pragma unroll
+            for (int c = 0; c < THIN_CC; ++c)
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) {
+                    const int wq = (g0 >> 2) + tid + 256 * u;
+                    if (wq < 0 || wq >= xw4) rq[c][u] = thin_f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // (x_len % 4 == 0: words are all-in or all-out)
+                }
+            __syncthreads();   // the previous round's arithmetic has finished reading the window
+#pragma unroll
+            for (int c = 0; c < THIN_CC; ++c)
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) {
+                    const int j = tid + 256 * u;
+                    if (j < nwords) reinterpret_cast<thin_f32x4*>(xs + c * row)[j] = rq[c][u];
+                }
+            __syncthreads();
+            if (c0 + THIN_CC < Cin) issue_round(c0 + THIN_CC);
+        } else {
         // all reads of the round are issued before the first LDS store (a store between them would serialise the round trips)
         float r[THIN_CC][NJ];
 #pragma unroll
@@ -64,6 +107,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const float* __restrict_
                 if (j < row) xs[c * row + j] = r[c][u];
             }
         __syncthreads();
+        }
         for (int c = 0; c < nc; ++c) {
             const float* xl = xs + c * row + 4 * tid;
             float wv[COUT][K];
@@ -73,7 +117,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const float* __restrict_
                 for (int k = 0; k < K; ++k) wv[co][k] = w[((int64_t)co * Cin + (c0 + c)) * K + k];   // uniform: scalar loads
             if (dil == 1) {
                 // the 4 outputs of this thread read window slots [4*tid, 4*tid + K + 3): whole 16-byte words
-                constexpr int NV = (K + 3 + 3) / 4;
+                constexpr int NV = (K + 3 + 3 + (VEC ? 3 : 0)) / 4;   // (VEC: up to 3 slots of alignment shift)
                 float xw[4 * NV];
 #pragma unroll
                 for (int q = 0; q < NV; ++q) {
@@ -85,13 +129,13 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const float* __restrict_
 #pragma unroll
                     for (int co = 0; co < COUT; ++co)
 #pragma unroll
-                        for (int o = 0; o < 4; ++o) acc[co][o] = fmaf(wv[co][k], xw[k + o], acc[co][o]);
+                        for (int o = 0; o < 4; ++o) acc[co][o] = fmaf(wv[co][k], xw[k + o + sh], acc[co][o]);
             } else {
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     float xv[4];
 #pragma unroll
-                    for (int o = 0; o < 4; ++o) xv[o] = xl[k * dil + o];
+                    for (int o = 0; o < 4; ++o) xv[o] = xl[k * dil + o + sh];
 #pragma unroll
                     for (int co = 0; co < COUT; ++co)
 #pragma unroll
@@ -115,12 +159,15 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const float* __restrict_
 }
 
 template <int COUT>
-static bool launch_thin_k(int K, dim3 grid, size_t lds, hipStream_t s, const float* x, int64_t xb, int64_t xc, int Cin, int x_len, const float* w,
+static bool launch_thin_k(int K, bool vec, dim3 grid, size_t lds, hipStream_t s, const float* x, int64_t xb, int64_t xc, int Cin, int x_len, const float* w,
                           const float* bias, float* y, int64_t yb, int64_t yc, int Tout, int pad, int dil, int ntt, int tanh_out) {
     switch (K) {
-        case 7: hipLaunchKernelGGL((conv_thin_kernel<COUT, 7>), grid, dim3(256), lds, s, x, xb, xc, Cin, x_len, w, bias, y, yb, yc, Tout, pad, dil, ntt, tanh_out); return true;
-        case 3: hipLaunchKernelGGL((conv_thin_kernel<COUT, 3>), grid, dim3(256), lds, s, x, xb, xc, Cin, x_len, w, bias, y, yb, yc, Tout, pad, dil, ntt, tanh_out); return true;
-        case 1: hipLaunchKernelGGL((conv_thin_kernel<COUT, 1>), grid, dim3(256), lds, s, x, xb, xc, Cin, x_len, w, bias, y, yb, yc, Tout, pad, dil, ntt, tanh_out); return true;
+        case 7:
+            if (vec) hipLaunchKernelGGL((conv_thin_kernel<COUT, 7, true>), grid, dim3(256), lds, s, x, xb, xc, Cin, x_len, w, bias, y, yb, yc, Tout, pad, dil, ntt, tanh_out);
+            else hipLaunchKernelGGL((conv_thin_kernel<COUT, 7, false>), grid, dim3(256), lds, s, x, xb, xc, Cin, x_len, w, bias, y, yb, yc, Tout, pad, dil, ntt, tanh_out);
+            return true;
+        case 3: hipLaunchKernelGGL((conv_thin_kernel<COUT, 3, false>), grid, dim3(256), lds, s, x, xb, xc, Cin, x_len, w, bias, y, yb, yc, Tout, pad, dil, ntt, tanh_out); return true;
+        case 1: hipLaunchKernelGGL((conv_thin_kernel<COUT, 1, false>), grid, dim3(256), lds, s, x, xb, xc, Cin, x_len, w, bias, y, yb, yc, Tout, pad, dil, ntt, tanh_out); return true;
     }
     return false;
 }
@@ -130,14 +177,18 @@ bool launch_conv_thin(const float* x, int64_t x_bstride, int64_t x_cstride, int 
                       int64_t y_bstride, int64_t y_cstride, int B, int Cout, int K, int pad, int dil, int64_t Tout, bool tanh_out, hipStream_t s) {
     if (Cout < 1 || Cout > 2 || (K != 7 && K != 3 && K != 1) || Tout <= 0) return false;
     const int halo = (K - 1) * dil;
-    const int row = (THIN_TILE + halo + 3 + 4) & ~3;   // + one spare 16-byte word for the whole-word reads
+    const int row = (THIN_TILE + halo + 3 + 3 + 4) & ~3;   // + up to 3 slots of alignment shift + one spare 16-byte word for the whole-word reads
     if (row > 1280) return false;
+    // 16-byte window reads: k = 7, dilation 1 (the PCM heads), rows that start on 16-byte boundaries and hold whole 16-byte words
+    static const bool no_vec = std::getenv("NC_THIN_NO_VEC") != nullptr;
+    const bool vec = !no_vec && K == 7 && dil == 1 && (x_len & 3) == 0 && x_len >= 4 && (x_bstride & 3) == 0 && (x_cstride & 3) == 0 &&
+                     (reinterpret_cast<uintptr_t>(x) & 15) == 0 && row <= 4 * 512;
     const size_t lds = sizeof(float) * (size_t)THIN_CC * row;
     if (lds > 64 * 1024) return false;
     const int ntt = (int)((Tout + THIN_TILE - 1) / THIN_TILE);
     const dim3 grid((unsigned)(B * ntt));
-    bool ok = Cout == 1 ? launch_thin_k<1>(K, grid, lds, s, x, x_bstride, x_cstride, Cin, x_len, w_dense, bias, y, y_bstride, y_cstride, (int)Tout, pad, dil, ntt, tanh_out)
-                        : launch_thin_k<2>(K, grid, lds, s, x, x_bstride, x_cstride, Cin, x_len, w_dense, bias, y, y_bstride, y_cstride, (int)Tout, pad, dil, ntt, tanh_out);
+    bool ok = Cout == 1 ? launch_thin_k<1>(K, vec, grid, lds, s, x, x_bstride, x_cstride, Cin, x_len, w_dense, bias, y, y_bstride, y_cstride, (int)Tout, pad, dil, ntt, tanh_out)
+                        : launch_thin_k<2>(K, vec, grid, lds, s, x, x_bstride, x_cstride, Cin, x_len, w_dense, bias, y, y_bstride, y_cstride, (int)Tout, pad, dil, ntt, tanh_out);
     if (ok) NC_HIP(hipGetLastError());
     return ok;
 }
