@@ -490,6 +490,125 @@ __global__ __launch_bounds__(256) void euclid_vq_kernel(float* __restrict__ resi
     }
 }
 
+// All n_q stages of the Euclidean RVQ for a block of 32 frames in ONE launch, cross terms on the matrix cores
+// (ResidualVectorQuantizer.cs:139-156 over EuclideanCodebook.cs:155-182).  Same arithmetic as euclid_vq_kernel, operation for
+// operation: cr_n = fma chain over d ascending from +0 of e_d * c_{n,d} -- which is what a chain of v_mfma_f32_32x32x2_f32 over
+// k = d computes for output (row n, column frame) -- then dist_n = (|e|^2 + |c_n|^2) - 2 * cr_n, argmin with the lowest index on
+// ties, residual -= embed[idx].  Rows = codes (A fragments straight from the transposed codebook [D][N]: 32 consecutive codes per
+// lane half, L2-resident), columns = frames (B fragments from the residual block in LDS, [d][frame]); wave w scans codes
+// [w*N/4, (w+1)*N/4) 128 codes at a time (four independent accumulation chains; row l of tile i = code 4 l + i, so a lane's four A
+// values per k are one 16-byte load), the reads two groups of steps ahead of the matrix cores.  The residual block never leaves LDS between
+// the stages.  8 launches of 63-90 us (600 workgroups re-streaming the 512 KB codebook each) become one of ~0.2 ms on C3.
+constexpr int EM_F = 32, EM_MAXD = 128;
+typedef float em_f32x16 __attribute__((ext_vector_type(16)));
+typedef float em_f32x4 __attribute__((ext_vector_type(4)));
+template <int DD>
+__global__ __launch_bounds__(256) void euclid_rvq_mfma_kernel(const float* __restrict__ residual, const float* const* __restrict__ cbT_ptrs,
+                                                              const float* const* __restrict__ cb_ptrs, const float* const* __restrict__ c2_ptrs,
+                                                              int n_q, int N, int B, int64_t T, int64_t* __restrict__ codes,
+                                                              int64_t codes_bstride) {
+    constexpr int D = DD;
+    __shared__ float es[EM_MAXD][EM_F];   // residual block [d][frame]: lane (frame, k half) of a B fragment reads es[2kp + half][frame]
+    __shared__ float e2s[EM_F];
+    __shared__ float bd[4][EM_F];
+    __shared__ int bi[4][EM_F];
+    __shared__ int win[EM_F];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int64_t f0 = (int64_t)blockIdx.x * EM_F, total = (int64_t)B * T;
+    for (int i = tid; i < EM_F * D; i += 256) {
+        const int d = i >> 5, f = i & 31;
+        const int64_t fr = f0 + f;
+        float v = 0.0f;
+        if (fr < total) { const int64_t b = fr / T, t = fr - b * T; v = residual[(b * D + d) * T + t]; }
+        es[d][f] = v;
+    }
+    const int npw = N >> 2;                  // codes per wave (a multiple of 32)
+    for (int q = 0; q < n_q; ++q) {
+        const float* __restrict__ cbT = cbT_ptrs[q];
+        const float* __restrict__ cb = cb_ptrs[q];
+        const float* __restrict__ c2 = c2_ptrs[q];
+        __syncthreads();                     // es holds the residual entering this stage
+        if (tid < EM_F) {
+            float a = 0.0f;
+            for (int d = 0; d < D; ++d) a = nc_fma(es[d][tid], es[d][tid], a);
+            e2s[tid] = a;
+        }
+        __syncthreads();
+        const float e2 = e2s[l31];
+        float best = __builtin_inff();
+        int besti = 0x7fffffff;
+        for (int n0 = wave * npw; n0 < (wave + 1) * npw; n0 += 128) {
+            // 128 codes per pass as four row tiles; row l of tile i is code n0 + 4 l + i, so the four A values a lane needs for one k
+            // are four consecutive codes of the transposed codebook: ONE 16-byte load, 512 contiguous bytes per lane half
+            em_f32x16 acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+            // (the stage's pointers come out of a pointer table: say that they are global memory, or the reads are issued as flat
+            // loads, which count against the LDS counter too and serialise with the B-fragment reads)
+            typedef __attribute__((address_space(1))) const em_f32x4* em_gp4;
+            const em_gp4 ap = (em_gp4)(cbT + (int64_t)hi * N + n0 + 4 * l31);   // k = hi at kp = 0
+            const int64_t kstride = (int64_t)2 * N / 4;                    // float4 words per MFMA step (two codebook rows)
+            constexpr int G = 8, NG = DD / 2 / G;                          // MFMA steps per group, groups per pass
+            em_f32x4 av[3][G];                                             // ring: the reads run two groups ahead of the matrix cores
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int u = 0; u < G; ++u) av[g][u] = ap[(int64_t)(g * G + u) * kstride];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 2 < NG) {
+#pragma unroll
+                    for (int u = 0; u < G; ++u) av[(g + 2) % 3][u] = ap[(int64_t)((g + 2) * G + u) * kstride];
+                }
+                __builtin_amdgcn_sched_barrier(0);   // the reads of group g+2 stay ahead of the matrix-core steps of group g
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const float bv = es[2 * (g * G + u) + hi][l31];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g % 3][u][i], bv, acc[i], 0, 0, 0);
+                }
+            }
+            // D[row = (r & 3) + 8 (r >> 2) + 4 hi][column = l31]; lowest index on ties (codes are not visited in ascending order)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nb = n0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * hi);
+                const em_f32x4 cc = *(em_gp4)(c2 + nb);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float dist = (e2 + cc[i]) - 2.0f * acc[i][r];
+                    if (dist < best || (dist == best && nb + i < besti)) { best = dist; besti = nb + i; }
+                }
+            }
+        }
+        {   // the two lane halves hold the same frame; then the four waves meet in LDS
+            const float od = __shfl_xor(best, 32, 64);
+            const int oi = __shfl_xor(besti, 32, 64);
+            if (od < best || (od == best && oi < besti)) { best = od; besti = oi; }
+            if (hi == 0) { bd[wave][l31] = best; bi[wave][l31] = besti; }
+        }
+        __syncthreads();
+        if (tid < EM_F) {
+            float d0 = bd[0][tid];
+            int i0 = bi[0][tid];
+            for (int w = 1; w < 4; ++w)
+                if (bd[w][tid] < d0 || (bd[w][tid] == d0 && bi[w][tid] < i0)) { d0 = bd[w][tid]; i0 = bi[w][tid]; }
+            if (i0 == 0x7fffffff) i0 = 0;
+            win[tid] = i0;
+            const int64_t fr = f0 + tid;
+            if (fr < total) { const int64_t b = fr / T, t = fr - b * T; codes[b * codes_bstride + (int64_t)q * T + t] = (int64_t)i0; }
+        }
+        __syncthreads();
+        for (int i = tid; i < EM_F * D; i += 256) {       // residual -= embed[idx]: 8 threads per frame walk its code vector
+            const int f = i / D, d = i - f * D;
+            es[d][f] = es[d][f] - ((__attribute__((address_space(1))) const float*)cb)[(int64_t)win[f] * D + d];
+        }
+    }
+}
+
 // ResidualVectorQuantizer.Decode (:107-124): emb = ((0 + e_0[idx_0]) + e_1[idx_1]) + ...
 __global__ void emb_sum_kernel(const int64_t* __restrict__ codes, const float* const* __restrict__ cbs, int n_q, int N, int D, int B,
                                int64_t T, float* __restrict__ emb) {
@@ -708,6 +827,14 @@ void EncodecModel::load(const Blob& b) {
     }
     book_ptrs.reserve(ptrs.size() * sizeof(float*));
     NC_HIP(hipMemcpy(book_ptrs.p, ptrs.data(), ptrs.size() * sizeof(float*), hipMemcpyHostToDevice));
+    {   // transposed codebooks and squared norms of all stages, for the stage-fused RVQ kernel
+        std::vector<const float*> pt, p2;
+        for (auto& bk : books) { pt.push_back(bk->cbT.as<float>()); p2.push_back(bk->c2.as<float>()); }
+        book_ptrsT.reserve(pt.size() * sizeof(float*));
+        book_ptrs2.reserve(p2.size() * sizeof(float*));
+        NC_HIP(hipMemcpy(book_ptrsT.p, pt.data(), pt.size() * sizeof(float*), hipMemcpyHostToDevice));
+        NC_HIP(hipMemcpy(book_ptrs2.p, p2.data(), p2.size() * sizeof(float*), hipMemcpyHostToDevice));
+    }
     load_sconv(b, "decoder.layers.0", dec_in, cfg.dimension, mult * nf, cfg.kernel_size, 1, false);
     load_lstm(b, "decoder.layers.1", dec_lstm, mult * nf);
     n = 2;
@@ -1070,10 +1197,19 @@ void EncodecModel::encode_batch(const float* x, int N, int64_t L, int64_t Tz, in
     if (emb_out) NC_HIP(hipMemcpyAsync(emb_out, residual, (size_t)N * D * Tz * 4, hipMemcpyDeviceToDevice, stream));
     const int64_t total = (int64_t)N * Tz;
     if (prof.on) prof.begin(stream, NC_KC_RVQ, 3.0 * 2.0 * D * cfg.codebook_size * (double)total * n_q, 0.0);
-    for (int q = 0; q < n_q; ++q) {
-        Codebook& cb = *books[q];
-        hipLaunchKernelGGL(euclid_vq_kernel, dim3((unsigned)((total + EQ_F - 1) / EQ_F)), dim3(256), 0, stream, residual, cb.cbT.as<float>(),
-                           cb.cb.as<float>(), cb.c2.as<float>(), cb.N, D, N, Tz, codes + (int64_t)q * Tz, (int64_t)n_q * Tz);
+    static const bool no_mfma_vq = std::getenv("NC_EUCLID_NO_MFMA") != nullptr;
+    const int Nc = cfg.codebook_size;
+    if (!no_mfma_vq && Nc % 512 == 0 && D == 128) {
+        // all stages in one launch, cross terms on the matrix cores (the residual block stays in LDS between the stages)
+        hipLaunchKernelGGL(euclid_rvq_mfma_kernel<128>, dim3((unsigned)((total + EM_F - 1) / EM_F)), dim3(256), 0, stream, residual,
+                           book_ptrsT.as<const float*>(), book_ptrs.as<const float*>(), book_ptrs2.as<const float*>(), n_q, Nc, N, Tz, codes,
+                           (int64_t)n_q * Tz);
+    } else {
+        for (int q = 0; q < n_q; ++q) {
+            Codebook& cb = *books[q];
+            hipLaunchKernelGGL(euclid_vq_kernel, dim3((unsigned)((total + EQ_F - 1) / EQ_F)), dim3(256), 0, stream, residual, cb.cbT.as<float>(),
+                               cb.cb.as<float>(), cb.c2.as<float>(), cb.N, D, N, Tz, codes + (int64_t)q * Tz, (int64_t)n_q * Tz);
+        }
     }
     NC_HIP(hipGetLastError());
     if (prof.on) prof.end(stream);

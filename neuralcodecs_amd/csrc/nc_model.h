@@ -199,7 +199,7 @@ struct EncodecModel : Codec {
     ResBlock enc_res[8], dec_res[8];
     Lstm enc_lstm, dec_lstm;
     std::vector<std::unique_ptr<Codebook>> books;
-    DevBuf book_ptrs;
+    DevBuf book_ptrs, book_ptrsT, book_ptrs2;   // per stage: codebook [N][D], its transpose [D][N], squared norms [N] (device pointer arrays)
 
     std::vector<std::unique_ptr<DevBuf>> pool;   // per-call intermediates, same allocation order every call (grow-only)
     size_t pool_i = 0;
