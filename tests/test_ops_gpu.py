@@ -145,6 +145,53 @@ def test_flattened_column_axis_bit_exact(cin, cout, k, s, p, d, T, B, tr):
     assert np.array_equal(got_p, want[perm])
 
 
+def _random_conv_shapes(n, seed):
+    """Seeded random layer shapes around the tiling decisions: short rows x many clips (flattened axis, 2-4 segments per tile), rows
+    just above / below the tile widths, every kernel size the models use, strided and transposed forms, ragged channel counts."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        kind = rng.choice(["s1", "strided", "up"])
+        B = int(rng.integers(1, 12))
+        if kind == "s1":
+            k = int(rng.choice([1, 3, 7])); d = int(rng.choice([1, 3, 9])) if k == 7 else 1
+            s, p, tr = 1, d * (k - 1) // 2, False
+            T = int(rng.choice([rng.integers(33, 200), rng.integers(250, 300), rng.integers(500, 800)]))
+        elif kind == "strided":
+            s = int(rng.choice([2, 4, 5, 8])); k, d, tr = 2 * s, 1, False
+            p = (s + 1) // 2
+            T = int(rng.integers(40, 160)) * s + int(rng.integers(0, s))
+        else:
+            s = int(rng.choice([2, 4, 8])); k, d, tr = 2 * s, 1, True
+            p = (s + 1) // 2
+            T = int(rng.integers(33, 180))
+        cin = int(rng.choice([8, 24, 32, 48, 64, 96, 160])); cout = int(rng.choice([16, 32, 40, 64, 96, 128, 192]))
+        if tr and (cout * s) % 32:
+            cout = 32
+        out.append((cin, cout, k, s, p, d, T, B, bool(tr)))
+    return out
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,d,T,B,tr", _random_conv_shapes(36, seed=20260102))
+def test_conv1d_random_shapes_bit_exact(cin, cout, k, s, p, d, T, B, tr):
+    rng = np.random.default_rng(cin + 7 * cout + 13 * k + T + B)
+    x = _rand(rng, B, cin, T)
+    a = _alpha(rng, cin) if rng.random() < 0.5 else None
+    b = _rand(rng, cout, scale=0.1)
+    xin = c_oracle.snake(x, a) if a is not None else x
+    if tr:
+        w = _rand(rng, cin, cout, k, scale=1.0 / np.sqrt(cin * 2))
+        want = c_oracle.conv_transpose1d(xin, w, b, s, p)
+        got = ops.conv1d(x, w, b, s, p, 1, alpha_in=a, transposed=True)
+    else:
+        w = _rand(rng, cout, cin, k, scale=1.0 / np.sqrt(cin * k))
+        res = _rand(rng, *c_oracle.conv1d(xin, w, b, s, p, d).shape) if rng.random() < 0.4 else None
+        want = c_oracle.conv1d(xin, w, b, s, p, d, residual=res)
+        got = ops.conv1d(x, w, b, s, p, d, alpha_in=a, residual=res)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+
+
 def test_flattened_column_axis_residual_and_snake_epilogues():
     """Stride-1 k=7 over 87-column rows with the residual / next-Snake epilogues (the full-tile straight-line path and edge tiles)."""
     rng = np.random.default_rng(77)
