@@ -469,6 +469,25 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
             }
         }
     }
+    {   // Small grids of small layers: two 128-column tiles instead of one 256-column tile when that fills the chip better (the
+        // latency-bound layers of the 1-clip / 150-frame configurations: C1 2.93 -> 2.66 ms, C3 11.66 -> 11.43 ms, Encodec 24 kHz
+        // 7.05 -> 6.83 ms).  Only where the whole weight set is a few MB: the deep DAC layers stream 16-75 MB of weights per launch and
+        // a 128-column tile re-reads them twice as often -- there the same switch LOSES 8-23 % (C = 768 k=7 1.74 -> 1.88 ms, up-conv
+        // 1536->768 1.31 -> 1.62 ms) although the round count says otherwise.
+        static const bool no_tn_rounds = std::getenv("NC_NO_TN_ROUNDS") && std::getenv("NC_NO_TN_ROUNDS")[0] == '1';
+        if (!no_tn_rounds && c.TN == 2 && !io.fuse_k1 && !narrow && c.TM <= 4) {
+            static const int bpc_gen[5] = {0, 4, 3, 2, 2};
+            const double slots = 256.0 * bpc_gen[c.TM];
+            const int64_t n_co = (L.rows() + c.BM() - 1) / c.BM();
+            auto ntiles = [&](int64_t bn) { return flat ? ((int64_t)B * n_cols_all + bn - 1) / bn : (int64_t)B * ((n_cols_all + bn - 1) / bn); };
+            const double r2 = std::ceil((double)(L.n_phase * n_co * ntiles(256)) / slots), r1 = std::ceil((double)(L.n_phase * n_co * ntiles(128)) / slots);
+            const double w_bytes = 4.0 * L.rows() * (double)L.Cin * L.Ktaps;
+            if (r2 <= 3 && r1 * 1.08 < 2.0 * r2 && w_bytes <= 4.0 * 1024 * 1024) {
+                c.TN = 1;
+                if (flat) flat_S = (int)((128 - 2) / n_cols_all) + 2;
+            }
+        }
+    }
     // light variant (reduction block of 4 channels, 3 workgroups per CU): same packed weights when Cin is a multiple of 8
     int nx = nx_for_k(c.K);
     bool light = false;
