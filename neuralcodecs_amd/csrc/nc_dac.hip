@@ -9,6 +9,7 @@
 //   launch 2: conv k1         [bias | + x residual]
 // so no activation makes an HBM round trip of its own.
 #include <cstdlib>
+#include <cstring>
 
 #include "nc_model.h"
 
@@ -134,6 +135,43 @@ void DacModel::load(const Blob& b) {
         if (cb.dims.size() != 2 || cb.dims[0] != cfg.codebook_size || cb.dims[1] != cfg.codebook_dim)
             fail(NC_EINVAL, "%s.codebook.weight has the wrong shape", p.c_str());
         codebooks.back()->build(static_cast<const float*>(cb.data), cfg.codebook_size, cfg.codebook_dim);
+    }
+    {   // dense projection weights of every stage for the stage-fused quantizer (same folded values as the packed images)
+        const int D = cfg.codebook_dim;
+        rvq_dense.clear();
+        std::vector<RvqStage> tab((size_t)cfg.n_codebooks);
+        auto dense = [&](const std::string& prefix, int64_t d0, int64_t inner, bool transpose, const float** w_dev, const float** b_dev, int64_t nb) {
+            const BlobTensor& v = b.get(prefix + ".weight_v");
+            const BlobTensor& g = b.get(prefix + ".weight_g");
+            const BlobTensor* bias = b.find(prefix + ".bias");
+            std::vector<float> w((size_t)(d0 * inner)), wt;
+            fold_weight_norm_dac(static_cast<const float*>(v.data), static_cast<const float*>(g.data), d0, inner, w.data());
+            if (transpose) {
+                wt.resize(w.size());
+                for (int64_t r = 0; r < d0; ++r)
+                    for (int64_t c = 0; c < inner; ++c) wt[(size_t)(c * d0 + r)] = w[(size_t)(r * inner + c)];
+            }
+            rvq_dense.emplace_back(new DevBuf());
+            upload(*rvq_dense.back(), transpose ? wt.data() : w.data(), w.size());
+            *w_dev = rvq_dense.back()->as<float>();
+            std::vector<float> bz((size_t)nb, 0.0f);
+            if (bias) std::memcpy(bz.data(), bias->data, (size_t)nb * sizeof(float));
+            rvq_dense.emplace_back(new DevBuf());
+            upload(*rvq_dense.back(), bz.data(), bz.size());
+            *b_dev = rvq_dense.back()->as<float>();
+        };
+        for (int i = 0; i < cfg.n_codebooks; ++i) {
+            snprintf(nm, sizeof nm, "quantizer.quantizers.%d", i);
+            const std::string p = nm;
+            RvqStage& t = tab[(size_t)i];
+            dense(p + ".in_proj", D, latent, true, &t.w_inT, &t.b_in, D);          // [D][latent] -> [latent][D]
+            dense(p + ".out_proj", latent, D, false, &t.w_out, &t.b_out, latent);  // [latent][D]
+            t.cbT = codebooks[(size_t)i]->cbT.as<float>();
+            t.c2 = codebooks[(size_t)i]->c2.as<float>();
+            t.cb = codebooks[(size_t)i]->cb.as<float>();
+        }
+        rvq_stages.reserve(tab.size() * sizeof(RvqStage));
+        NC_HIP(hipMemcpy(rvq_stages.p, tab.data(), tab.size() * sizeof(RvqStage), hipMemcpyHostToDevice));
     }
 
     int ch = cfg.decoder_dim;
@@ -272,6 +310,7 @@ void DacModel::encode_dev(const float* pcm, int B, int64_t T, int sample_rate, i
     // ---- residual vector quantizer (ResidualVectorQuantizer.cs:54-103)
     float* zq_d = z ? z : zq.as<float>();
     float* lat_d = latents ? latents : lat.as<float>();
+    if (launch_dac_rvq_fused(rvq_stages.as<RvqStage>(), nq, latent, D, cfg.codebook_size, residual, B, Tz, codes, zq_d, lat_d, stream, &prof)) return;
     NC_HIP(hipMemsetAsync(zq_d, 0, (size_t)B * latent * Tz * 4, stream));
     for (int i = 0; i < nq; ++i) {
         ConvIO pi{};  // in_proj 1x1: residual -> z_e, stored as channel slice i of `latents`

@@ -21,6 +21,21 @@ struct Codebook {
     DevBuf c2;   // [N] squared norms (canonical fma chain, computed once on the host)
     void build(const float* host_cb, int N, int D);
 };
+// One stage of the stage-fused DAC quantizer (nc_rvq.hip): dense projection weights beside the codebook images, all device pointers.
+struct RvqStage {
+    const float* w_inT;   // [latent][D]  in_proj weight, transposed (folded weight norm)
+    const float* b_in;    // [D]
+    const float* w_out;   // [latent][D]  out_proj weight
+    const float* b_out;   // [latent]
+    const float* cbT;     // [D][N]
+    const float* c2;      // [N]
+    const float* cb;      // [N][D]
+};
+// ResidualVectorQuantizer.forward for n_q stages in ONE launch (ResidualVectorQuantizer.cs:54-103); returns false when the shape has
+// no instantiation (the caller then runs the stage-by-stage launches).  residual [B,L,T] (read only), zq [B,L,T], latents
+// [B,n_q*D,T], codes [B,n_q,T].
+bool launch_dac_rvq_fused(const RvqStage* stages_dev, int n_q, int L, int D, int N, const float* residual, int B, int64_t T, int64_t* codes,
+                          float* zq, float* latents, hipStream_t s, Profiler* prof);
 // z_e [B,D,T] (batch stride ze_bstride) -> codes[b*codes_bstride + t] (int64) and st [B,D,T] = z_e + (cb[idx] - z_e)
 void launch_vq_argmin(const Codebook& cb, const float* z_e, int64_t ze_bstride, int B, int64_t T, int64_t* codes,
                       int64_t codes_bstride, float* st, hipStream_t s, Profiler* prof);
@@ -76,6 +91,8 @@ struct DacModel : Codec {
 
     std::vector<std::unique_ptr<ConvLayer>> in_proj, out_proj;
     std::vector<std::unique_ptr<Codebook>> codebooks;
+    std::vector<std::unique_ptr<DevBuf>> rvq_dense;   // dense projection weights / biases of the stage-fused quantizer
+    DevBuf rvq_stages;                                // RvqStage[n_codebooks]
 
     ConvLayer dec_in;
     struct DecBlk {

@@ -9,6 +9,8 @@
 // each lane scans N/64 codes, then a wavefront DPP/shuffle min-reduction over (distance, index) picks
 // the winner with the first-index tie-break.  HBM traffic per frame is D floats in, D floats + one
 // int64 out: the kernel is bound by LDS/VALU rate, not by HBM.
+#include <cstdlib>
+
 #include "nc_math.h"
 #include "nc_model.h"
 
@@ -157,6 +159,177 @@ void launch_vq_argmin(const Codebook& cb, const float* z_e, int64_t ze_bstride, 
                        cb.cb.as<float>(), cb.N, cb.D, z_e, ze_bstride, B, T, codes, codes_bstride, st);
     NC_HIP(hipGetLastError());
     if (prof && prof->on) prof->end(s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Stage-fused DAC quantizer: in_proj -> nearest code -> out_proj -> (zq += q, residual -= q) for ALL n_q stages in one launch
+// (ResidualVectorQuantizer.cs:54-103 over VectorQuantizer.cs:67-125).  Every frame is independent, so a workgroup owns 16 frames and
+// walks the stages with the residual block [latent][16] in LDS and its share of zq (4 channels x 16 frames per thread) in registers;
+// the stage's codebook ([D][N] + norms) and in_proj weights are staged into LDS once per stage.  Same arithmetic, operation for
+// operation, as the stage-by-stage launches (skinny_proj_kernel / vq_argmin_kernel / the 1x1 template with the RVQ epilogue):
+//   z_e[d]  = (fma chain over c ascending of W_in[d][c] * r[c], from +0) + b_in[d]
+//   idx     = argmin_n (|z_e|^2 + |c_n|^2) - 2 (z_e . c_n), chains over d ascending, lowest index on ties
+//   st[d]   = z_e[d] + (c_idx[d] - z_e[d])
+//   q[c]    = (fma chain over d ascending of W_out[c][d] * st[d], from +0) + b_out[c];   zq[c] = zq[c] + q[c];   r[c] = r[c] - q[c]
+// 36 launches (4 per stage) and the round trips of residual / zq through HBM between them become one launch.
+constexpr int RF = 16;     // frames per workgroup
+constexpr int RD = 8;      // codebook dimension of this instantiation
+typedef float rvq_f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const float* rvq_gp;
+typedef __attribute__((address_space(1))) const rvq_f32x4* rvq_gp4;
+struct RvqFusedArgs {
+    const RvqStage* stages;
+    const float* residual;
+    float* zq;
+    float* latents;
+    int64_t* codes;
+    int n_q, L, N, B;
+    int64_t T;
+};
+__global__ __launch_bounds__(256) void dac_rvq_fused_kernel(const RvqFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int L = a.L, N = a.N;
+    float* rs = sm;                       // [L][RF] residual block
+    float* s_cb = rs + L * RF;            // [RD][N]
+    float* s_c2 = s_cb + RD * N;          // [N]
+    float* s_w = s_c2 + N;                // [L][RD] in_proj weight (transposed)
+    float* s_ze = s_w + L * RD;           // [RF][RD]
+    float* s_st = s_ze + RF * RD;         // [RF][RD]
+    int* s_bt = reinterpret_cast<int*>(s_st + RF * RD);   // [RF][2]: clip, frame within the clip (clip = -1: past the end)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t T = a.T, total = (int64_t)a.B * T, f0 = (int64_t)blockIdx.x * RF;
+    if (tid < RF) {
+        const int64_t fr = f0 + tid;
+        const int64_t b = fr < total ? fr / T : -1;
+        s_bt[2 * tid] = (int)b;
+        s_bt[2 * tid + 1] = (int)(fr < total ? fr - b * T : 0);
+    }
+    __syncthreads();
+    for (int i = tid; i < L * RF; i += 256) {
+        const int c = i / RF, f = i - c * RF;
+        const int b = s_bt[2 * f], t = s_bt[2 * f + 1];
+        rs[i] = b >= 0 ? a.residual[((int64_t)b * L + c) * T + t] : 0.0f;
+    }
+    const int NJ = L / 256;               // channels per thread in the out_proj / update phase (host: L % 256 == 0, NJ <= 4)
+    float zqr[4][RF];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int f = 0; f < RF; ++f) zqr[j][f] = 0.0f;
+    for (int q = 0; q < a.n_q; ++q) {
+        const RvqStage sg = a.stages[q];
+        __syncthreads();                  // the previous stage has finished with the codebook / weight images and updated rs
+        {
+            const rvq_gp4 c4 = (rvq_gp4)sg.cbT, w4 = (rvq_gp4)sg.w_inT, n4 = (rvq_gp4)sg.c2;
+            rvq_f32x4* d4 = reinterpret_cast<rvq_f32x4*>(s_cb);
+            for (int i = tid; i < RD * N / 4; i += 256) d4[i] = c4[i];
+            d4 = reinterpret_cast<rvq_f32x4*>(s_c2);
+            for (int i = tid; i < N / 4; i += 256) d4[i] = n4[i];
+            d4 = reinterpret_cast<rvq_f32x4*>(s_w);
+            for (int i = tid; i < L * RD / 4; i += 256) d4[i] = w4[i];
+        }
+        // out_proj rows of this thread's channels: read now, used after the search (their latency hides under the in_proj chains)
+        rvq_f32x4 wo[4][2];
+        float bo4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = min(tid + 256 * j, L - 1);
+            wo[j][0] = ((rvq_gp4)sg.w_out)[2 * c];
+            wo[j][1] = ((rvq_gp4)sg.w_out)[2 * c + 1];
+            bo4[j] = ((rvq_gp)sg.b_out)[c];
+        }
+        __syncthreads();
+        if (tid < RF * RD) {              // in_proj: thread = (frame, d), one chain over the latent channels
+            const int f = tid / RD, d = tid - f * RD;
+            float acc = 0.0f;
+#pragma unroll 16
+            for (int c = 0; c < L; ++c) acc = nc_fma(s_w[c * RD + d], rs[c * RF + f], acc);
+            const float ze = acc + ((rvq_gp)sg.b_in)[d];
+            s_ze[tid] = ze;
+            const int b = s_bt[2 * f], t = s_bt[2 * f + 1];
+            if (b >= 0) a.latents[((int64_t)b * a.n_q * RD + (int64_t)q * RD + d) * T + t] = ze;
+        }
+        __syncthreads();
+        for (int fi = 0; fi < RF / 4; ++fi) {   // nearest code: wave = 4 frames, lane scans N/64 codes (vq_argmin_kernel)
+            const int f = wave * (RF / 4) + fi;
+            float e[RD];
+#pragma unroll
+            for (int d = 0; d < RD; ++d) e[d] = s_ze[f * RD + d];
+            float e2 = 0.0f;
+#pragma unroll
+            for (int d = 0; d < RD; ++d) e2 = nc_fma(e[d], e[d], e2);
+            float best = __builtin_inff();
+            int bi = 0x7fffffff;
+            for (int n = lane; n < N; n += 64) {
+                float cr = 0.0f;
+#pragma unroll
+                for (int d = 0; d < RD; ++d) cr = nc_fma(e[d], s_cb[d * N + n], cr);
+                const float dist = (e2 + s_c2[n]) - 2.0f * cr;
+                if (dist < best) { best = dist; bi = n; }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float od = __shfl_xor(best, off, 64);
+                const int oi = __shfl_xor(bi, off, 64);
+                if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
+            }
+            if (bi == 0x7fffffff) bi = 0;
+            const int b = s_bt[2 * f], t = s_bt[2 * f + 1];
+            if (lane == 0 && b >= 0) a.codes[((int64_t)b * a.n_q + q) * T + t] = (int64_t)bi;
+            if (lane < RD) {
+                const float qv = ((rvq_gp)sg.cb)[(int64_t)bi * RD + lane];
+                const float ev = s_ze[f * RD + lane];
+                s_st[f * RD + lane] = ev + (qv - ev);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {           // out_proj + zq += q ; residual -= q: thread = 1 channel per pass x all frames
+            if (j < NJ) {
+                const int c = tid + 256 * j;
+                const float wv[RD] = {wo[j][0][0], wo[j][0][1], wo[j][0][2], wo[j][0][3], wo[j][1][0], wo[j][1][1], wo[j][1][2], wo[j][1][3]};
+#pragma unroll
+                for (int f = 0; f < RF; ++f) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int d = 0; d < RD; ++d) acc = nc_fma(wv[d], s_st[f * RD + d], acc);
+                    const float y = acc + bo4[j];
+                    zqr[j][f] = zqr[j][f] + y;
+                    rs[c * RF + f] = rs[c * RF + f] - y;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j < NJ) {
+            const int c = tid + 256 * j;
+#pragma unroll
+            for (int f = 0; f < RF; ++f) {
+                const int b = s_bt[2 * f], t = s_bt[2 * f + 1];
+                if (b >= 0) a.zq[((int64_t)b * L + c) * T + t] = zqr[j][f];
+            }
+        }
+    }
+}
+
+bool launch_dac_rvq_fused(const RvqStage* stages_dev, int n_q, int L, int D, int N, const float* residual, int B, int64_t T, int64_t* codes,
+                          float* zq, float* latents, hipStream_t s, Profiler* prof) {
+    static const bool off = std::getenv("NC_DAC_RVQ_STAGEWISE") != nullptr;
+    if (off || D != RD || L % 256 != 0 || L > 1024 || N % 64 != 0 || n_q <= 0) return false;
+    const size_t lds = sizeof(float) * ((size_t)L * RF + (size_t)RD * N + N + (size_t)L * RD + 2 * RF * RD + 2 * RF);
+    if (lds > 160 * 1024) return false;
+    ensure_dynamic_lds((const void*)dac_rvq_fused_kernel, 160 * 1024);
+    const int64_t total = (int64_t)B * T;
+    RvqFusedArgs a{};
+    a.stages = stages_dev; a.residual = residual; a.zq = zq; a.latents = latents; a.codes = codes;
+    a.n_q = n_q; a.L = L; a.N = N; a.B = B; a.T = T;
+    if (prof && prof->on)
+        prof->begin(s, NC_KC_RVQ, (3.0 * 2.0 * D * N + 4.0 * D * L) * (double)total * n_q, 4.0 * total * (2.0 * L + (double)n_q * (D + 2)));
+    hipLaunchKernelGGL(dac_rvq_fused_kernel, dim3((unsigned)((total + RF - 1) / RF)), dim3(256), lds, s, a);
+    NC_HIP(hipGetLastError());
+    if (prof && prof->on) prof->end(s);
+    return true;
 }
 
 void launch_vq_gather(const Codebook& cb, const int64_t* codes, int64_t codes_bstride, int B, int64_t T, float* out, hipStream_t s,
