@@ -74,6 +74,7 @@ static conv_kernel_fn narrow_kernel(int K, int TM) {
     return nullptr;
 }
 conv_kernel_fn conv1x1_kernel_table(int, int);
+conv_kernel_fn conv1x1_stream_kernel_table(int, int);
 bool launch_conv_thin(const float* x, int64_t x_bstride, int64_t x_cstride, int Cin, int x_len, const float* w_dense, const float* bias, float* y,
                       int64_t y_bstride, int64_t y_cstride, int B, int Cout, int K, int pad, int dil, int64_t Tout, bool tanh_out, hipStream_t s);
 bool launch_conv_stem(const float* x, int64_t x_bstride, int x_len, const float* w_dense, const float* bias, const float* alpha_out, float* y,
@@ -355,12 +356,28 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
     a.n_t_tiles = (int32_t)((T + 255) / 256);
     a.n_cb = (L.Cin + 15) / 16;
     a.co_group = pick_co_group(a.n_co_tiles, 4.0 * B * L.Cin * (double)T, 4.0 * L.Cin * (double)L.Cout, (double)B * a.n_t_tiles);
-    const int64_t grid = (int64_t)a.n_co_tiles * B * a.n_t_tiles;
+    int64_t grid = (int64_t)a.n_co_tiles * B * a.n_t_tiles;
+    size_t lds = 0;
+    {   // streaming variant: narrow long rows, whole weight tile of a row tile resident in LDS (see conv1x1_stream_kernel)
+        static const bool no_stream = std::getenv("NC_NO_PW_STREAM") && std::getenv("NC_NO_PW_STREAM")[0] == '1';
+        const size_t need = sizeof(float) * ((size_t)L.Cin * BM + 3 * (size_t)BM);
+        conv_kernel_fn sfn = (!no_stream && !in_mode && mode <= 4 && L.Cin % 32 == 0 && L.Cin <= 192 && L.Cout % BM == 0 && need <= 76 * 1024 &&
+                              grid >= 2048)
+                                 ? conv1x1_stream_kernel_table(tc.cfg.TM, mode)
+                                 : nullptr;
+        if (sfn) {
+            fn = sfn;
+            lds = need;
+            ensure_dynamic_lds((const void*)fn, 80 * 1024);
+            const int64_t per = std::max<int64_t>(1, 512 / a.n_co_tiles);            // two workgroups per CU, a whole number per row tile
+            grid = (int64_t)a.n_co_tiles * std::min<int64_t>(per, (int64_t)B * a.n_t_tiles);
+        }
+    }
     if (prof && prof->on) {
         const double bytes = 4.0 * ((double)B * L.Cin * T + (double)B * L.Cout * T * (io.res ? 2 : 1) + (double)L.Cin * L.Cout);
         prof->begin(stream, L.kclass, L.flops(B, T), bytes);
     }
-    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, stream, a);
     NC_HIP(hipGetLastError());
     if (prof && prof->on) prof->end(stream);
     return true;

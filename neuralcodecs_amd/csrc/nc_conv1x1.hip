@@ -291,6 +291,172 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
     }
 }
 
+typedef void (*conv_kernel_fn)(const ConvArgs);
+
+// Streaming pointwise convolution for the narrow long rows (Cin <= 192: the SNAC residual / noise / attention projections at
+// 5 s x 44.1 kHz, the DAC C = 192 units): these layers move 12*C bytes per 2*C*C flops -- 16-32 flop/B, the HBM side of the machine
+// balance -- and the tile-per-workgroup kernel above reaches 3.0-3.5 TB/s on them: its B ring holds 4 steps (2 KB per wave) and
+// every 16 channels cost a workgroup barrier and a weight-tile hand-over.  Here the WHOLE weight tile of the row tile (BM x Cin
+// floats = the packed image of the row tile, <= 72 KB) is loaded into LDS once per workgroup and the workgroup walks many column
+// tiles: the loop has no barrier at all (waves run free), the B ring is 16 steps deep (8 KB per wave in flight) and runs ACROSS
+// column tiles -- the first steps of tile k+1 are read before the stores of tile k, so no read waits behind a store acknowledgement.
+// Arithmetic unchanged: per output one chain over ci ascending from +0, + bias, + residual (or residual + noise * .), Snake.
+template <int TM, int MODE>
+__global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvArgs p) {
+    constexpr int TN = 2, BM = 32 * TM, BNW = 32 * TN, BN = 4 * BNW, PF = 16;
+    constexpr bool RES = (MODE & 5) != 0, SNAKE = (MODE & 2) != 0, NOISE = (MODE & 4) != 0;
+    extern __shared__ __attribute__((aligned(16))) float sa[];   // [Cin][BM] packed weights | [3][BM] bias, alpha, 1/alpha
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Cin = p.Cin, KS = Cin >> 1, T = p.Tout;
+    const int n_co = p.n_co_tiles, n_t = p.n_t_tiles;
+    const int co_tile = blockIdx.x % n_co, slot = blockIdx.x / n_co, stride = gridDim.x / n_co;   // host: gridDim.x % n_co == 0
+    const int units = p.B * n_t;
+    float* const Ep = sa + Cin * BM;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.w + (int64_t)co_tile * Cin * BM);
+        f32x4* dst = reinterpret_cast<f32x4*>(sa);
+        const int nv = Cin * BM / 4;
+        for (int i0 = 0; i0 < nv; i0 += 8 * 256) {
+            f32x4 r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = src[min(i0 + tid + 256 * u, nv - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + tid + 256 * u < nv) dst[i0 + tid + 256 * u] = r[u];
+        }
+        for (int i = tid; i < BM; i += 256) {
+            const int co = co_tile * BM + i;
+            const float ao = p.alpha_out ? p.alpha_out[co] : 0.0f;
+            Ep[i] = p.bias ? p.bias[co] : 0.0f;
+            Ep[BM + i] = ao;
+            Ep[2 * BM + i] = nc_snake_inv(ao);
+        }
+    }
+    __syncthreads();
+    if (slot >= units) return;
+    const unsigned x_cstride = (unsigned)p.x_cstride, cstride = (unsigned)p.y_cstride;
+    const float* const Ab = sa + hi * BM + nc_a_lane_off<TM>(l31);
+    // per-unit addressing: unit u -> clip b = u / n_t, column tile t = u % n_t
+    auto unit_x = [&](int u, const float*& xb, unsigned& xoff, int& col, int& bclip) __attribute__((always_inline)) {
+        const int b = u / n_t, t = u - b * n_t;
+        col = t * BN + wave * BNW + TN * l31;
+        const int colc = min(col, T - TN);
+        xb = p.x + (int64_t)b * p.x_bstride;
+        xoff = (unsigned)hi * x_cstride + (unsigned)colc;
+        bclip = b;
+    };
+    const float* xb; unsigned xoff; int col, bclip;
+    unit_x(slot, xb, xoff, col, bclip);
+    f32x2 bq[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) bq[u] = *reinterpret_cast<const f32x2*>(xb + (size_t)(2 * u) * x_cstride + xoff);
+    for (int unit = slot; unit < units; unit += stride) {
+        // the unit after this one (its first PF steps are read during this unit's last PF steps)
+        const int nunit = unit + stride;
+        const float* xbn = xb; unsigned xoffn = xoff; int coln = col, bn = bclip;
+        if (nunit < units) unit_x(nunit, xbn, xoffn, coln, bn);
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int g0 = 0; g0 < KS; g0 += PF) {
+            const bool tail = g0 + PF >= KS;                       // the refills of this group belong to the next unit
+            const float* rb = tail ? xbn : xb;
+            const unsigned ro = tail ? xoffn : xoff;
+            const int gb = tail ? 0 : g0 + PF;
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                float a[TM];
+                nc_load_a_frag<TM>(Ab + 2 * (g0 + u) * BM, l31, a);
+                const f32x2 bv = bq[u];
+                bq[u] = *reinterpret_cast<const f32x2*>(rb + (size_t)(2 * (gb + u)) * x_cstride + ro);   // (last unit: re-reads its own rows, unused)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[0], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[1], acc[i][1], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue of this unit (full row tiles only: host).  Phase A: every global read (residual quads, noise), folded into the
+        //      accumulators; phase B: stores.
+        if (col < T) {
+            const int64_t tile_base = (int64_t)bclip * p.y_bstride + (int64_t)co_tile * BM * p.y_cstride;
+            const unsigned lane_off = (unsigned)(4 * hi) * cstride + (unsigned)col;
+            f32x2 nz = {0.0f, 0.0f};
+            if constexpr (NOISE) nz = *reinterpret_cast<const f32x2*>(p.noise + (int64_t)bclip * p.noise_bstride + col);
+            const float* const rt = p.res + tile_base;
+            f32x2 rs[2][4];
+            unsigned loff = lane_off;
+            auto load_quad = [&](int q, f32x2 (&dst)[4]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int R = (q >> 2) * 32 + rr + 8 * (q & 3);
+                    dst[rr] = *reinterpret_cast<const f32x2*>(rt + (size_t)R * cstride + loff);
+                }
+            };
+            if constexpr (RES) load_quad(0, rs[0]);
+            nc_static_for_1x1<4 * TM>([&](auto qt) __attribute__((always_inline)) {
+                constexpr int q = decltype(qt)::value, i = q >> 2, rq = q & 3;
+                if constexpr (RES && q + 1 < 4 * TM) {
+                    if constexpr (q >= 1) asm volatile("" : "+v"(loff) : "v"(acc[(q - 1) >> 2][0][4 * ((q - 1) & 3) + 3]));
+                    load_quad(q + 1, rs[(q + 1) & 1]);
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int r = 4 * rq + rr;
+                    const float bias = Ep[i * 32 + rr + 8 * rq + 4 * hi];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        float v = acc[i][j][r] + bias;
+                        if constexpr (NOISE) v = rs[q & 1][rr][j] + nz[j] * v;
+                        else if constexpr (RES) v = v + rs[q & 1][rr][j];
+                        acc[i][j][r] = v;
+                    }
+                }
+            });
+            float* const yt = p.y + tile_base;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int R = i * 32 + (r & 3) + 8 * (r >> 2);
+                    f32x2 v = {acc[i][0][r], acc[i][1][r]};
+                    if constexpr (SNAKE) {
+                        const float ao = Ep[BM + R + 4 * hi], ao_inv = Ep[2 * BM + R + 4 * hi];
+                        v[0] = nc_snakef(v[0], ao, ao_inv);
+                        v[1] = nc_snakef(v[1], ao, ao_inv);
+                    }
+                    *reinterpret_cast<f32x2*>(yt + (size_t)R * cstride + lane_off) = v;
+                }
+        }
+        xb = xbn; xoff = xoffn; col = coln; bclip = bn;
+    }
+}
+
+template <int TM>
+static conv_kernel_fn conv1x1_stream_by_mode(int mode) {
+    switch (mode) {
+        case 0: return &conv1x1_stream_kernel<TM, 0>;
+        case 1: return &conv1x1_stream_kernel<TM, 1>;
+        case 2: return &conv1x1_stream_kernel<TM, 2>;
+        case 3: return &conv1x1_stream_kernel<TM, 3>;
+        case 4: return &conv1x1_stream_kernel<TM, 4>;
+    }
+    return nullptr;
+}
+// streaming variant (weights resident in LDS): TM = 2 / 3, modes 0..4
+conv_kernel_fn conv1x1_stream_kernel_table(int TM, int mode) {
+    switch (TM) {
+        case 2: return conv1x1_stream_by_mode<2>(mode);
+        case 3: return conv1x1_stream_by_mode<3>(mode);
+    }
+    return nullptr;
+}
+
 // Skinny projection: 1x1 conv with Cout <= 16 (the RVQ in_proj 1024 -> 8, VectorQuantizer.cs:47,76) over N = B*T frames.  The
 // generic tile would run one workgroup per clip with a barrier every 16 channels; here one wavefront owns 16 frames and walks the
 // whole reduction with v_mfma_f32_16x16x4_f32 (exact k-ordered chain), weights pre-packed [Cin/4][64 lanes] (rows >= Cout are 0),
@@ -340,8 +506,6 @@ void launch_skinny_proj(const float* x, int64_t x_bstride, int64_t x_cstride, co
                        y_cstride, B, Cin, Cout, T);
     NC_HIP(hipGetLastError());
 }
-
-typedef void (*conv_kernel_fn)(const ConvArgs);
 
 template <int TM>
 static conv_kernel_fn conv1x1_by_mode(int mode) {

@@ -192,6 +192,22 @@ def test_conv1d_random_shapes_bit_exact(cin, cout, k, s, p, d, T, B, tr):
     assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
 
 
+@pytest.mark.parametrize("C,res,snake", [(64, True, False), (96, True, True), (96, False, False), (192, True, False)])
+def test_pointwise_streaming_variant_bit_exact(C, res, snake):
+    """Long narrow rows take the streaming pointwise kernel (weights resident in LDS, B ring across column tiles): >= 2048 column tiles."""
+    rng = np.random.default_rng(C + res + 2 * snake)
+    B, T = 8, 66000 if C < 192 else 33100
+    x = _rand(rng, B, C, T)
+    w = _rand(rng, C, C, 1, scale=1.0 / np.sqrt(C)); b = _rand(rng, C, scale=0.1)
+    r = _rand(rng, B, C, T) if res else None
+    a = _alpha(rng, C) if snake else None
+    want = c_oracle.conv1d(x, w, b, residual=r)
+    if snake:
+        want = c_oracle.snake(want, a)
+    got = ops.conv1d(x, w, b, residual=r, alpha_out=a)
+    assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+
+
 def test_flattened_column_axis_residual_and_snake_epilogues():
     """Stride-1 k=7 over 87-column rows with the residual / next-Snake epilogues (the full-tile straight-line path and edge tiles)."""
     rng = np.random.default_rng(77)
