@@ -1014,6 +1014,15 @@ float* EncodecModel::materialize(const Act& a, int N, const float* scale, int mo
     return y;
 }
 
+// [N][C][T] -> [C][T][N]: the layout in which a range of steps is one contiguous column range (run_lstm's chunked input projections)
+__global__ void nct_to_ctn_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int64_t T) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)N * C * T) return;
+    const int n = (int)(i % N);
+    const int64_t r = i / N, t = r % T, c = r / T;
+    y[i] = x[((int64_t)n * C + c) * T + t];
+}
+
 // SLSTM.forward (SLSTM.cs:40-57) on a dense x [N,C,T]; returns lstm(x) + x
 float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
     const int C = l.C;
@@ -1081,7 +1090,7 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
                 const int nt = std::min(per_launch, n_tiles - tl);
                 LstmSeqArgs a{};
                 a.gi = gi[li]; a.whhp = y.whhp.as<float>(); a.bhh = y.bhh.as<float>(); a.skip = last ? x : nullptr; a.out = out[li];
-                if (li > 0 && piped) { a.gi_b = 1; a.gi_c = T * N; a.gi_t = N; }
+                if (piped) { a.gi_b = 1; a.gi_c = T * N; a.gi_t = N; }
                 else { a.gi_b = (int64_t)4 * C * T; a.gi_c = T; a.gi_t = 1; }
                 if (between(li)) { a.out_b = 1; a.out_c = T * N; a.out_t = N; }
                 else { a.out_b = (int64_t)C * T; a.out_c = T; a.out_t = 1; }
@@ -1108,8 +1117,6 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
         }
         if (!lstm_stream) NC_HIP(hipStreamCreateWithFlags(&lstm_stream, hipStreamNonBlocking));
         sB = lstm_stream;
-        // layer 0's input projections depend on x alone: one full GEMM ahead of everything
-        ih_gemm(*l.layers[0], x, gi[0], sA);
         {
             hipEvent_t fork = next_event();
             NC_HIP(hipEventRecord(fork, sA));
@@ -1122,15 +1129,27 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
             io.y = g + t0 * N; io.y_bstride = 0; io.y_cstride = T * N;
             launch_conv(y.ih, io, 1, s, &prof);
         };
-        std::vector<hipEvent_t> prev(nch, nullptr);   // prev[k]: chunk k of the layer below is complete
+        // layer 0's input projections depend on x alone: x goes to the [C][T][N] layout once and its chunk GEMMs run ahead on the second
+        // stream, chunk k releasing layer 0's chunk k -- the recurrence starts after the first chunk's GEMM, not after the whole one
+        std::vector<hipEvent_t> prev(nch, nullptr);   // prev[k]: chunk k of the layer below (for layer 0: of its input projection) is complete
+        {
+            float* xT = alloc((size_t)N * C * T);
+            const int64_t n = (int64_t)N * C * T;
+            hipLaunchKernelGGL(nct_to_ctn_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sB, x, xT, N, C, T);
+            NC_HIP(hipGetLastError());
+            for (int k = 0; k < nch; ++k) {
+                const int64_t t0 = (int64_t)k * chunk, t1 = std::min(T, t0 + chunk);
+                ih_gemm_chunk(*l.layers[0], xT, gi[0], t0, t1 - t0, sB);
+                prev[k] = next_event();
+                NC_HIP(hipEventRecord(prev[k], sB));
+            }
+        }
         for (int li = 0; li < nl; ++li) {
             hipStream_t s = layer_stream(li);
             for (int k = 0; k < nch; ++k) {
                 const int64_t t0 = (int64_t)k * chunk, t1 = std::min(T, t0 + chunk);
-                if (li > 0) {
-                    NC_HIP(hipStreamWaitEvent(s, prev[k], 0));
-                    ih_gemm_chunk(*l.layers[li], out[li - 1], gi[li], t0, t1 - t0, s);
-                }
+                NC_HIP(hipStreamWaitEvent(s, prev[k], 0));
+                if (li > 0) ih_gemm_chunk(*l.layers[li], out[li - 1], gi[li], t0, t1 - t0, s);
                 lstm_chunk(li, t0, t1);
                 if (li + 1 < nl) {
                     hipEvent_t e = next_event();
