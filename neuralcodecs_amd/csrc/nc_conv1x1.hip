@@ -303,7 +303,8 @@ typedef void (*conv_kernel_fn)(const ConvArgs);
 // Arithmetic unchanged: per output one chain over ci ascending from +0, + bias, + residual (or residual + noise * .), Snake.
 template <int TM, int MODE>
 __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvArgs p) {
-    constexpr int TN = 2, BM = 32 * TM, BNW = 32 * TN, BN = 4 * BNW, PF = 16;
+    constexpr int TN = 2, BM = 32 * TM, BNW = 32 * TN, BN = 4 * BNW;
+    constexpr int PF = (TM == 3 && MODE == 3) ? 8 : 16;   // (residual + Snake at 96 rows: a 16-step ring spills)
     constexpr bool RES = (MODE & 5) != 0, SNAKE = (MODE & 2) != 0, NOISE = (MODE & 4) != 0;
     extern __shared__ __attribute__((aligned(16))) float sa[];   // [Cin][BM] packed weights | [3][BM] bias, alpha, 1/alpha
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
