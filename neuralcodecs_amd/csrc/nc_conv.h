@@ -68,6 +68,15 @@ struct ConvArgs {
     int32_t flat, flat_px, flat_pc, flat_hc, Bc;
     int32_t co_group;              // row tiles per group of the block -> tile order (see the kernel's tile map); >= 1, divides n_co_tiles
     int32_t in_left, in_Lz, in_L;  // bit 2: padded position j reads q = reflect(j - left) over [0,Lz); samples q >= L are the zero extension (D9)
+    // two-input form (in_mode bit 3, IN2 kernels): second operand with the geometry of x and its own pending GroupNorm
+    const float* x2;
+    const float* in_stats2;
+    const float* in_gamma2;
+    const float* in_beta2;
+    // GroupNorm(1,C) statistics of the OUTPUT emitted from the epilogue (nc_gn.h): (S1, S2) of every 32x32 block of the tile, binary64,
+    // at gn_part[((clip*gn_nrb + row block)*gn_ncb + column block)*2]; null = off.  Plain epilogues only (bias, no residual / activation).
+    double* gn_part;
+    int32_t gn_nrb, gn_ncb;
 };
 
 // Position of row (32*i + r) of a weight tile inside one kk row of BM = 32*TM floats.  The TM values of one matrix-core lane
@@ -143,6 +152,12 @@ struct ConvIO {
     const float* in_beta = nullptr;
     bool in_elu = false;
     int64_t in_left = 0, in_Lz = 0, in_L = 0;
+    const float* x2 = nullptr;                  // Encodec two-input mode: second operand (same strides / lengths as x), added after its own GroupNorm
+    const float* in_stats2 = nullptr;
+    const float* in_gamma2 = nullptr;
+    const float* in_beta2 = nullptr;
+    double* gn_part = nullptr;                  // GroupNorm block sums of the output ([B][gn_nrb][gn_ncb][2], see ConvArgs::gn_part); needs conv_gn_fusable()
+    int gn_nrb = 0, gn_ncb = 0;
     const float* alpha_out2 = nullptr;          // with fuse_k1: Snake applied to the unit's output y (consumer's activation)
     const struct ConvLayer* fuse_k1 = nullptr;  // fused residual unit: the 1x1 layer applied to snake(alpha_out)(this conv) + res
 };
@@ -151,5 +166,14 @@ TileCfg pick_tile(int Cout, int Ktaps);
 // true when `k7` followed by `k1` can run as one fused residual-unit launch
 bool can_fuse_res_unit(const ConvLayer& k7, const ConvLayer& k1);  // TN is chosen per launch from the column count
 void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream, Profiler* prof);
+// true when launch_conv can emit the GroupNorm block sums of this launch's output from the kernel epilogue (ConvIO::gn_part); the
+// streaming thin / stem / skinny kernels and the per-phase transposed launches cannot (the caller then runs the stand-alone pass)
+bool conv_gn_fusable(const ConvLayer& L, const ConvIO& io);
+// true when launch_conv has a two-input (ConvIO::x2) kernel for this layer
+bool conv_in2_available(const ConvLayer& L);
+// block view of a [C][T] GroupNorm input behind layer L (sub-pixel transposed convolutions: rows = (channel, phase) pairs)
+inline int conv_gn_sub(int K, int stride, int Cout, bool transposed) {
+    return (transposed && (stride == 2 || stride == 4 || stride == 8) && K == 2 * stride && (Cout * stride) % 32 == 0) ? stride : 1;
+}
 
 }  // namespace nc

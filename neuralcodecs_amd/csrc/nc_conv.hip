@@ -73,6 +73,24 @@ static conv_kernel_fn narrow_kernel(int K, int TM) {
     }
     return nullptr;
 }
+conv_kernel_fn conv_kernel_table_in2_k4(int, int);
+conv_kernel_fn conv_kernel_table_in2_k8(int, int);
+conv_kernel_fn conv_kernel_table_in2_k10(int, int);
+conv_kernel_fn conv_kernel_table_in2_k16(int, int);
+conv_kernel_fn conv_kernel_table_in2_k2(int, int);
+conv_kernel_fn conv_kernel_table_in2_sub_k2(int, int);
+// two-input (ConvIO::x2) kernel of a layer's tile shape; null: none instantiated
+static conv_kernel_fn in2_kernel(int Ktaps, bool sub, int TM, int TN) {
+    if (sub) return Ktaps == 2 ? conv_kernel_table_in2_sub_k2(TM, TN) : nullptr;
+    switch (Ktaps) {
+        case 2: return conv_kernel_table_in2_k2(TM, TN);
+        case 4: return conv_kernel_table_in2_k4(TM, TN);
+        case 8: return conv_kernel_table_in2_k8(TM, TN);
+        case 10: return conv_kernel_table_in2_k10(TM, TN);
+        case 16: return conv_kernel_table_in2_k16(TM, TN);
+    }
+    return nullptr;
+}
 conv_kernel_fn conv1x1_kernel_table(int, int);
 conv_kernel_fn conv1x1_stream_kernel_table(int, int);
 bool launch_conv_thin(const float* x, int64_t x_bstride, int64_t x_cstride, int Cin, int x_len, const float* w_dense, const float* bias, float* y,
@@ -337,10 +355,11 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
     if (!al8(io.x) || !al8(io.y) || (io.res && !al8(io.res)) || (io.noise && !al8(io.noise))) return false;
     if ((io.epi & EPI_NOISE) && (!io.noise || !io.res)) return false;
     const int in_mode = (io.in_stats ? 1 : 0) | (io.in_elu ? 2 : 0);
-    if (io.in_L > 0) return false;   // (reflect addressing: the windowed template)
+    if (io.in_L > 0 || io.x2) return false;   // (reflect addressing / two operands: the windowed template)
     if (in_mode && (io.res || io.alpha_out || io.epi || L.Cin > 512)) return false;
     const TileChoice tc = choose_tile(L, (int64_t)B * ((T + 255) / 256), true);
     const int mode = in_mode ? 8 : (io.epi & EPI_NOISE) ? 4 : ((io.res ? 1 : 0) | (io.alpha_out ? 2 : 0));
+    if (io.gn_part && mode != 8) return false;   // block sums are emitted by the input-mode instance only (the windowed template has them everywhere)
     conv_kernel_fn fn = conv1x1_kernel_table(tc.cfg.TM, mode);
     if (!fn) return false;
     ConvArgs a{};
@@ -350,6 +369,7 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
     a.res = io.res; a.noise = io.noise; a.noise_bstride = T; a.epi = io.epi; a.alpha_out = io.alpha_out;
     a.y = io.y; a.y_bstride = io.y_bstride; a.y_cstride = io.y_cstride;
     a.in_mode = in_mode; a.in_stats = io.in_stats; a.in_gamma = io.in_gamma; a.in_beta = io.in_beta;
+    a.gn_part = io.gn_part; a.gn_nrb = io.gn_nrb; a.gn_ncb = io.gn_ncb;
     a.Cout = L.Cout; a.B = B; a.Tout = (int32_t)T;
     const int BM = tc.cfg.BM();
     a.n_co_tiles = (L.Cout + BM - 1) / BM;
@@ -383,10 +403,34 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
     return true;
 }
 
+bool conv_in2_available(const ConvLayer& L) {
+    static const bool off = std::getenv("NC_NO_IN2") && std::getenv("NC_NO_IN2")[0] == '1';
+    if (off || L.w_thin.p || L.w_stem.p || L.w_skinny.p) return false;
+    // Only where ONE row tile covers all output rows: every row tile re-stages (normalises twice, adds, activates) the window it
+    // shares with the others, and on the matrix-core-bound deep layers that vector work sits on the critical path -- measured on C3:
+    // 64 -> 128 k8 419 -> 432 us, 128 -> 256 k10 493 -> 1224 us, 256 -> 512 k16 +370 us against the summed copy + one-input launch,
+    // while the single-tile layers gain (32 -> 64 k4: 314 -> 275 us, 64 -> 32 up-conv: 368 -> 311 us).
+    if (L.rows() > 64 || L.cfg.TM == 3) return false;
+    return in2_kernel(L.Ktaps, L.sub_shift != 0, L.cfg.TM, 1) != nullptr;
+}
+
+bool conv_gn_fusable(const ConvLayer& L, const ConvIO& io) {
+    static const bool off = std::getenv("NC_NO_GN_FUSE") && std::getenv("NC_NO_GN_FUSE")[0] == '1';
+    // plain epilogues only; one launch covering the whole output (no per-phase transposed launches); the streaming thin-output /
+    // stem / skinny kernels keep the stand-alone statistics pass (launch_conv skips them when gn_part is set, so the answer here only
+    // has to say which layers are WORTH routing through the matrix-core template: all but those three)
+    if (off || io.res || io.alpha_out || io.alpha_in || io.epi || io.fuse_k1 || L.n_phase != 1) return false;
+    if (L.w_thin.p || L.w_stem.p || L.w_skinny.p) return false;
+    return true;
+}
+
 void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream, Profiler* prof) {
     static const bool no_skinny = std::getenv("NC_NO_SKINNY") && std::getenv("NC_NO_SKINNY")[0] == '1';
-    const int in_mode = (io.in_stats ? 1 : 0) | (io.in_elu ? 2 : 0) | (io.in_L > 0 ? 4 : 0);
+    const int in_mode = (io.in_stats ? 1 : 0) | (io.in_elu ? 2 : 0) | (io.in_L > 0 ? 4 : 0) | (io.x2 ? 8 : 0);
     if (in_mode && (io.alpha_in || io.fuse_k1)) fail(NC_ESTATE, "internal: the Encodec input mode does not combine with Snake / fused units");
+    if (io.x2 && (!conv_in2_available(L) || (io.in_stats != nullptr) != (io.in_stats2 != nullptr)))
+        fail(NC_ESTATE, "internal: no two-input kernel for this layer");
+    if (io.gn_part && !conv_gn_fusable(L, io)) fail(NC_ESTATE, "internal: this launch cannot emit GroupNorm block sums");
     if (L.w_skinny.p && !no_skinny && !in_mode && !io.alpha_in && !io.alpha_out && !io.res && io.epi == 0 && !io.fuse_k1 && io.x_len == io.Tin) {
         if (prof && prof->on)
             prof->begin(stream, L.kclass, L.flops(B, io.Tin), 4.0 * ((double)B * L.Cin * io.Tin + (double)B * L.Cout * io.Tin + (double)L.Cin * L.Cout));
@@ -441,7 +485,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         const int sx0 = L.transposed ? 1 : L.stride, ad0 = L.transposed ? 1 : L.dil;
         const int xw96 = 95 * sx0 + (L.Ktaps - 1) * ad0 + 1;
         const bool fits = c.CB * ((xw96 + 63) / 64) <= 3 * nx_for_k(c.K);
-        if (!no_narrow && fits && !io.fuse_k1 && c.TN == 1 && n_cols_all <= 96 && rem > 64 && narrow_kernel(c.K, c.TM)) {
+        if (!no_narrow && fits && !io.fuse_k1 && !io.x2 && c.TN == 1 && n_cols_all <= 96 && rem > 64 && narrow_kernel(c.K, c.TM)) {
             narrow = true;
             c.NW = 3;
         }
@@ -465,7 +509,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
             const int xw = (BN - 1 + (S - 1) * hc) * sx0 + (L.Ktaps - 1) * ad0 + 1;
             return c.CB * ((xw + 63) / 64) <= 4 * nx_for_k(c.K);
         };
-        const bool cand = !no_flat && B > 1 && L.n_phase == 1 && !io.fuse_k1 && !(in_mode & 1) && !(io.epi & EPI_NOISE) && Tq >= 32 && L.Cin * L.Ktaps >= 64 &&
+        const bool cand = !no_flat && B > 1 && L.n_phase == 1 && !io.fuse_k1 && !(in_mode & 1) && !io.gn_part && !io.x2 && !(io.epi & EPI_NOISE) && Tq >= 32 && L.Cin * L.Ktaps >= 64 &&
                           3 * io.x_bstride + io.x_len < ((int64_t)1 << 32) &&
                           (int64_t)(c.BM() + 4) * io.y_cstride + Tout + 3 * io.y_bstride < ((int64_t)1 << 31) &&
                           (Tq + hc) * sx0 < (1 << 28);
@@ -526,7 +570,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         // 215 -> 145 us (32->16 k3, 48000 steps x 32 clips), 152 -> 118 us (64->32), 80 -> 51 us (2->32 k7).  Measured neutral or
         // slower for the strided k=4 / k=8 layers and the sub-pixel up-convolutions, which keep the standard blocks.
         static const bool no_slim = std::getenv("NC_NO_SLIM") && std::getenv("NC_NO_SLIM")[0] == '1';
-        if (!no_slim && !flat && !light && !narrow && !io.fuse_k1 && !L.sub_shift && !L.transposed && c.TM <= 2 && n_cols_all >= 1024) {
+        if (!no_slim && !flat && !light && !narrow && !io.fuse_k1 && !io.x2 && !L.sub_shift && !L.transposed && c.TM <= 2 && n_cols_all >= 1024) {
             int cb2 = 0, nx2 = 0;
             if (c.K == 3 && c.CB == 16) { slim_fn = conv_kernel_table_slim_k3(c.TM, c.TN); cb2 = 8; nx2 = 10; }
             else if (c.K == 7 && c.CB == 8 && L.Cin <= 4 && L.stride == 1 && L.dil == 1) { slim_fn = conv_kernel_table_slim_k7(c.TM, c.TN); cb2 = 4; nx2 = 5; }
@@ -562,12 +606,14 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     a.x = io.x; a.x_bstride = io.x_bstride; a.x_cstride = io.x_cstride; a.Cin = L.Cin; a.x_len = io.x_len;
     a.alpha_in = io.alpha_in;
     a.in_mode = in_mode; a.in_stats = io.in_stats; a.in_gamma = io.in_gamma; a.in_beta = io.in_beta;
+    a.x2 = io.x2; a.in_stats2 = io.in_stats2; a.in_gamma2 = io.in_gamma2; a.in_beta2 = io.in_beta2;
     a.in_left = (int32_t)io.in_left; a.in_Lz = (int32_t)io.in_Lz; a.in_L = (int32_t)io.in_L;
     a.w = tsel.w; a.w_phase_stride = tsel.w_phase_stride;
     a.bias = L.has_bias ? L.bias.as<float>() : nullptr;
     a.alpha_out = io.alpha_out; a.res = io.res;
     a.y = io.y; a.y_bstride = io.y_bstride; a.y_cstride = io.y_cstride;
     a.rvq_zq = io.rvq_zq; a.rvq_res = io.rvq_res;
+    a.gn_part = io.gn_part; a.gn_nrb = io.gn_nrb; a.gn_ncb = io.gn_ncb;
     a.noise = io.noise; a.noise_bstride = L.out_len(io.Tin);
     if ((io.epi & EPI_NOISE) && (!io.noise || !io.res)) fail(NC_ESTATE, "internal: noise epilogue needs noise and residual");
     a.Cout = L.rows(); a.sub_shift = L.sub_shift; a.B = B; a.epi = io.epi;
@@ -613,7 +659,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         const int q = k * a.dil + a.xneg;
         a.tapoff[k] = (k < L.Ktaps) ? (sx == 1 ? q : (q % sx) * a.xwp + q / sx) : 0;
     }
-    size_t lds_f = 2 * (size_t)KB * BM + 2 * (size_t)a.xbuf + ((io.alpha_in || (in_mode & 1)) ? 2 * (size_t)a.n_cb * CB : 0);
+    size_t lds_f = 2 * (size_t)KB * BM + 2 * (size_t)a.xbuf + ((io.alpha_in || (in_mode & 1)) ? 2 * (size_t)a.n_cb * CB * (io.x2 ? 2 : 1) : 0);
     if (io.fuse_k1) lds_f = std::max(lds_f, fused_wide ? (size_t)2 * BM * 32 : (size_t)BM * BM);   // the 1x1 weights reuse the tile buffers
     a.ep_off = (int32_t)lds_f;
     size_t lds = sizeof(float) * (lds_f + 6 * (size_t)BM);
@@ -635,6 +681,9 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     } else if (n_prod) {
         fn = conv_kernel_table_spec_k7(c.TM, c.TN);
         if (!fn) fail(NC_EUNSUPPORTED, "no specialised conv kernel for TM=%d TN=%d", c.TM, c.TN);
+    } else if (io.x2) {
+        fn = in2_kernel(c.K, L.sub_shift != 0, c.TM, c.TN);
+        if (!fn) fail(NC_EUNSUPPORTED, "no two-input conv kernel for K=%d TM=%d TN=%d", c.K, c.TM, c.TN);
     } else if (L.sub_shift) {
         fn = c.K != 2 ? nullptr : narrow ? conv_kernel_table_sub_narrow_k2(c.TM) : conv_kernel_table_sub_k2(c.TM, c.TN);
         if (!fn) fail(NC_EUNSUPPORTED, "no sub-pixel conv kernel for K=%d TM=%d TN=%d", c.K, c.TM, c.TN);

@@ -17,6 +17,7 @@
 #include "nc_conv.h"
 #include "nc_math.h"
 #include "nc_frag.h"
+#include "nc_gn.h"
 
 namespace nc {
 
@@ -181,11 +182,45 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
     // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*hi] for this lane's TN consecutive columns.  Phase A issues every global read
     //      (residual tile, noise) and folds it into the accumulators; phase B only stores.  A global read issued after a store waits
     //      for all earlier stores to be acknowledged, so the per-row operands (bias, Snake alpha) come from the LDS table Ep.
+    const int rows_total = p.Cout - co_tile * BM;   // uniform
+    if constexpr (INM) {
+        // GroupNorm(1,C) block sums of the output (nc_gn.h), emitted from the accumulators.  Column of (lane, j) = 2*l31 + j inside the
+        // wave's 64 columns: lanes l31 < 16 hold the first 32-column block, l31 >= 16 the second, and the canonical column tree
+        // (xor 16, 8, 4, 2, 1 of the column index) is lane xor 8, 4, 2, 1 followed by the in-lane sum over j.
+        if (p.gn_part != nullptr) {
+            double* const gp = p.gn_part + (int64_t)b * p.gn_nrb * p.gn_ncb * 2;
+            const bool colok = col < T;   // (T is even: both columns of a lane are in or out together)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                double a1[TN], a2[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float vv[16];
+                    unsigned okm16 = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int R = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        vv[r] = acc[i][j][r] + Ep[R];
+                        if (colok && R < rows_total) okm16 |= 1u << r;
+                    }
+                    nc_gn_slot_sums<false>(vv, okm16, a1[j], a2[j]);
+                }
+                // column tree low bit first: bit 0 of the column is j (in-lane), bits 1..4 are lane bits 0..3, then the lane half
+                double s1 = a1[0] + a1[1], s2 = a2[0] + a2[1];
+                nc_gn_butterfly_row(s1, s2);
+                s1 = nc_gn_swap_add<true>(s1);
+                s2 = nc_gn_swap_add<true>(s2);
+                const int rbk = co_tile * TM + i, cbk = ((t_tile * BN + wave * BNW) >> 5) + (l31 >> 4);
+                if ((lane & 47) == 0 && rbk < p.gn_nrb && cbk < p.gn_ncb)   // lanes 0 and 16
+                    *reinterpret_cast<double2*>(gp + ((int64_t)rbk * p.gn_ncb + cbk) * 2) = double2{s1, s2};
+                __builtin_amdgcn_sched_barrier(0);   // one row block at a time (register budget of the 5-waves-per-SIMD instances)
+            }
+        }
+    }
     if (col >= T) return;
     const int64_t tile_base = (int64_t)b * p.y_bstride + (int64_t)co_tile * BM * p.y_cstride;
     const unsigned cstride = (unsigned)p.y_cstride;
     const unsigned lane_off = (unsigned)(4 * hi) * cstride + (unsigned)col;
-    const int rows_total = p.Cout - co_tile * BM;   // uniform
     const int rows_left = rows_total - 4 * hi;
     // rows_tag: all BM rows of the tile are inside the tensor (row addresses are then uniform base + 32-bit lane offset)
     auto run_epilogue = [&](auto res_tag, auto snake_tag, auto noise_tag, auto rows_tag) __attribute__((always_inline)) {

@@ -5,6 +5,7 @@
 #include "nc_conv.h"
 #include "nc_math.h"
 #include "nc_frag.h"
+#include "nc_gn.h"
 
 #include <type_traits>
 #include <utility>
@@ -77,7 +78,11 @@ typedef __attribute__((address_space(3))) void* nc_lptr;
 // R = co*s + r, whose element (R, q) is output sample t = q*s + r - pad of channel co.  The 4 consecutive D rows a lane holds are
 // then consecutive samples of one channel, and the 32 columns x 2 lane halves of a store instruction cover a contiguous run of the
 // output row -- where the per-phase launches wrote every s-th sample from different workgroups (3x write amplification in HBM).
-template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0, bool DIST = false, bool SUB = false>
+// IN2: two-input form of the Encodec input mode (the sum of a residual block's shortcut and branch, each a raw conv output with its own
+// pending GroupNorm: SEANetResnetBlock.cs:72-85 feeding the next SConv1d / SConvTranspose1d): both operands are read with the same
+// window addresses, normalised separately, added, then ELU + pad -- the summed / activated / padded copy is never written.
+template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0, bool DIST = false, bool SUB = false,
+          bool IN2 = false>
 __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const ConvArgs p) {
     constexpr bool SPEC = NP > 0;
     constexpr int NT = 64 * (NW + NP);             // threads per workgroup
@@ -104,6 +109,8 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     constexpr int NG = NSEG - 1;
     constexpr int GA = (NA + NG - 1) / NG;         // per-group register footprint
     constexpr int GX = (NX + NG - 1) / NG;
+    constexpr int GXX = IN2 ? 2 * GX : GX;         // staging registers per group: the second operand's samples sit behind the first's
+    static_assert(!IN2 || (!FUSE && !SPEC && !DIST), "the two-input staging mode belongs to the plain template");
     static_assert(KB % 2 == 0, "reduction block must hold an even number of kk");
     static_assert(A_FLOATS % 4 == 0, "A tile must be 16-byte granular");
 
@@ -189,6 +196,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     const f32x4* const wbase =
         reinterpret_cast<const f32x4*>(p.w + (int64_t)phase * p.w_phase_stride + (int64_t)co_tile * p.n_cb * A_FLOATS);
     const float* const xb = p.x + (int64_t)b * p.x_bstride;
+    const float* const xb2 = IN2 ? p.x2 + (int64_t)b * p.x_bstride : nullptr;
 
     float* const As0 = smem;
     float* const Xs0 = smem + 2 * A_FLOATS;
@@ -201,11 +209,13 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     // Encodec input mode (ConvArgs::in_mode): pending GroupNorm + ELU + reflect pad applied while staging
     const int in_mode = p.in_mode;
     const float in_mu = (in_mode & 1) ? p.in_stats[2 * b] : 0.0f, in_rs = (in_mode & 1) ? p.in_stats[2 * b + 1] : 1.0f;
+    const float in_mu2 = (IN2 && (in_mode & 1)) ? p.in_stats2[2 * b] : 0.0f, in_rs2 = (IN2 && (in_mode & 1)) ? p.in_stats2[2 * b + 1] : 1.0f;
     int tap[K];  // window slot of tap k (wave-uniform scalars)
 #pragma unroll
     for (int k = 0; k < K; ++k) tap[k] = p.tapoff[k];
     // Snake alphas of all input channels, staged once per block behind the tile buffers
     float2* const Al = reinterpret_cast<float2*>(Xs0 + 2 * xbuf);   // (alpha, 1/alpha) per input channel
+    float2* const Al2 = Al + p.n_cb * CB;                           // IN2: (gamma, beta) of the second operand
     // per-row epilogue operands of this tile: bias, Snake alpha and 1/alpha (and the fused unit's second set).  The epilogue
     // reads them from LDS: a global read issued after the first store would wait for every earlier store to be acknowledged.
     // (Both tables are filled in the prologue below, behind the first tile's reads.)
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     // weights: thread t copies float4 words t + 256*n; input window: wave-level items of 64 consecutive
     // window slots of one channel, item -> wave item%4; items past n_items land in pad rows.
     f32x4 ra[GA];
-    float rx[GX];
+    float rx[GXX];
     // loop-invariant part of the window reads: item i of this wave covers channel xc[i] (wave-uniform) of the reduction block and
     // the 64 window slots starting at xj[i]; its lanes read x[clamp(xs0 + slot)] = xg[i] of that channel row
     unsigned xg[NX];
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
             xg[i] = (unsigned)min(sg, p.Bc - 1 - b) * (unsigned)p.x_bstride + (unsigned)min(max(q, 0), p.in_L - 1);
         }
     }
-    auto issue_group_to = [&](int cbn, auto gtag, f32x4 (&ra)[GA], float (&rx)[GX]) __attribute__((always_inline)) {
+    auto issue_group_to = [&](int cbn, auto gtag, f32x4 (&ra)[GA], float (&rx)[GXX]) __attribute__((always_inline)) {
         constexpr int g = decltype(gtag)::value;
         const f32x4* src = wbase + (size_t)cbn * A_VEC;
 #ifdef NC_A_DMA
@@ -253,6 +263,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 rx[u] = (float)xg[i];
 #else
                 rx[u] = row[xg[i]];
+                if constexpr (IN2) rx[GX + u] = (xb2 + (size_t)((unsigned)ci * x_cstride))[xg[i]];
 #endif
             }
         });
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     };
     auto issue_group = [&](int cbn, auto gtag) __attribute__((always_inline)) { issue_group_to(cbn, gtag, ra, rx); };
     auto store_group_from = [&](int cbn, float* Ad, float* Xd, auto gtag, auto snake_tag, const f32x4 (&ra)[GA],
-                                const float (&rx)[GX]) __attribute__((always_inline)) {
+                                const float (&rx)[GXX]) __attribute__((always_inline)) {
         constexpr int g = decltype(gtag)::value;
         constexpr int IMODE = (int)decltype(snake_tag)::value;   // 0 plain, 1 (true_type) Snake, 2 Encodec input mode
         constexpr bool SNAKE = IMODE == 1;
@@ -299,12 +310,14 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
             }
         });
         float2 al[GX];
+        float2 al2[IN2 ? GX : 1];
         if (SNAKE || (IMODE == 2 && (in_mode & 1))) {
             nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
                 constexpr int u = decltype(ut)::value, i = g * GX + u;
                 if constexpr (i < NX) {
                     const int item = swave + SW * i;
                     al[u] = Al[cbn * CB + ((item * chunk_magic) >> 20)];
+                    if constexpr (IN2) al2[u] = Al2[cbn * CB + ((item * chunk_magic) >> 20)];
                 }
             });
         }
@@ -321,6 +334,11 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 if constexpr (IMODE == 2) {
                     float t = rx[u];
                     if (in_mode & 1) t = ((t - in_mu) * in_rs) * al[u].x + al[u].y;   // GroupNorm(1,C) apply (NormConv1d.cs:155)
+                    if constexpr (IN2) {   // shortcut + branch (SEANetResnetBlock.cs:84): each normalised with its own statistics, then added
+                        float t2 = rx[GX + u];
+                        if (in_mode & 1) t2 = ((t2 - in_mu2) * in_rs2) * al2[u].x + al2[u].y;
+                        t = t + t2;
+                    }
                     if (in_mode & 2) t = nc_eluf(t);
                     v[u] = ok ? t : 0.0f;                                                // the pad zero-extends the ACTIVATED row
                 } else {
@@ -367,7 +385,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     // the two LDS tables -- is issued before anything waits: one memory round trip in all.
     {
         f32x4 ra0[NG][GA];
-        float rx0[NG][GX];
+        float rx0[NG][GXX];
         if (!SPEC || producer)
             nc_static_for<NG>([&](auto g) __attribute__((always_inline)) { issue_group_to(0, g, ra0[decltype(g)::value], rx0[decltype(g)::value]); });
         // Snake alphas of all input channels -> (alpha, 1/alpha), 4 reads per thread in flight per pass
@@ -385,6 +403,8 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         if (in_mode & 1) {   // (gamma, beta) of the pending GroupNorm, per input channel, in the Snake table's place
             const int n_al = n_cb * CB;
             for (int i = tid; i < n_al; i += NT) Al[i] = make_float2(p.in_gamma[min(i, Cin - 1)], p.in_beta[min(i, Cin - 1)]);
+            if constexpr (IN2)
+                for (int i = tid; i < n_al; i += NT) Al2[i] = make_float2(p.in_gamma2[min(i, Cin - 1)], p.in_beta2[min(i, Cin - 1)]);
         }
         for (int i = tid; i < BM; i += NT) {
             const int co = SUB ? min((co_tile * BM + i) >> p.sub_shift, (p.Cout >> p.sub_shift) - 1) : min(co_tile * BM + i, p.Cout - 1);
@@ -462,7 +482,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
             // waves run at raised issue priority: their short vector instructions are not starved by the consumers' matrix stream.
             __builtin_amdgcn_s_setprio(3);
             f32x4 pa[2][GA];
-            float px[2][GX];
+            float px[2][GXX];
             if (n_cb > 1) issue_group_to(1, std::integral_constant<int, 0>{}, pa[0], px[0]);
             for (int cb = 0; cb < n_cb; ++cb) {
                 const int cur = cb & 1;
@@ -810,6 +830,39 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         });
     };
 
+    if constexpr (!FUSE && !SPEC && !DIST) {
+        // GroupNorm(1,C) block sums of the output (Encodec's NormConv1d, NormConv1d.cs:155): every 32x32 accumulator tile is reduced in
+        // registers in the canonical order of nc_gn.h and leaves ONE (S1, S2) pair -- the tensor is not read back for its statistics.
+        if (p.gn_part != nullptr) {
+            double* const gp = p.gn_part + (int64_t)b * p.gn_nrb * p.gn_ncb * 2;
+            auto gn_blocks = [&](auto full_tag) __attribute__((always_inline)) {
+                constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        float vv[16];
+                        unsigned okm16 = 0;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int R = i * 32 + (r & 3) + 8 * (r >> 2);
+                            vv[r] = acc[i][j][r] + Ep[R + 4 * hi];
+                            if constexpr (!FULL)
+                                if (okrow(j, R)) okm16 |= 1u << r;
+                        }
+                        double s1, s2;
+                        nc_gn_slot_sums<FULL>(vv, okm16, s1, s2);
+                        nc_gn_butterfly(s1, s2);
+                        const int rbk = co_tile * TM + i, cbk = (col0 + wave * BNW + j * 32) >> 5;
+                        if (lane == 0 && rbk < p.gn_nrb && cbk < p.gn_ncb)
+                            *reinterpret_cast<double2*>(gp + ((int64_t)rbk * p.gn_ncb + cbk) * 2) = double2{s1, s2};
+                        __builtin_amdgcn_sched_barrier(0);   // one block at a time: the sums of several blocks in flight spill
+                    }
+            };
+            if (tile_full) gn_blocks(std::true_type{});
+            else gn_blocks(std::false_type{});
+        }
+    }
     if constexpr (!FUSE) {
         // phase A: every global read of the epilogue (residual tile, noise row), folded into the accumulators; phase B: stores only.
         // The rare RVQ-accumulate / noise-injection epilogues take the generic instance, everything else the lean one.
@@ -996,9 +1049,10 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
 
 typedef void (*conv_kernel_fn)(const ConvArgs);
 
-template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0, bool DIST = false, bool SUB = false>
+template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0, bool DIST = false, bool SUB = false,
+          bool IN2 = false>
 inline conv_kernel_fn get_conv_kernel() {
-    return &conv_mfma_kernel<TM, TN, K, CB, NX, FUSE, OCC, NW, NP, DIST, SUB>;
+    return &conv_mfma_kernel<TM, TN, K, CB, NX, FUSE, OCC, NW, NP, DIST, SUB, IN2>;
 }
 
 }  // namespace nc
@@ -1021,6 +1075,21 @@ inline conv_kernel_fn get_conv_kernel() {
     }                                                                                                      \
     int conv_kernel_cb_k##KVAL() { return CBVAL; }                                                         \
     int conv_kernel_nx_k##KVAL() { return NXVAL; }                                                         \
+    }
+
+// Two-input variants of the Encodec input mode (IN2): the strided down-convolutions and the up-convolutions that consume the sum of a
+// residual block's shortcut and branch.  SUBV selects the sub-pixel form.
+#define NC_INSTANTIATE_CONV_IN2(NAME, KVAL, CBVAL, NXVAL, SUBV)                                            \
+    namespace nc {                                                                                         \
+    conv_kernel_fn conv_kernel_table_##NAME(int TM, int TN) {                                              \
+        switch (TM * 10 + TN) {                                                                            \
+            case 11: return get_conv_kernel<1, 1, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, SUBV, true>(); \
+            case 12: return get_conv_kernel<1, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, SUBV, true>(); \
+            case 21: return get_conv_kernel<2, 1, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, SUBV, true>(); \
+            case 22: return get_conv_kernel<2, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, SUBV, true>(); \
+        }                                                                                                  \
+        return nullptr;                                                                                    \
+    }                                                                                                      \
     }
 
 // Sub-pixel transposed-convolution variants (stride 2 / 4 / 8 up-convolutions: rows = (channel, phase) pairs).

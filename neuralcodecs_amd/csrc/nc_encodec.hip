@@ -11,13 +11,13 @@
 #include <cmath>
 #include <cstdlib>
 
+#include "nc_gn.h"
 #include "nc_math.h"
 #include "nc_model.h"
 
 namespace nc {
 
 constexpr int GN_CHUNK = 256;    // RMS-scale chunks
-constexpr int GNS_CHUNK = 1024;  // GroupNorm chunk: 64 slots x 16 strided samples
 
 // ---------------------------------------------------------------------------------------------- kernels
 struct ActView {          // [B,C,L] view of a raw conv output with its pending GroupNorm (applied by the consumer)
@@ -76,66 +76,59 @@ __global__ __launch_bounds__(256) void pad_act_kernel(ActView a, ActView b2, int
     }
 }
 
-// Chunk sums of the GroupNorm statistics, canonical order (identical in oracle/c/nc_ref_encodec.c chunk_sums): a chunk is 1024
-// aligned samples of one row; lane i of a wavefront adds samples i, i+64, ..., i+960 of the chunk (ascending, binary64, from +0),
-// then the 64 lane sums are combined by the xor butterfly 32,16,8,4,2,1 (p_i <- p_i + p_{i^off}; addition commutes, so every lane
-// ends with the same value).  One wavefront per chunk: 16 coalesced 256-byte reads in flight, one butterfly per 4 KB, no LDS -- a
-// streaming pass (the tensor was just written by the conv and is largely still in L2 / the 256 MB Infinity Cache).
-__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int64_t rows, int64_t T, int nchunk) {
-    const int lane = threadIdx.x & 63;
-    const int64_t total = rows * nchunk;
-    const int64_t ci = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ci >= total) return;
-    const int64_t r = ci / nchunk, ch = ci - r * nchunk;
-    const float* row = x + r * T;
+// Stand-alone GroupNorm block sums in the canonical order of nc_gn.h, for the outputs whose producing kernel cannot emit them from
+// its epilogue (the streaming thin-output head, per-phase transposed launches): one wavefront per 32x32 block of the (rows = c*sub +
+// t % sub, columns = t / sub) view of x [B][C][T]; lane (h, c) adds its 16 rows of column c, then the butterfly.
+__global__ __launch_bounds__(256) void gn_block_kernel(const float* __restrict__ x, double* __restrict__ part, int64_t B, int C, int64_t T, int sub,
+                                                       int nrb, int ncb) {
+    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+    const int64_t total = B * nrb * ncb;
+    const int64_t bi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bi >= total) return;
+    const int64_t b = bi / ((int64_t)nrb * ncb), rem = bi - b * nrb * ncb;
+    const int rb = (int)(rem / ncb), cb = (int)(rem - (int64_t)rb * ncb);
+    const float* xb = x + b * C * T;
+    const int64_t q = (int64_t)cb * 32 + c;
     float v[16];
+    unsigned okm = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int64_t t = ch * GNS_CHUNK + j * 64 + lane;
-        v[j] = t < T ? row[t] : 0.0f;
+    for (int r = 0; r < 16; ++r) {
+        const int R = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int co = R / sub;
+        const int64_t t = q * sub + (R - co * sub);
+        const bool ok = co < C && t < T;
+        v[r] = ok ? xb[(int64_t)co * T + t] : 0.0f;
+        if (ok) okm |= 1u << r;
     }
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const double d = (double)v[j];
-        s1 += d;
-        s2 += d * d;
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        s1 += __shfl_xor(s1, off, 64);
-        s2 += __shfl_xor(s2, off, 64);
-    }
+    double s1, s2;
+    nc_gn_slot_sums<false>(v, okm, s1, s2);
+    nc_gn_butterfly(s1, s2);
     if (lane == 0) {
-        part[2 * ci] = s1;
-        part[2 * ci + 1] = s2;
+        part[2 * bi] = s1;
+        part[2 * bi + 1] = s2;
     }
 }
-// one block per sample: row totals (chunks ascending) in parallel, then rows ascending by one thread -> (mean, rstd)
-__global__ __launch_bounds__(256) void gn_final_kernel(const double* __restrict__ part, float* __restrict__ stats, int C, int64_t T,
-                                                       int nchunk) {
-    extern __shared__ double rsum[];   // [2*C]
-    const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const double* p = part + 2 * ((int64_t)(b * C + c) * nchunk);
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < nchunk; ++k) {
-            s1 += p[2 * k];
-            s2 += p[2 * k + 1];
+// one wavefront per sample: the n block sums of the sample by 64 strided slots (slot i: idx = i, i+64, ... ascending) + butterfly
+// -> (mean, rstd); count = C*T elements
+__global__ __launch_bounds__(64) void gn_final_kernel(const double* __restrict__ part, float* __restrict__ stats, int64_t n, double count) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const double* p = part + 2 * (int64_t)b * n;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t k0 = 0; k0 < n; k0 += 64 * 8) {   // 8 independent 16-byte reads in flight per lane
+        double a[8], c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t k = k0 + lane + 64 * u;
+            const double2 v = k < n ? *reinterpret_cast<const double2*>(p + 2 * k) : double2{0.0, 0.0};
+            a[u] = v.x; c[u] = v.y;
         }
-        rsum[2 * c] = s1;
-        rsum[2 * c + 1] = s2;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s1 += a[u]; s2 += c[u]; }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double S1 = 0.0, S2 = 0.0;
-        for (int c = 0; c < C; ++c) {
-            S1 += rsum[2 * c];
-            S2 += rsum[2 * c + 1];
-        }
-        const double N = (double)C * (double)T;
-        const double mu = S1 / N;
-        double var = S2 / N - mu * mu;
+    nc_gn_butterfly(s1, s2);
+    if (lane == 0) {
+        const double mu = s1 / count;
+        double var = s2 / count - mu * mu;
         if (var < 0.0) var = 0.0;
         stats[2 * b] = (float)mu;
         stats[2 * b + 1] = (float)(1.0 / sqrt(var + 1e-5));
@@ -912,18 +905,31 @@ float* EncodecModel::pad_act(const Act& a, const Act* b2, bool elu, int N, const
     return dst;
 }
 
-const float* EncodecModel::gn_stats(const float* raw, int N, int C, int64_t L) {
-    if (!cfg.time_group_norm) return nullptr;
-    const int nchunk = (int)((L + GNS_CHUNK - 1) / GNS_CHUNK);
-    const int64_t nparts = (int64_t)N * C * nchunk;
-    double* part = reinterpret_cast<double*>(alloc((size_t)nparts * 4));
-    float* stats = alloc((size_t)N * 2);
-    {
-        ProfScope ps(&prof, stream, NC_KC_NORM, 3.0 * N * C * (double)L, 4.0 * N * C * (double)L);
-        hipLaunchKernelGGL(gn_partial_kernel, dim3((unsigned)((nparts + 3) / 4)), dim3(256), 0, stream, raw, part, (int64_t)N * C, L,
-                           nchunk);
+// GroupNorm(1,C) statistics of a raw conv output [N,C,L] (NormConv1d.cs:155).  gn_begin sizes the block-sum buffer and, when the
+// producing launch can emit the sums from its epilogue, hands the buffer to it (ConvIO::gn_part); gn_end runs the stand-alone block
+// pass otherwise and then the per-sample final: (mean, rstd) pairs the consumer applies while staging its input.
+EncodecModel::GnJob EncodecModel::gn_begin(const ConvLayer& conv, ConvIO& io, int N, int C, int64_t L, int sub) {
+    GnJob j;
+    if (!cfg.time_group_norm) return j;
+    j.on = true; j.sub = sub;
+    j.nrb = (int)(((int64_t)C * sub + 31) / 32);
+    j.ncb = (int)(((L + sub - 1) / sub + 31) / 32);
+    j.part = reinterpret_cast<double*>(alloc((size_t)N * j.nrb * j.ncb * 4));
+    if (conv_gn_fusable(conv, io)) {
+        io.gn_part = j.part; io.gn_nrb = j.nrb; io.gn_ncb = j.ncb;
+        j.fused = true;
     }
-    hipLaunchKernelGGL(gn_final_kernel, dim3((unsigned)N), dim3(256), (size_t)2 * C * sizeof(double), stream, part, stats, C, L, nchunk);
+    return j;
+}
+const float* EncodecModel::gn_end(const GnJob& j, const float* raw, int N, int C, int64_t L) {
+    if (!j.on) return nullptr;
+    float* stats = alloc((size_t)N * 2);
+    const int64_t n = (int64_t)j.nrb * j.ncb;
+    ProfScope ps(&prof, stream, NC_KC_NORM, 3.0 * N * C * (double)L, j.fused ? 16.0 * N * (double)n : 4.0 * N * C * (double)L);
+    if (!j.fused)
+        hipLaunchKernelGGL(gn_block_kernel, dim3((unsigned)(((int64_t)N * n + 3) / 4)), dim3(256), 0, stream, raw, j.part, (int64_t)N, C, L, j.sub, j.nrb,
+                           j.ncb);
+    hipLaunchKernelGGL(gn_final_kernel, dim3((unsigned)N), dim3(64), 0, stream, j.part, stats, n, (double)C * (double)L);
     NC_HIP(hipGetLastError());
     return stats;
 }
@@ -944,13 +950,22 @@ static void fused_input(ConvIO& io, const EncodecModel::Act& a, bool elu, const 
     }
 }
 
+// second operand of a two-input layer (the branch of a residual block beside its shortcut): same geometry, own pending GroupNorm
+static void second_input(ConvIO& io, const EncodecModel::Act& b2) {
+    io.x2 = b2.p + b2.off;
+    io.in_stats2 = b2.stats; io.in_gamma2 = b2.stats ? b2.gamma : nullptr; io.in_beta2 = b2.stats ? b2.beta : nullptr;
+}
+
 EncodecModel::Act EncodecModel::sconv(SConv& L, const Act& a, const Act* b2, bool elu, int N) {
     const Plan pl = plan_sconv(a.L, L.K, L.stride, 1);
     static const bool no_fuse = std::getenv("NC_ENCODEC_NO_FUSE") && std::getenv("NC_ENCODEC_NO_FUSE")[0] == '1';
     float* y = nullptr;
     ConvIO io{};
-    if (!b2 && !no_fuse && pl.Lp < ((int64_t)1 << 30)) {
+    const bool two_in = b2 && !no_fuse && conv_in2_available(L.conv) && b2->C == a.C && b2->L == a.L && b2->rs == a.rs &&
+                        (a.stats != nullptr) == (b2->stats != nullptr);
+    if ((!b2 || two_in) && !no_fuse && pl.Lp < ((int64_t)1 << 30)) {
         fused_input(io, a, elu, &pl);
+        if (two_in) second_input(io, *b2);
         y = alloc((size_t)N * L.Cout * pl.Lout);
     } else {
         const bool passthrough = !b2 && !elu && !a.stats && pl.left == 0 && pl.Lp == a.L && a.off == 0 && a.rs == a.L;
@@ -959,10 +974,11 @@ EncodecModel::Act EncodecModel::sconv(SConv& L, const Act& a, const Act* b2, boo
         io.x = xin; io.x_bstride = (int64_t)L.Cin * pl.Lp; io.x_cstride = pl.Lp; io.x_len = (int32_t)pl.Lp; io.Tin = pl.Lp;
     }
     io.y = y; io.y_bstride = (int64_t)L.Cout * pl.Lout; io.y_cstride = pl.Lout;
+    const GnJob gj = gn_begin(L.conv, io, N, L.Cout, pl.Lout, 1);
     launch_conv(L.conv, io, N, stream, &prof);
     Act o;
     o.p = y; o.C = L.Cout; o.L = pl.Lout; o.rs = pl.Lout; o.off = 0;
-    o.stats = gn_stats(y, N, L.Cout, pl.Lout);
+    o.stats = gn_end(gj, y, N, L.Cout, pl.Lout);
     o.gamma = o.stats ? L.gamma.as<float>() : nullptr;
     o.beta = o.stats ? L.beta.as<float>() : nullptr;
     return o;
@@ -973,8 +989,11 @@ EncodecModel::Act EncodecModel::sconvT(SConv& L, const Act& a, const Act* b2, bo
     static const bool no_fuse = std::getenv("NC_ENCODEC_NO_FUSE") && std::getenv("NC_ENCODEC_NO_FUSE")[0] == '1';
     const int64_t Lfull = (a.L - 1) * L.stride + L.K;
     ConvIO io{};
-    if (!b2 && !no_fuse) {
+    const bool two_in = b2 && !no_fuse && conv_in2_available(L.conv) && b2->C == a.C && b2->L == a.L && b2->rs == a.rs &&
+                        (a.stats != nullptr) == (b2->stats != nullptr);
+    if ((!b2 || two_in) && !no_fuse) {
         fused_input(io, a, elu, nullptr);
+        if (two_in) second_input(io, *b2);
     } else {
         Plan pl; pl.left = 0; pl.right = 0; pl.Lz = a.L; pl.Lp = a.L; pl.Lout = a.L;
         const float* xin = pad_act(a, b2, elu, N, pl);
@@ -982,6 +1001,8 @@ EncodecModel::Act EncodecModel::sconvT(SConv& L, const Act& a, const Act* b2, bo
     }
     float* y = alloc((size_t)N * L.Cout * Lfull);
     io.y = y; io.y_bstride = (int64_t)L.Cout * Lfull; io.y_cstride = Lfull;
+    // (the block view of the statistics follows the layer geometry, not the kernel form: the same sums under NC_NO_SUBPIXEL)
+    const GnJob gj = gn_begin(L.conv, io, N, L.Cout, Lfull, conv_gn_sub(L.K, L.stride, L.Cout, true));
     launch_conv(L.conv, io, N, stream, &prof);
     const int64_t pt = L.K - L.stride;
     int64_t right, left;
@@ -989,7 +1010,7 @@ EncodecModel::Act EncodecModel::sconvT(SConv& L, const Act& a, const Act* b2, bo
     else { right = pt / 2; left = pt - right; }
     Act o;
     o.p = y; o.C = L.Cout; o.L = Lfull - left - right; o.rs = Lfull; o.off = left;
-    o.stats = gn_stats(y, N, L.Cout, Lfull);
+    o.stats = gn_end(gj, y, N, L.Cout, Lfull);
     o.gamma = o.stats ? L.gamma.as<float>() : nullptr;
     o.beta = o.stats ? L.beta.as<float>() : nullptr;
     return o;

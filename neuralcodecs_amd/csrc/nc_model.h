@@ -258,7 +258,9 @@ struct EncodecModel : Codec {
     void load_lstm(const Blob& b, const std::string& key, Lstm& l, int C);
     float* alloc(size_t n_floats);
     float* pad_act(const Act& a, const Act* b2, bool elu, int N, const Plan& pl);
-    const float* gn_stats(const float* raw, int N, int C, int64_t L);
+    struct GnJob { bool on = false, fused = false; int sub = 1, nrb = 0, ncb = 0; double* part = nullptr; };
+    GnJob gn_begin(const ConvLayer& conv, ConvIO& io, int N, int C, int64_t L, int sub);
+    const float* gn_end(const GnJob& j, const float* raw, int N, int C, int64_t L);
     Act sconv(SConv& L, const Act& a, const Act* b2, bool elu, int N);
     Act sconvT(SConv& L, const Act& a, const Act* b2, bool elu, int N);
     void resblock(ResBlock& r, const Act& x, int N, Act& s, Act& y);

@@ -14,9 +14,9 @@
  *   AudioTools/AudioTensorDSP.cs:161-261 (LinearOverlapAdd), Utils/TorchUtils.cs:26-30 (ELU, alpha = 1)
  *
  * Canonical definitions added here:
- *   GroupNorm(1,C):  S1 = sum x, S2 = sum x*x in binary64, summed hierarchically: 1024-sample chunks of one channel row (chunk_sums:
- *                    64 strided slot sums + xor butterfly),
- *                    chunks of a row ascending, rows ascending.  mu = S1/N, var = max(S2/N - mu*mu, 0), r = (float)(1/sqrt(var + 1e-5)),
+ *   GroupNorm(1,C):  S1 = sum x, S2 = sum x*x in binary64, summed hierarchically over 32x32 blocks in the accumulator layout of the
+ *                    fp32 matrix-core instruction (gn_sums / block_sums below: 16-row slot sums, xor butterfly, then the block sums of a
+ *                    sample by 64 strided slots + butterfly).  mu = S1/N, var = max(S2/N - mu*mu, 0), r = (float)(1/sqrt(var + 1e-5)),
  *                    y = ((x - (float)mu) * r) * gamma[c] + beta[c]
  *   ELU:             x > 0 ? x : exp(x) - 1
  *   LSTM cell:       pre = (chain_ih + b_ih) + (chain_hh + b_hh); chain_ih one fma chain (k ascending), chain_hh four quarter chains
@@ -88,48 +88,65 @@ static const float* get_weight(ref_encodec* m, const char* key, int* d0, int* d1
 
 /* ---- canonical reductions --------------------------------------------------------------------------- */
 #define GN_CHUNK 256     /* RMS-scale chunks */
-#define GNS_CHUNK 1024  /* GroupNorm chunks: 64 slots x 16 strided samples */
-/* One chunk (n <= 1024 samples): slot i of 64 adds samples i, i+64, ..., i+960 (ascending, binary64, from +0); the 64 slot sums are
- * combined by the xor butterfly 32,16,8,4,2,1 (p_i <- p_i + p_{i^off}).  A fixed tree of the width of a CDNA wavefront: the device
- * kernel runs it with one lane per slot. */
-static void chunk_sums(const float* x, int64_t n, double* s1_out, double* s2_out) {
-    double p1[64], p2[64], q1[64], q2[64];
+/* xor butterfly 1,2,4,8,16,32 over 64 slot sums (p_i <- p_i + p_{i^off}; addition commutes, so every slot ends with the same value):
+ * a fixed tree of the width of a CDNA wavefront */
+static void butterfly64(double* p1, double* p2) {
+    double q1[64], q2[64];
+    for (int off = 1; off <= 32; off <<= 1) {
+        for (int i = 0; i < 64; i++) { q1[i] = p1[i] + p1[i ^ off]; q2[i] = p2[i] + p2[i ^ off]; }
+        memcpy(p1, q1, sizeof q1); memcpy(p2, q2, sizeof q2);
+    }
+}
+
+/* GroupNorm(1,C) sums of one sample y [C][T], canonical order.  The tensor is viewed as the matrix the matrix-core kernels emit it from:
+ * rows R = c*sub + (t % sub), columns q = t / sub, with sub = 1 for every convolution and sub = stride behind a stride-2/4/8 transposed
+ * convolution with k = 2*stride (its sub-pixel form: rows are (channel, phase) pairs).  The matrix is cut into 32x32 blocks (row block rb,
+ * column block cb, aligned at row 0 / column 0; elements outside the tensor count as +0).  Inside a block, slot i = 32*h + c (h = 0,1;
+ * c = 0..31) adds the 16 elements of column 32*cb + c in rows 32*rb + 8*j + 4*h + k (j = 0..3 outer, k = 0..3 inner: ascending rows),
+ * binary64 from +0 (squares are exact in binary64), and the 64 slot sums meet in the xor butterfly 1,2,4,8,16,32 -- the accumulator layout
+ * of v_mfma_f32_32x32x2_f32, so a wavefront reduces the block it has just computed without moving a value.  The block sums of a sample,
+ * listed as idx = rb*ncb + cb, are then added by 64 slots (slot i: idx = i, i+64, ... ascending) and one more butterfly. */
+static int gn_sub_for(int k, int stride, int cout) {
+    return ((stride == 2 || stride == 4 || stride == 8) && k == 2 * stride && (cout * stride) % 32 == 0) ? stride : 1;
+}
+static void block_sums(const float* y, int C, int64_t T, int sub, int64_t rb, int64_t cb, double* s1_out, double* s2_out) {
+    double p1[64], p2[64];
     for (int i = 0; i < 64; i++) {
+        const int h = i >> 5, c = i & 31;
+        const int64_t q = cb * 32 + c;
         double a = 0.0, b = 0.0;
-        for (int j = 0; j < GNS_CHUNK / 64; j++) {
-            const int64_t t = i + 64 * j;
-            if (t < n) { const double v = (double)x[t]; a += v; b += v * v; }
+        for (int r = 0; r < 16; r++) {
+            const int64_t R = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int64_t co = R / sub, t = q * sub + R % sub;
+            if (co < C && t < T) { const double v = (double)y[co * T + t]; a += v; b += v * v; }
         }
         p1[i] = a; p2[i] = b;
     }
-    for (int off = 32; off >= 1; off >>= 1) {
-        for (int i = 0; i < 64; i++) { q1[i] = p1[i] + p1[i ^ off]; q2[i] = p2[i] + p2[i ^ off]; }
-        memcpy(p1, q1, sizeof p1); memcpy(p2, q2, sizeof p2);
+    butterfly64(p1, p2);
+    *s1_out = p1[0]; *s2_out = p2[0];
+}
+static void gn_sums(const float* y, int C, int64_t T, int sub, double* s1_out, double* s2_out) {
+    const int64_t nrb = ((int64_t)C * sub + 31) / 32, ncb = ((T + sub - 1) / sub + 31) / 32, n = nrb * ncb;
+    double* part = (double*)malloc(sizeof(double) * 2 * (size_t)n);
+    for (int64_t rb = 0; rb < nrb; rb++)
+        for (int64_t cb = 0; cb < ncb; cb++) block_sums(y, C, T, sub, rb, cb, &part[2 * (rb * ncb + cb)], &part[2 * (rb * ncb + cb) + 1]);
+    double p1[64], p2[64];
+    for (int i = 0; i < 64; i++) {
+        double a = 0.0, b = 0.0;
+        for (int64_t k = i; k < n; k += 64) { a += part[2 * k]; b += part[2 * k + 1]; }
+        p1[i] = a; p2[i] = b;
     }
+    butterfly64(p1, p2);
+    free(part);
     *s1_out = p1[0]; *s2_out = p2[0];
 }
 
-/* S1, S2 of rows x[r*T .. r*T+T) for r in [0,R): chunk -> row -> total, all binary64, ascending */
-static void hier_sums(const float* x, int64_t R, int64_t T, double* s1_out, double* s2_out) {
-    double S1 = 0.0, S2 = 0.0;
-    for (int64_t r = 0; r < R; r++) {
-        double r1 = 0.0, r2 = 0.0;
-        for (int64_t t0 = 0; t0 < T; t0 += GNS_CHUNK) {
-            const int64_t t1 = t0 + GNS_CHUNK < T ? t0 + GNS_CHUNK : T;
-            double c1, c2;
-            chunk_sums(x + r * T + t0, t1 - t0, &c1, &c2);
-            r1 += c1; r2 += c2;
-        }
-        S1 += r1; S2 += r2;
-    }
-    *s1_out = S1; *s2_out = S2;
-}
-
-REF_API void ref_group_norm1(const float* x, int64_t B, int C, int64_t T, const float* gamma, const float* beta, float* y) {
+/* GroupNorm(1,C) over x [B,C,T] (NormConv1d.cs:155); `sub` selects the canonical block view (gn_sums) */
+REF_API void ref_group_norm1(const float* x, int64_t B, int C, int64_t T, int sub, const float* gamma, const float* beta, float* y) {
 #pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < B; b++) {
         double s1, s2;
-        hier_sums(x + b * C * T, C, T, &s1, &s2);
+        gn_sums(x + b * C * T, C, T, sub < 1 ? 1 : sub, &s1, &s2);
         const double N = (double)C * (double)T;
         const double mu = s1 / N;
         double var = s2 / N - mu * mu;
@@ -190,7 +207,7 @@ static float* sconv(ref_encodec* m, const char* key, const float* x, int64_t B, 
     if (m->cfg.group_norm) {
         snprintf(nm, sizeof nm, "%s.norm.weight", key); const float* g = getf(m, nm, d0);
         snprintf(nm, sizeof nm, "%s.norm.bias", key); const float* b = getf(m, nm, d0);
-        if (g && b) ref_group_norm1(y, B, d0, p.Lout, g, b, y);
+        if (g && b) ref_group_norm1(y, B, d0, p.Lout, 1, g, b, y);
     }
     *Cout = d0; *Lout = p.Lout;
     return y;
@@ -210,7 +227,7 @@ static float* sconvT(ref_encodec* m, const char* key, const float* x, int64_t B,
     if (m->cfg.group_norm) {
         snprintf(nm, sizeof nm, "%s.norm.weight", key); const float* g = getf(m, nm, d1);
         snprintf(nm, sizeof nm, "%s.norm.bias", key); const float* b = getf(m, nm, d1);
-        if (g && b) ref_group_norm1(y, B, d1, Lfull, g, b, y);
+        if (g && b) ref_group_norm1(y, B, d1, Lfull, gn_sub_for(k, stride, d1), g, b, y);
     }
     const int64_t pt = k - stride;
     int64_t right, left;

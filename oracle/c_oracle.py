@@ -88,7 +88,7 @@ def lib():
         L.ref_encodec_encode_frame.argtypes = [C.c_void_p, f32p, C.c_int64, C.c_int64, C.c_int, i64p, C.c_void_p, C.c_void_p]
         L.ref_encodec_decode_frame.argtypes = [C.c_void_p, i64p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, f32p, C.c_void_p]
         L.ref_linear_overlap_add.argtypes = [f32p, i64p, i64p, C.c_int, C.c_int64, C.c_int64, f32p, C.c_int64]
-        L.ref_group_norm1.argtypes = [f32p, C.c_int64, C.c_int, C.c_int64, f32p, f32p, f32p]
+        L.ref_group_norm1.argtypes = [f32p, C.c_int64, C.c_int, C.c_int64, C.c_int, f32p, f32p, f32p]
         _lib = L
     return _lib
 

@@ -31,8 +31,19 @@ def timed(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
+def class_table(m, fn, steps):
+    """per-class HIP-event times of `steps` rounds (the engine's profiler: event pairs around every launch)"""
+    m.profile_enable(True)
+    m.profile_reset()
+    timed(fn, steps, 0)
+    prof = m.profile_read()
+    m.profile_enable(False)
+    return {n: {"ms": round(v["ms"] / steps, 4), "launches": round(v["launches"] / steps, 1)} for n, v in prof.items() if v["launches"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--classes", action="store_true", help="also print the per-class kernel times")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--only", default="")
@@ -51,6 +62,8 @@ def main():
             nz = [torch.from_numpy(n).to(dev) for n in snac_noise(cfg, B, frames, seed=3)]
             dt = timed(lambda: m.decode(m.encode(x), nz), a.steps, a.warmup)
             out[name] = {"ms": round(dt * 1e3, 3), "x_realtime": round(B * secs / dt, 1), "B": B, "seconds": secs}
+            if a.classes:
+                out[name]["classes"] = class_table(m, lambda: m.decode(m.encode(x), nz), a.steps)
             m.dispose()
     if not a.only or "encodec" in a.only:
         for name, cfg, B, secs in (("encodec48k_c3", EncodecConfig.encodec_48khz(), 16, 2.0), ("encodec24k", EncodecConfig.encodec_24khz(), 16, 2.0)):
@@ -62,6 +75,8 @@ def main():
             x = torch.from_numpy(synthetic_pcm(B, cfg.channels, T, cfg.sampling_rate, seed=1)).to(dev)
             dt = timed(lambda: m.decode(m.encode(x), T), a.steps, a.warmup)
             out[name] = {"ms": round(dt * 1e3, 3), "x_realtime": round(B * secs / dt, 1), "B": B, "seconds": secs}
+            if a.classes:
+                out[name]["classes"] = class_table(m, lambda: m.decode(m.encode(x), T), a.steps)
             m.dispose()
     print(json.dumps(out))
 
