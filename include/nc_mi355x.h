@@ -90,6 +90,12 @@ NC_API nc_status nc_blob_check(const void* blob, size_t nbytes, int32_t* n_tenso
 NC_API nc_status nc_codec_set_stream(nc_codec* h, void* hip_stream);
 NC_API nc_status nc_codec_reset_stream(nc_codec* h);
 NC_API nc_status nc_codec_synchronize(nc_codec* h);
+/* Errors raised by device code after a device-pointer call returned (today: the bounded spins of Encodec's persistent LSTM kernel, which
+ * needs its workgroups co-resident).  Non-blocking: call it once the caller knows the stream is idle (after its own stream / device
+ * synchronisation); nc_codec_synchronize and the host-pointer entry points check by themselves, and every device-pointer call checks
+ * for a failure of the previous one first.  NC_EDEVICE = the results of that call are invalid; the handle has switched to the
+ * step-wise kernels, so repeating the call succeeds (the host-pointer entry points repeat it themselves). */
+NC_API nc_status nc_codec_check_errors(nc_codec* h);
 
 /* Shape helper for DAC.Preprocess (Models/DAC.cs:141-154): padded length and frame count T'. */
 NC_API nc_status nc_dac_query(const nc_codec* h, int64_t T, int64_t* T_padded, int64_t* frames);
@@ -281,7 +287,8 @@ NC_API nc_status nc_audio_resample_linear_dev(int device_index, const float* in,
  * by side: Models/SNAC.cs:129-150), issued on a side stream per device behind the encode, so the local decode overlaps it.
  * librccl is opened at run time by these entry points only.
  *   rank  mode: one process per GPU; rank 0 draws a unique id (nc_group_unique_id) and hands it to the others out of band.
- *   local mode: one process drives ndev GPUs (handles[i] created on device i): the natural layout of a single C# host process. */
+ *   local mode: one process drives ndev GPUs (handles[i] created on device i): the natural layout of a single C# host process.
+ * Lifetime: a group BORROWS its codec handles -- destroy the group (nc_group_destroy) before the codecs it was created over. */
 typedef struct nc_group nc_group;
 #define NC_GROUP_UID_BYTES 128
 NC_API nc_status nc_group_unique_id(void* uid /* [NC_GROUP_UID_BYTES] */);
@@ -291,13 +298,16 @@ NC_API nc_status nc_group_destroy(nc_group* g);
 NC_API nc_status nc_group_info(const nc_group* g, int32_t* world, int32_t* rank /* -1 in local mode */);
 /* rank mode, device pointers, asynchronous: encode this rank's B_local clips (nc_dac_encode_dev / nc_snac_encode_dev semantics) with the
  * codes written straight into slot `rank` of codes_all [world*B_local, ...], then the in-place all-gather on the group's side stream.
+ * B_local must be the same on every rank (a ragged batch: pad the short shards to the longest one and drop the padding rows).
  * nc_group_wait makes the codec's stream wait for the gather (no host synchronisation). */
 NC_API nc_status nc_group_dac_encode_allgather_dev(nc_group* g, const float* pcm, int32_t B_local, int64_t T, int32_t sample_rate, int32_t n_q,
                                                    int64_t* codes_all, float* z_local, float* latents_local);
 NC_API nc_status nc_group_snac_encode_allgather_dev(nc_group* g, const float* pcm, int32_t B_local, int64_t T, int64_t* codes_all);
 NC_API nc_status nc_group_wait(nc_group* g);
-/* local mode, host pointers, synchronous: B_total clips split into contiguous equal blocks over the devices (B_total % ndev == 0);
- * codes [B_total, ...] come back gathered; z nullable [B_total, latent, T'] (each device returns its block). */
+/* local mode, host pointers, synchronous: B_total clips split into contiguous blocks over the devices (the first B_total % ndev devices
+ * hold one clip more; slots of the gathered buffer are sized for the largest block, so ragged batches gather in one collective);
+ * codes [B_total, ...] come back gathered in clip order; z nullable [B_total, latent, T'] (each device returns its block).  One host
+ * thread per device stages its block through pinned memory, so the uploads and encodes of all devices overlap. */
 NC_API nc_status nc_group_dac_encode_allgather(nc_group* g, const float* pcm, int32_t B_total, int64_t T, int32_t sample_rate, int32_t n_q,
                                                int64_t* codes, float* z);
 NC_API nc_status nc_group_snac_encode_allgather(nc_group* g, const float* pcm, int32_t B_total, int64_t T, int64_t* codes);

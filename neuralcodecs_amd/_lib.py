@@ -74,6 +74,7 @@ SYMBOLS = [
     ("nc_codec_set_stream", C.c_int, [_P, _P]),
     ("nc_codec_reset_stream", C.c_int, [_P]),
     ("nc_codec_synchronize", C.c_int, [_P]),
+    ("nc_codec_check_errors", C.c_int, [_P]),
     ("nc_dac_query", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("nc_dac_encode", C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P]),
     ("nc_dac_encode_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P]),
@@ -182,6 +183,11 @@ def check(status: int) -> None:
 
 class ProfileMixin:
     """HIP-event kernel-class profile of a codec handle (nc_codec_profile_*): the numbers bench.py's `roofline` objects come from."""
+
+    def check_errors(self) -> None:
+        """nc_codec_check_errors: device-side failures of an earlier device-pointer call (raises NcDeviceError); call it once the
+        caller's own synchronisation (torch.cuda.synchronize) has made the stream idle."""
+        check(lib().nc_codec_check_errors(self._h))
 
     def profile_enable(self, on: bool = True):
         check(lib().nc_codec_profile_enable(self._h, 1 if on else 0))

@@ -144,6 +144,13 @@ nc_status nc_codec_synchronize(nc_codec* h) {
     });
 }
 
+nc_status nc_codec_check_errors(nc_codec* h) {
+    return guard([&] {
+        if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");
+        h->impl->check_async_errors();
+    });
+}
+
 nc_status nc_dac_query(const nc_codec* h, int64_t T, int64_t* T_padded, int64_t* frames) {
     return guard([&] {
         DacModel& m = as_dac(const_cast<nc_codec*>(h));
@@ -439,12 +446,17 @@ nc_status nc_encodec_encode(nc_codec* h, const float* pcm, int32_t B, int64_t T,
                      n_emb = (size_t)B * m.cfg.dimension * fr * 4;
         m.h_in.reserve(n_in); m.h_codes.reserve(n_codes); m.h_scales.reserve(n_sc); m.h_emb.reserve(n_emb);
         h2d(m.h_in.p, pcm, n_in, m.stream);
-        m.encode_dev(m.h_in.as<float>(), B, T, m.h_codes.as<int64_t>(), m.h_scales.as<float>(), emb ? m.h_emb.as<float>() : nullptr);
+        for (int attempt = 0;; ++attempt) {
+            m.encode_dev(m.h_in.as<float>(), B, T, m.h_codes.as<int64_t>(), m.h_scales.as<float>(), emb ? m.h_emb.as<float>() : nullptr);
+            NC_HIP(hipStreamSynchronize(m.stream));
+            if (!m.lstm_timed_out() || attempt) break;
+            try { m.check_async_errors(); } catch (const Error&) {}   // clears the word, switches the handle to the step-wise LSTM: run again
+        }
+        m.check_async_errors();
         d2h(codes, m.h_codes.p, n_codes, m.stream);
         if (scales && m.cfg.normalize) d2h(scales, m.h_scales.p, n_sc, m.stream);
         if (emb) d2h(emb, m.h_emb.p, n_emb, m.stream);
         NC_HIP(hipStreamSynchronize(m.stream));
-        m.check_async_errors();
     });
 }
 
@@ -465,10 +477,15 @@ nc_status nc_encodec_decode(nc_codec* h, const int64_t* codes, const float* scal
         m.h_codes.reserve(n_codes); m.h_scales.reserve(n_sc); m.h_out.reserve(n_out);
         h2d(m.h_codes.p, codes, n_codes, m.stream);
         if (scales) h2d(m.h_scales.p, scales, n_sc, m.stream);
-        m.decode_dev(m.h_codes.as<int64_t>(), scales ? m.h_scales.as<float>() : nullptr, B, T, n_q, m.h_out.as<float>());
+        for (int attempt = 0;; ++attempt) {
+            m.decode_dev(m.h_codes.as<int64_t>(), scales ? m.h_scales.as<float>() : nullptr, B, T, n_q, m.h_out.as<float>());
+            NC_HIP(hipStreamSynchronize(m.stream));
+            if (!m.lstm_timed_out() || attempt) break;
+            try { m.check_async_errors(); } catch (const Error&) {}   // step-wise LSTM from here on: run again
+        }
+        m.check_async_errors();
         d2h(pcm, m.h_out.p, n_out, m.stream);
         NC_HIP(hipStreamSynchronize(m.stream));
-        m.check_async_errors();
     });
 }
 

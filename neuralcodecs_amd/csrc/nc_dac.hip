@@ -29,6 +29,8 @@ void Codec::init_device(int device_index) {
     NC_HIP(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         fail(NC_EDEVICE, "device %d is %s; this engine is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    cu_count = prop.multiProcessorCount;
+    lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
     NC_HIP(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
     stream = own_stream;
 }

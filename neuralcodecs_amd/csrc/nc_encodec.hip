@@ -237,8 +237,11 @@ typedef __attribute__((address_space(3))) void* lstm_lptr;
 //   * h_t of a column tile is exchanged between its C/16 workgroups through global memory with the placement-independent
 //     release/acquire protocol of cdna_hip_programming.md G16 (recipe R1): write-through (sc1) payload stores -> vmcnt(0) ->
 //     workgroup barrier -> one relaxed agent-scope flag store per workgroup; consumers poll the flags of their tile (one lane per
-//     producer, relaxed), then ONE agent-scope acquire fence, a workgroup barrier, and plain coalesced loads of the h tile
-//     (layout [unit][16 clips] = the B-fragment order: every operand load is a 256-byte row).  Double-buffered by step parity: a
+//     producer, relaxed), a workgroup barrier, and then read the h tile with relaxed AGENT-SCOPE (sc1) loads, which bypass the CU's L1
+//     and observe the producers' write-through stores directly -- the shipped build has NO acquire fence (the "sc1 stores and sc1
+//     loads both sides" form of MI355X_MICROARCH.md; ordering between the flag and the payload comes from the producer's vmcnt(0)
+//     drain before its flag store and the consumer's barrier before its loads).  -DNC_LSTM_FENCE builds the fence + plain-load
+//     variant (tools/probe/envmatrix.sh).  Layout [unit][16 clips] = the B-fragment order: every operand load is a 256-byte row.  Double-buffered by step parity: a
 //     workgroup can only publish h_{t+1} after every workgroup of the tile has published h_t, i.e. finished reading h_{t-1}.
 //   * Every spin is bounded: a timeout sets *tmo and all workgroups leave (the host reports NC_EDEVICE at the next synchronise).
 // Grid = (C/16, column tiles): at most 128 workgroups of 140 KB LDS per launch, all co-resident on the 256 CUs.
@@ -842,8 +845,15 @@ void EncodecModel::load(const Blob& b) {
     }
     snprintf(nm, sizeof nm, "decoder.layers.%d", n + 1);
     load_sconv(b, nm, dec_out, nf, cfg.channels, cfg.last_kernel_size, 1, false);
-    lstm_sync.reserve(4096);
-    NC_HIP(hipMemset(lstm_sync.p, 0, 4096));
+    if (!lstm_tmo_host) {
+        void* hp = nullptr;
+        NC_HIP(hipHostMalloc(&hp, 64, hipHostMallocMapped));
+        std::memset(hp, 0, 64);
+        lstm_tmo_host = static_cast<unsigned*>(hp);
+        void* dp = nullptr;
+        NC_HIP(hipHostGetDevicePointer(&dp, hp, 0));
+        lstm_tmo_dev = static_cast<unsigned*>(dp);
+    }
     if (!ev_fork) {
         for (int i = 0; i < 2; ++i) {
             NC_HIP(hipStreamCreateWithFlags(&side_stream[i], hipStreamNonBlocking));
@@ -866,16 +876,19 @@ EncodecModel::~EncodecModel() {
     for (hipEvent_t e : ola_ev)
         if (e) (void)hipEventDestroy(e);
     if (ola_pin) (void)hipHostFree(ola_pin);
+    if (lstm_tmo_host) (void)hipHostFree(lstm_tmo_host);
 }
 
+// Called where the host knows the stream is idle (nc_codec_synchronize, the host-pointer entry points, nc_codec_check_errors) and at the
+// start of every device-pointer call: a persistent LSTM launch that timed out invalidated the call it belonged to.  The handle then
+// switches to the step-wise kernels (fresh launches need no co-residency), so the caller's retry -- or, for the host-pointer entry
+// points, the engine's own -- succeeds.
 void EncodecModel::check_async_errors() {
-    if (!lstm_sync.p) return;
-    unsigned tmo = 0;
-    NC_HIP(hipMemcpy(&tmo, lstm_sync.p, 4, hipMemcpyDeviceToHost));
-    if (tmo) {
-        NC_HIP(hipMemset(lstm_sync.p, 0, 4));
-        fail(NC_EDEVICE, "persistent LSTM kernel: a workgroup exchange timed out (its workgroups were not co-resident); results of the call are invalid");
-    }
+    if (!lstm_timed_out()) return;
+    *reinterpret_cast<volatile unsigned*>(lstm_tmo_host) = 0;
+    lstm_force_stepwise = true;
+    fail(NC_EDEVICE, "persistent LSTM kernel: a workgroup exchange timed out (its workgroups were not co-resident); the results of that call are "
+                     "invalid -- this handle now runs the step-wise LSTM kernels, repeat the call");
 }
 
 // ---- launch helpers --------------------------------------------------------------------------------
@@ -1048,9 +1061,14 @@ __global__ void nct_to_ctn_kernel(const float* __restrict__ x, float* __restrict
 float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
     const int C = l.C;
     if (l.layers.empty()) return const_cast<float*>(x);
-    static const bool stepwise = std::getenv("NC_LSTM_STEPWISE") && std::getenv("NC_LSTM_STEPWISE")[0] == '1';
+    static const bool stepwise_env = std::getenv("NC_LSTM_STEPWISE") && std::getenv("NC_LSTM_STEPWISE")[0] == '1';
     const int KS = C / 4;
     const int nl = (int)l.layers.size();
+    // The persistent kernel needs every workgroup of a launch resident at once (one per CU at 140 KB of LDS): up to 64 per launch, two
+    // launches in flight when the layers are pipelined, beside a concurrent segment group.  Devices (or partitions) that cannot hold
+    // that, and handles that have seen a timeout, take the step-wise kernels.
+    const size_t lds_need = (size_t)4 * KS * 64 * 4 + 3 * 4 * 64 * 16;
+    const bool stepwise = stepwise_env || lstm_force_stepwise || cu_count < 192 || lds_per_cu < lds_need + 1024;
     auto ih_gemm = [&](LstmLayer& y, const float* in, float* gi, hipStream_t s) {
         ConvIO io{};   // W_ih * x_t + b_ih for all steps: one pointwise convolution over the [N,C,T] tensor
         io.x = in; io.x_bstride = (int64_t)C * T; io.x_cstride = T; io.x_len = (int32_t)T; io.Tin = T;
@@ -1077,7 +1095,11 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
         const bool piped = nch > 1;
         const int nprod = C / 16, n_tiles = (N + 15) / 16, per_launch = std::max(1, 64 / nprod);
         const size_t lds = (size_t)4 * KS * 64 * 4 + 3 * 4 * 64 * 16;
-        unsigned* sync = lstm_sync.as<unsigned>();                                     // [0] = timeout word (zeroed at load)
+        unsigned* sync = lstm_tmo_dev;                                                 // timeout word (host-visible)
+        {   // NC_LSTM_FAKE_TIMEOUT=1 (tests): the first persistent launch of the process is reported as timed out
+            static bool fake = std::getenv("NC_LSTM_FAKE_TIMEOUT") && std::getenv("NC_LSTM_FAKE_TIMEOUT")[0] == '1';
+            if (fake) { fake = false; *reinterpret_cast<volatile unsigned*>(lstm_tmo_host) = 1; }
+        }
         std::vector<float*> gi(nl), out(nl), hx(nl), cs(nl);
         std::vector<unsigned*> flags(nl);
         for (int li = 0; li < nl; ++li) {
@@ -1288,6 +1310,7 @@ void EncodecModel::encode_dev(const float* pcm, int B, int64_t T, int64_t* codes
     if (!pcm || !codes) fail(NC_EINVAL, "pcm and codes must not be null");
     if (B <= 0 || T <= 0 || T > ((int64_t)1 << 30)) fail(NC_EINVAL, "B and T must be positive");
     use_device();
+    check_async_errors();   // an earlier device-pointer call on this handle may have timed out unnoticed
     pool_i = 0;
     const std::vector<Seg> segs = segments(T);
     const int C = cfg.channels, D = cfg.dimension;
@@ -1340,6 +1363,7 @@ void EncodecModel::decode_dev(const int64_t* codes, const float* scales, int B, 
     if (nq <= 0 || nq > cfg.n_codebooks) fail(NC_EINVAL, "codes carry %d codebooks; the model has %d", nq, cfg.n_codebooks);
     if (cfg.normalize && !scales) fail(NC_EINVAL, "this model normalises frames: scales must be given");
     use_device();
+    check_async_errors();
     pool_i = 0;
     const std::vector<Seg> segs = segments(T);
     const int C = cfg.channels;

@@ -13,7 +13,10 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
+#include <exception>
 #include <mutex>
+#include <thread>
 
 #include "nc_model.h"
 
@@ -38,13 +41,23 @@ Rccl& rccl() {
     static std::once_flag once;
     static std::string err;
     std::call_once(once, [] {
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names)
-            if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;   // a copy already in the process (e.g. PyTorch's) wins
+        // NC_RCCL_LIB=<path> names the one library to open (deployments with a private RCCL; tests force the load failure with it)
+        const char* forced = std::getenv("NC_RCCL_LIB");
+        const char* defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        std::vector<const char*> names;
+        if (forced && forced[0]) names.push_back(forced);
+        else names.assign(std::begin(defaults), std::end(defaults));
+        if (!(forced && forced[0]))
+            for (const char* n : names)
+                if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;   // a copy already in the process (e.g. PyTorch's) wins
         if (!r.lib)
             for (const char* n : names)
                 if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-        if (!r.lib) { err = dlerror() ? dlerror() : "librccl not found"; return; }
+        if (!r.lib) {
+            const char* e = dlerror();   // (one call: dlerror() clears the message it returns)
+            err = e ? e : "librccl not found";
+            return;
+        }
         auto sym = [&](const char* s) { void* p = dlsym(r.lib, s); if (!p) err = std::string("librccl lacks ") + s; return p; };
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
@@ -84,24 +97,42 @@ nc_status guard(F&& f) {
 
 }  // namespace
 
+// pinned host staging (grow-only): the host-pointer entry points take pageable memory, and a hipMemcpyAsync from pageable memory is
+// synchronous -- staged through pinned buffers by one host thread per device, the uploads of all devices overlap
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        NC_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        cap = bytes;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct nc_group {
     int world = 1, rank = -1;        // rank == -1: local mode (this process drives all `world` devices)
     struct Member {
-        nc_codec* h = nullptr;
+        nc_codec* h = nullptr;       // borrowed: the codec must outlive the group (nc_group_destroy before nc_codec_destroy)
+        int device = 0;              // (kept here so that the destructor never reads through the borrowed handle)
         ncclComm_t comm = nullptr;
         hipStream_t side = nullptr;
         hipEvent_t ev_enc = nullptr, ev_gather = nullptr;
         DevBuf pcm, codes_all, z;    // local mode staging
+        PinBuf pin_in, pin_out, pin_z;
     };
     std::vector<Member> m;
     ~nc_group() {
         for (auto& x : m) {
-            if (x.h && x.h->impl) (void)hipSetDevice(x.h->impl->device);
+            (void)hipSetDevice(x.device);
             if (x.comm) (void)rccl().CommDestroy(x.comm);
             if (x.side) (void)hipStreamDestroy(x.side);
             if (x.ev_enc) (void)hipEventDestroy(x.ev_enc);
             if (x.ev_gather) (void)hipEventDestroy(x.ev_gather);
             x.pcm.release(); x.codes_all.release(); x.z.release();
+            x.pin_in.release(); x.pin_out.release(); x.pin_z.release();
         }
     }
 };
@@ -111,6 +142,7 @@ namespace {
 void init_member(nc_group::Member& x, nc_codec* h) {
     if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");
     x.h = h;
+    x.device = h->impl->device;
     h->impl->use_device();
     NC_HIP(hipStreamCreateWithFlags(&x.side, hipStreamNonBlocking));
     NC_HIP(hipEventCreateWithFlags(&x.ev_enc, hipEventDisableTiming));
@@ -151,54 +183,95 @@ void rank_encode_allgather(nc_group* g, int kind, const float* pcm, int B, int64
     NC_HIP(hipEventRecord(x.ev_gather, x.side));
 }
 
+// Local mode: ONE process drives all devices.  Clips are split into contiguous blocks (the first B_total % W devices hold one clip more:
+// neuralcodecs_amd/parallel.py shard_bounds); every device's slot of the gathered buffer is sized for the largest block, so ragged
+// batches gather with one collective and the padding rows are dropped on the way back to the host.  One host thread per device stages
+// its block through pinned memory, uploads, and queues the encode; the grouped all-gather is issued by the calling thread.
 void local_encode_allgather(nc_group* g, int kind, const float* pcm, int B_total, int64_t T, int sample_rate, int n_q, int64_t* codes, float* z) {
     if (!g || g->rank >= 0) fail(NC_EINVAL, "group was not created with nc_group_create_local");
     if (!pcm || !codes || B_total <= 0 || T <= 0) fail(NC_EINVAL, "bad arguments");
     const int W = g->world;
-    if (B_total % W != 0) fail(NC_EINVAL, "%d clips do not split evenly over %d devices", B_total, W);
-    const int B = B_total / W;
-    int64_t per_rank = 0, z_per = 0;
-    for (int d = 0; d < W; ++d) {
-        nc_group::Member& x = g->m[d];
-        Codec& c = *x.h->impl;
-        c.use_device();
-        int64_t total = 0;
+    for (int d = 0; d < W; ++d)   // before any cast below
+        if (g->m[(size_t)d].h->kind != kind) fail(NC_EINVAL, kind == 0 ? "handle is not a DAC codec" : "handle is not a SNAC codec");
+    const int q = B_total / W, r = B_total % W, B_max = q + (r ? 1 : 0);
+    auto lo_of = [&](int d) { return d * q + std::min(d, r); };
+    auto n_of = [&](int d) { return q + (d < r ? 1 : 0); };
+    int64_t per_clip = 0, z_clip = 0;
+    int channels = 1;
+    {
+        Codec& c0 = *g->m[0].h->impl;
         if (kind == 0) {
-            DacModel& m = static_cast<DacModel&>(c);
+            DacModel& m = static_cast<DacModel&>(c0);
             const int nq = (n_q <= 0 || n_q > m.cfg.n_codebooks) ? m.cfg.n_codebooks : n_q;
-            total = (int64_t)B_total * nq * m.frames(T);
-            z_per = (int64_t)B * m.latent * m.frames(T);
+            per_clip = (int64_t)nq * m.frames(T);
+            z_clip = (int64_t)m.latent * m.frames(T);
         } else {
-            SnacModel& m = static_cast<SnacModel&>(c);
-            total = (int64_t)B_total * m.codes_per_clip(m.padded_len(T) / m.hop);
+            SnacModel& m = static_cast<SnacModel&>(c0);
+            per_clip = m.codes_per_clip(m.padded_len(T) / m.hop);
         }
-        x.pcm.reserve((size_t)B * T * 4);
-        x.codes_all.reserve((size_t)total * 8);
-        if (z && kind == 0) x.z.reserve((size_t)z_per * 4);
-        NC_HIP(hipMemcpyAsync(x.pcm.p, pcm + (int64_t)d * B * T, (size_t)B * T * 4, hipMemcpyHostToDevice, c.stream));
-        per_rank = encode_into_slot(x, kind, d, x.pcm.as<float>(), B, T, sample_rate, n_q, x.codes_all.as<int64_t>(), (z && kind == 0) ? x.z.as<float>() : nullptr,
-                                    nullptr);
-        if (z && kind == 0) NC_HIP(hipMemcpyAsync(z + (int64_t)d * z_per, x.z.p, (size_t)z_per * 4, hipMemcpyDeviceToHost, c.stream));
     }
+    const int64_t per_rank = (int64_t)B_max * per_clip;
+    const bool want_z = z && kind == 0;
+    std::vector<std::exception_ptr> errs((size_t)W);
+    auto phase1 = [&](int d) {
+        try {
+            nc_group::Member& x = g->m[(size_t)d];
+            Codec& c = *x.h->impl;
+            c.use_device();
+            const int B = n_of(d);
+            x.codes_all.reserve((size_t)per_rank * W * 8);
+            if (B > 0) {
+                const size_t in_bytes = (size_t)B * channels * T * 4;
+                x.pcm.reserve(in_bytes);
+                x.pin_in.reserve(in_bytes);
+                std::memcpy(x.pin_in.p, pcm + (int64_t)lo_of(d) * channels * T, in_bytes);
+                NC_HIP(hipMemcpyAsync(x.pcm.p, x.pin_in.p, in_bytes, hipMemcpyHostToDevice, c.stream));
+                if (want_z) { x.z.reserve((size_t)B * z_clip * 4); x.pin_z.reserve((size_t)B * z_clip * 4); }
+                // (the slot is sized for B_max clips; this device fills the first B of them)
+                int64_t* slot = x.codes_all.as<int64_t>() + (int64_t)d * per_rank;
+                if (kind == 0) static_cast<DacModel&>(c).encode_dev(x.pcm.as<float>(), B, T, sample_rate, n_q, slot, want_z ? x.z.as<float>() : nullptr, nullptr);
+                else static_cast<SnacModel&>(c).encode_dev(x.pcm.as<float>(), B, T, slot, nullptr, nullptr, true);
+                if (want_z) NC_HIP(hipMemcpyAsync(x.pin_z.p, x.z.p, (size_t)B * z_clip * 4, hipMemcpyDeviceToHost, c.stream));
+            }
+            NC_HIP(hipEventRecord(x.ev_enc, c.stream));
+            NC_HIP(hipStreamWaitEvent(x.side, x.ev_enc, 0));
+        } catch (...) {
+            errs[(size_t)d] = std::current_exception();
+        }
+    };
+    if (W == 1) {
+        phase1(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int d = 0; d < W; ++d) th.emplace_back(phase1, d);
+        for (auto& t : th) t.join();
+    }
+    for (auto& e : errs)
+        if (e) std::rethrow_exception(e);
     NC_RCCL(rccl().GroupStart());
     for (int d = 0; d < W; ++d) {
-        nc_group::Member& x = g->m[d];
+        nc_group::Member& x = g->m[(size_t)d];
         int64_t* all = x.codes_all.as<int64_t>();
         NC_RCCL(rccl().AllGather(all + (int64_t)d * per_rank, all, (size_t)per_rank, ncclInt64, x.comm, x.side));
     }
     NC_RCCL(rccl().GroupEnd());
-    {   // every device now holds all codes; device 0's copy goes back to the host
+    {   // every device now holds all codes; device 0's copy goes back to the host (pinned, then the valid rows of every slot)
         nc_group::Member& x = g->m[0];
-        x.h->impl->use_device();
-        NC_HIP(hipMemcpyAsync(codes, x.codes_all.p, (size_t)per_rank * W * 8, hipMemcpyDeviceToHost, x.side));
+        (void)hipSetDevice(x.device);
+        x.pin_out.reserve((size_t)per_rank * W * 8);
+        NC_HIP(hipMemcpyAsync(x.pin_out.p, x.codes_all.p, (size_t)per_rank * W * 8, hipMemcpyDeviceToHost, x.side));
     }
     for (int d = 0; d < W; ++d) {
-        nc_group::Member& x = g->m[d];
-        x.h->impl->use_device();
+        nc_group::Member& x = g->m[(size_t)d];
+        (void)hipSetDevice(x.device);
         NC_HIP(hipStreamSynchronize(x.side));
         NC_HIP(hipStreamSynchronize(x.h->impl->stream));
         x.h->impl->check_async_errors();
+        if (want_z && n_of(d) > 0) std::memcpy(z + (int64_t)lo_of(d) * z_clip, x.pin_z.p, (size_t)n_of(d) * z_clip * 4);
     }
+    const int64_t* all = static_cast<const int64_t*>(g->m[0].pin_out.p);
+    for (int d = 0; d < W; ++d)
+        if (n_of(d) > 0) std::memcpy(codes + (int64_t)lo_of(d) * per_clip, all + (int64_t)d * per_rank, (size_t)n_of(d) * per_clip * 8);
 }
 
 }  // namespace
@@ -279,7 +352,7 @@ nc_status nc_group_wait(nc_group* g) {
     return guard([&] {
         if (!g || g->m.empty()) fail(NC_EINVAL, "null group");
         for (auto& x : g->m) {
-            x.h->impl->use_device();
+            (void)hipSetDevice(x.device);
             NC_HIP(hipStreamWaitEvent(x.h->impl->stream, x.ev_gather, 0));
         }
     });

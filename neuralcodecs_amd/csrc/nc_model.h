@@ -49,6 +49,8 @@ struct Codec {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     bool loaded = false;
+    int cu_count = 0;              // compute units of the device (multiProcessorCount)
+    size_t lds_per_cu = 0;         // LDS a workgroup may opt into (maxSharedMemoryPerMultiProcessor)
     Profiler prof;
     virtual ~Codec();
     virtual void load(const Blob& blob) = 0;
@@ -221,7 +223,13 @@ struct EncodecModel : Codec {
     std::vector<std::unique_ptr<DevBuf>> pool;   // per-call intermediates, same allocation order every call (grow-only)
     size_t pool_i = 0;
     DevBuf h_in, h_out, h_codes, h_scales, h_emb;
-    DevBuf lstm_sync;   // [0]: timeout word of the persistent LSTM kernels
+    // Timeout word of the persistent LSTM kernels: ONE word of pinned, device-mapped host memory -- a kernel that gives up its spin
+    // writes it over PCIe, the host reads it without touching the stream.  After a timeout the handle runs the step-wise kernels
+    // (lstm_force_stepwise): the persistent form needs its workgroups co-resident, which a busy / partitioned device may not grant.
+    unsigned* lstm_tmo_host = nullptr;
+    unsigned* lstm_tmo_dev = nullptr;
+    bool lstm_force_stepwise = false;
+    bool lstm_timed_out() const { return lstm_tmo_host && *reinterpret_cast<volatile unsigned*>(lstm_tmo_host) != 0; }
     // segment groups of one call are independent until the overlap-add: the first runs on the handle's stream, the others on side
     // streams (forked / joined with events), so the short tail segment of a clip hides behind the full-length batch
     hipStream_t side_stream[2] = {nullptr, nullptr};

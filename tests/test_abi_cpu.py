@@ -1,6 +1,7 @@
 """CPU suite: the C-ABI library loads, exports every symbol the header declares, and fails loudly without a GPU."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -122,3 +123,25 @@ def test_blob_parser_rejects_truncated_and_crafted_images():
         assert L.nc_blob_check(bytes(bad), len(bad), None) in (_lib.NC_OK, _lib.NC_EINVAL)
     assert L.nc_blob_check(b"NCWB0001" + b"\\0" * 8, 16, None) == _lib.NC_EINVAL
     assert L.nc_blob_check(None, 0, None) == _lib.NC_EINVAL
+
+
+def test_group_entry_points_fail_cleanly_without_rccl():
+    """on a host whose librccl cannot be opened every nc_group_* entry point must return NC_EDEVICE (with a message), not
+    crash.  NC_RCCL_LIB names the one library the loader tries; a child process (the loader caches its result) points it at nothing."""
+    import subprocess
+    code = (
+        "import ctypes as C, os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from neuralcodecs_amd import _lib\n"
+        "L = _lib.lib()\n"
+        "buf = (C.c_char * 128)()\n"
+        "st = L.nc_group_unique_id(buf)\n"
+        "msg = L.nc_last_error().decode()\n"
+        "assert st == _lib.NC_EDEVICE, st\n"
+        "assert 'RCCL is not available' in msg, msg\n"
+        "st2 = L.nc_group_unique_id(buf)\n"          # the cached failure path
+        "assert st2 == _lib.NC_EDEVICE\n"
+        "print('ok')\n" % ROOT)
+    env = dict(os.environ, NC_RCCL_LIB="/nonexistent/librccl-not-here.so")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout, r.stderr)

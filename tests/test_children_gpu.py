@@ -1,0 +1,72 @@
+"""GPU suite, child-process tests: (a) the persistent-LSTM timeout path (a faked timeout: the host-pointer entry points repeat the call
+on the step-wise kernels, the device-pointer path reports it through nc_codec_check_errors and succeeds on the repeat); (b) nc_group
+with MORE THAN ONE process / device -- rank mode with world = 2 (ncclCommInitRank, in-place all-gather, every slot checked against a
+1-GPU encode) and local mode with 2 devices (ncclCommInitAll + grouped all-gathers, ragged batches).  (b) skips on boxes with fewer
+than two GPUs (the build container's GPU box has one); the world = 1 / one-device forms of the same children run everywhere, so the
+harness itself is exercised on every box."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = os.path.join(ROOT, "tests", "_gpu_child.py")
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()   # (counting devices does not initialise the GPU in this process)
+
+
+def _run(args, env=None, timeout=600):
+    e = dict(os.environ)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if env:
+        e.update(env)
+    return subprocess.Popen([sys.executable, CHILD] + [str(a) for a in args], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+
+def _finish(procs, timeout=600):
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("child timed out")
+        outs.append(out)
+    for p, out in zip(procs, outs):
+        assert p.returncode == 0 and "CHILD_OK" in out, out[-3000:]
+
+
+@pytest.mark.parametrize("mode", ["lstm_fallback", "lstm_fallback_dev"])
+def test_lstm_timeout_falls_back_to_stepwise(mode):
+    _finish([_run([mode], env={"NC_LSTM_FAKE_TIMEOUT": "1"})])
+
+
+def test_group_children_single_device():
+    with tempfile.TemporaryDirectory() as d:
+        _finish([_run(["group_rank", 1, 0, os.path.join(d, "uid"), 4])])
+    _finish([_run(["group_local", 1, 3])])
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs (nc_group with world > 1)")
+def test_group_rank_mode_world2():
+    with tempfile.TemporaryDirectory() as d:
+        uid = os.path.join(d, "uid")
+        _finish([_run(["group_rank", 2, r, uid, 6]) for r in range(2)])
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs (nc_group local mode with ndev > 1)")
+def test_group_local_mode_two_devices_ragged():
+    _finish([_run(["group_local", 2, 5])])
+
+
+@pytest.mark.skipif(_n_gpus() < 4, reason="needs four GPUs")
+def test_group_local_mode_more_devices_than_clips():
+    _finish([_run(["group_local", 4, 3])])
