@@ -16,7 +16,8 @@ The JSON line carries
     GEMM: bound "mfma", peak = 157.3 TFLOP/s dense fp32 MFMA on MI355X) measured with HIP events on the launch stream;
   * `cpu_baseline`: the C oracle (kind "port") timed on the host cores on a bounded sample of the same workload, the
     GPU == oracle check on those clips (`gpu_equals_oracle`, outside the timed region) and `aten_proxy`: the same graph
-    as a sequence of ATen CPU operators (oracle/torch_ref, the closest stand-in for the reference's TorchSharp-CPU path);
+    as a sequence of ATen CPU operators (tools/aten_proxy.py, the closest stand-in for the reference's TorchSharp-CPU path);
+    both CPU legs: one warm-up + 3 timed passes, median (BASELINE.md 3);
   * `extra_configs` (N=1 only): BASELINE configs C3 (Encodec 48 kHz stereo, 16 x 2 s), C5's per-GPU share and C1
     (SNAC 24 kHz, 1 x 1 s) on the same GPU: ms, x real-time, per-class HIP-event times, dominant kernel class with its
     roofline fraction, algorithmic vs PMC bytes, and a GPU == oracle check on one clip.
@@ -40,7 +41,9 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 de
 HBM_PEAK_GBS = 8000.0
 MFMA_CLASSES = ("conv_k7", "conv_k1", "conv_down", "conv_up", "conv_misc", "lstm")   # dense contractions: priced against the fp32 matrix peak
 # algorithmic work per audio-second of encode+decode (layer-fused byte model)
-ALGO = {"dac44k": (201.8e9, 1.057e9), "encodec48k": (12.28e9 * 1.5, 0.47e9 * 1.5), "snac24k": (14.8e9, 0.44e9), "snac44k": (67.9e9, 1.23e9)}
+# (Encodec 48 kHz: a 2 s clip is cut into segments of 48000 + 48000 + 960 samples = 2.02 one-second segments of 12.28 GFLOP / 0.47 GB each,
+#  i.e. 1.01 segment-equivalents per audio-second: 397 GFLOP per C3 step of 16 clips)
+ALGO = {"dac44k": (201.8e9, 1.057e9), "encodec48k": (12.28e9 * 1.01, 0.47e9 * 1.01), "snac24k": (14.8e9, 0.44e9), "snac44k": (67.9e9, 1.23e9)}
 
 
 def class_table(prof, steps):
@@ -165,28 +168,22 @@ def extra_configs(dev, steps, warmup, check):
     return out
 
 
-def aten_proxy(cfg, blob_sd, pcm_h, seconds):
-    """The DAC graph as a sequence of ATen CPU operators (our torch restatement of the C# graph: F.conv1d / conv_transpose1d,
-    element-wise Snake, per-call weight-norm) -- what TorchSharp-CPU dispatches to.  A reported baseline only."""
-    import torch
-    from oracle.torch_ref.dac import TorchDAC
-    m = TorchDAC(cfg, blob_sd)
-    n = pcm_h.shape[0]
-    with torch.inference_mode():
-        t0 = time.perf_counter()
-        out = m.encode(torch.from_numpy(pcm_h))
-        m.decode(out[0])
-        dt = time.perf_counter() - t0
-    cpu = "unknown"
+def aten_proxy(cfg, state_dict, pcm_h, seconds, iters=3):
+    """The DAC graph as a sequence of ATen CPU operators -- what TorchSharp-CPU dispatches to (tools/aten_proxy.py: repo-owned, shares
+    no code with oracle/): 1 warm-up + `iters` timed passes, median.  A reported baseline only."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import aten_proxy as ap
+    return ap.run(cfg, state_dict, pcm_h, seconds, iters)
+
+
+def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
             if line.startswith("model name"):
-                cpu = line.split(":", 1)[1].strip()
-                break
+                return line.split(":", 1)[1].strip()
     except OSError:
         pass
-    return {"value": round(n * seconds / dt, 4), "unit": "audio-seconds/sec", "threads": int(torch.get_num_threads()), "cpu": cpu,
-            "sample": f"{n} clips, one cold encode+decode pass through ATen CPU ops (oracle/torch_ref/dac.py), {dt:.2f} s"}
+    return "unknown"
 
 
 def main():
@@ -198,7 +195,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default: 32 for dac44k, 8 for snac44k)")
     ap.add_argument("--seconds", type=float, default=0.0, help="clip length (default: 1 s for dac44k, 5 s for snac44k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=8, help="clips in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-clips", type=int, default=4, help="clips in the bounded CPU-baseline sample (1 warm-up + --cpu-iters timed passes over them)")
+    ap.add_argument("--cpu-iters", type=int, default=3, help="timed passes of the CPU baselines (median reported)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs block (C3 / C5 share / C1)")
     ap.add_argument("--no-check", action="store_true", help="skip the GPU == oracle comparisons (outside the timed region)")
     ap.add_argument("--check", action="store_true", help="(default now) kept for compatibility")
@@ -348,19 +346,33 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             from oracle import c_oracle
+            # the C restatement of the reference graph on this box's host cores, in this run: one warm-up pass, then
+            # --cpu-iters timed passes over a bounded sample of the step's clips; median
+            import statistics
             n = max(1, min(args.cpu_clips if not snac_mode else 1, B))
-            tc = time.perf_counter()
             if snac_mode:
                 ref = c_oracle.RefSNAC(cfg, blob)
-                _, _, rcodes = ref.encode(pcm_h[:n])
-                raudio = ref.decode(rcodes, [x[:n] for x in noise_h])
+
+                def cpu_pass():
+                    _, _, rc = ref.encode(pcm_h[:n])
+                    return rc, ref.decode(rc, [x[:n] for x in noise_h])
             else:
                 ref = c_oracle.RefDAC(cfg, blob)
-                rz, rcodes, _, _ = ref.encode(pcm_h[:n])
-                raudio = ref.decode(rz)
-            cdt = time.perf_counter() - tc
+
+                def cpu_pass():
+                    rz, rc, _, _ = ref.encode(pcm_h[:n])
+                    return rc, ref.decode(rz)
+            cpu_pass()
+            ctimes = []
+            for _ in range(max(1, args.cpu_iters)):
+                tc = time.perf_counter()
+                rcodes, raudio = cpu_pass()
+                ctimes.append(time.perf_counter() - tc)
+            cdt = statistics.median(ctimes)
             cpu = {"value": round(n * seconds / cdt, 4), "unit": "audio-seconds/sec", "cores": int(c_oracle.lib().ref_num_threads()),
-                   "kind": "port", "sample": f"{n} of the {B} clips of one step (encode+decode, C oracle with OpenMP), {cdt:.2f} s"}
+                   "kind": "port", "cpu": cpu_model(), "host_cpus": os.cpu_count(), "iterations": len(ctimes), "median_s": round(cdt, 3),
+                   "min_s": round(min(ctimes), 3), "max_s": round(max(ctimes), 3),
+                   "sample": f"{n} of the {B} clips of one step (encode+decode, C oracle with OpenMP): 1 warm-up + {len(ctimes)} timed passes, median"}
             if not args.no_check:
                 if snac_mode:
                     same_codes = all(np.array_equal(c[:n].cpu().numpy(), r) for c, r in zip(codes, rcodes))
@@ -370,7 +382,7 @@ def main():
                                             "pcm_max_abs_diff": float(np.abs(audio[:n].cpu().numpy() - raudio).max())}
             if not snac_mode:
                 try:
-                    cpu["aten_proxy"] = aten_proxy(cfg, sd, pcm_h[:min(4, B)], seconds)
+                    cpu["aten_proxy"] = aten_proxy(cfg, sd, pcm_h[:min(2, B)], seconds, args.cpu_iters)
                 except Exception as e:   # the proxy is informational: never lose the bench line to it
                     cpu["aten_proxy"] = {"error": repr(e)}
         extras = None
@@ -396,11 +408,25 @@ def main():
                        "collective": coll if use_dist else "none"},
             "roofline": roofline, "cpu_baseline": cpu, "extra_configs": extras,
         }
-    if use_dist and rank == 0 and not args.no_check:
-        if snac_mode:
-            assert torch.equal(gathered[:B], torch.cat([c.reshape(B, -1) for c in codes], dim=1)), "gathered codes differ from the local codes"
-        else:
-            assert torch.equal(gathered[:B], codes), "gathered codes differ from the local codes"
+    gathered_ok = None
+    if use_dist and not args.no_check:
+        # the gathered codes of the N-GPU run must equal the 1-GPU run on the same inputs -- EVERY slot, on every rank:
+        # each rank re-encodes every shard's clips (same seeds) on its own GPU, outside the timed region, and compares slot by slot
+        ok = True
+        for sh in range(world):
+            xs = torch.from_numpy(synthetic_pcm(B, 1, T, cfg.sampling_rate if snac_mode else cfg.sample_rate, seed=1234 + sh * B)).to(dev)
+            if snac_mode:
+                want = torch.cat([c.reshape(B, -1) for c in model.encode(xs)], dim=1)
+            else:
+                want = model.encode(xs)[1]
+            torch.cuda.synchronize()
+            ok = ok and bool(torch.equal(gathered[sh * B:(sh + 1) * B], want))
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gathered_ok = bool(flag.item() == 1)
+        if rank == 0:
+            out["config"]["gathered_equals_1gpu_every_slot_every_rank"] = gathered_ok
+        assert gathered_ok, "gathered codes differ from the 1-GPU encode of the same clips"
     model.dispose()
     if use_dist:
         dist.destroy_process_group()

@@ -1258,7 +1258,7 @@ void EncodecModel::encode_batch(const float* x, int N, int64_t L, int64_t Tz, in
     const int D = cfg.dimension;
     if (emb_out) NC_HIP(hipMemcpyAsync(emb_out, residual, (size_t)N * D * Tz * 4, hipMemcpyDeviceToDevice, stream));
     const int64_t total = (int64_t)N * Tz;
-    if (prof.on) prof.begin(stream, NC_KC_RVQ, 3.0 * 2.0 * D * cfg.codebook_size * (double)total * n_q, 0.0);
+    if (prof.on) prof.begin(stream, NC_KC_RVQ, 2.0 * D * cfg.codebook_size * (double)total * n_q, 0.0);   // the distance GEMM
     static const bool no_mfma_vq = std::getenv("NC_EUCLID_NO_MFMA") != nullptr;
     const int Nc = cfg.codebook_size;
     if (!no_mfma_vq && Nc % 512 == 0 && D == 128) {
