@@ -42,6 +42,10 @@ class TorchEncodec:
         self.n_q_total = int(1000 * max(cfg.target_bandwidths) / (math.ceil(cfg.sampling_rate / self.hop) * 10))
         self.bandwidth = cfg.bandwidth
         self._lstm = {}
+        # Deviations of the C# port that can be UNDONE to reproduce upstream (Meta / HF transformers) semantics, for the structural
+        # cross-check of tools/crosscheck_hf.py only: {"D9"} (the small-input reflect path never trims its zero
+        # extension).  Empty = the reference's behaviour.
+        self.upstream = set()
 
     # ---- segment properties (Encodec.cs:190-196)
     @property
@@ -72,14 +76,17 @@ class TorchEncodec:
             return y
         return F.group_norm(y, 1, self.sd[key + ".norm.weight"], self.sd[key + ".norm.bias"], 1e-5)
 
-    @staticmethod
-    def _pad1d(x, left, right):
+    def _pad1d(self, x, left, right):
         # SConv1d.cs:258-274: always reflect; the small-input path zero-pads first and never trims (D9)
         L = x.size(-1)
+        extra = 0
         if L <= max(left, right):
             extra = max(left, right) - L + 1
             x = F.pad(x, (0, extra), mode="constant", value=0.0)
-        return F.pad(x, (left, right), mode="reflect")
+        y = F.pad(x, (left, right), mode="reflect")
+        if extra and "D9" in self.upstream:                                    # upstream (ConvUtils.cs:62-100 / HF _pad1d): drop the zero extension again
+            y = y[..., : y.size(-1) - extra]
+        return y
 
     def sconv(self, x, key, k, stride=1, dilation=1):
         L = x.size(2)

@@ -27,3 +27,17 @@ def test_encodec_restatement_matches_hf_encoder_and_decoder():
     r = crosscheck_hf.crosscheck_encodec(seed=0)
     assert r["encoder_max_abs"] <= 1e-5 * max(1.0, r["encoder_scale"])
     assert r["decoder_max_abs"] < 1e-5
+
+
+def test_encodec_48k_layout_matches_hf_end_to_end_and_d9_is_reproduced():
+    """the 48 kHz LAYOUT (GroupNorm(1,C), non-causal reflect padding, RMS normalisation, chunking + overlap-add,
+    Euclidean RVQ) against HF's independent EncodecModel: per-chunk codes and scales, decoder + overlap-add, with the D9 switch."""
+    import crosscheck_hf
+    r = crosscheck_hf.crosscheck_encodec48(seed=0)
+    assert (r["segment_length"], r["segment_stride"]) == tuple(r["hf_chunk"])                     # same chunking (Encodec.cs:190-196)
+    assert r["upstream_frame_lens"] == r["hf_frame_lens"] == [84, 84, 3]                           # D9 undone: HF's frame counts
+    assert r["reference_frame_lens"] == [84, 84, 4]                                               # D9 as in the reference: one more frame in the tail
+    assert r["encoder_max_abs"] <= 1e-5 * max(1.0, r["encoder_scale"])
+    assert r["codes_equal_frac"] >= 0.995 and r["scale_max_abs"] < 1e-6                            # Euclidean RVQ + RMS scale
+    assert r["decode_len"][0] == r["decode_len"][1]
+    assert r["decode_max_abs"] <= 1e-5 * max(1.0, r["decode_scale"])                               # decoder + scale + linear overlap-add

@@ -104,6 +104,71 @@ def crosscheck_encodec(seed=0, T=4000):
     return out
 
 
+def crosscheck_encodec48(seed=0, T=8064):
+    """HF EncodecModel in the 48 kHz LAYOUT (stereo, GroupNorm(1,C) after every conv, non-causal asymmetric reflect padding, RMS
+    normalisation, 0.25 s chunks with 1 % overlap and linear overlap-add) at reduced width vs oracle/torch_ref/encodec.py:
+    Encode (per-chunk codes and scales), the Euclidean RVQ, Decode (overlap-add).  Models/Encodec.cs:213-285,457-489,
+    Modules/Encodec/NormConv1d.cs:122-164, SConv1d.cs:258-274, EuclideanCodebook.cs:155-182, AudioTools/AudioTensorDSP.cs:161-261.
+    T = 8064 samples at 16 kHz -> chunks of 4000 at stride 3960: 4000 + 4000 + 144; the 144-sample tail reaches the last encoder
+    convolution (k = 7, pads 3 + 3) with 3 frames and takes the small-input reflect path -- like the 960-sample tail of a 2 s clip in
+    the real 48 kHz model (960 -> 3 frames).  Upstream trims the zero extension again (3 code frames); the reference does not (D9: 4)."""
+    from transformers import EncodecConfig as HFEncodecConfig, EncodecModel
+    torch.manual_seed(seed)
+    hcfg = HFEncodecConfig(sampling_rate=16000, audio_channels=2, num_filters=4, hidden_size=32, upsampling_ratios=[4, 3, 2, 2], codebook_size=64,
+                           codebook_dim=32, target_bandwidths=[3.0, 6.0, 12.0], normalize=True, use_causal_conv=False, norm_type="time_group_norm",
+                           chunk_length_s=0.25, overlap=0.01, num_lstm_layers=2, compress=2, kernel_size=7, last_kernel_size=7,
+                           residual_kernel_size=3, use_conv_shortcut=True, pad_mode="reflect")
+    hf = EncodecModel(hcfg).eval()
+    with torch.no_grad():                                     # generic GroupNorm affines and codebooks (random init leaves them at 1 / 0 / zeros)
+        for n, p in hf.named_parameters():
+            if ".norm.weight" in n:
+                p.copy_(torch.empty_like(p).uniform_(0.8, 1.2))
+            elif ".norm.bias" in n:
+                p.copy_(torch.randn_like(p) * 0.05)
+        for n, b in hf.named_buffers():
+            if n.endswith("codebook.embed"):
+                b.copy_(torch.randn_like(b))
+    native = {k: v.detach().numpy() for k, v in hf.state_dict().items()}
+    cfg = EncodecConfig(sampling_rate=16000, channels=2, dimension=32, norm="time_group_norm", causal=False, normalize=True, segment_seconds=0.25,
+                        target_bandwidths=(3.0, 6.0, 12.0), bandwidth=6.0, codebook_size=64, n_filters=4, ratios=(4, 3, 2, 2))
+    ours = TorchEncodec(cfg, native)
+    x = torch.randn(2, 2, T) * 0.3
+    out = {"segment_length": ours.segment_length, "segment_stride": ours.segment_stride, "hf_chunk": (hcfg.chunk_length, hcfg.chunk_stride)}
+    with torch.inference_mode():
+        codes_hf, scales_hf, pad_hf = hf.encode(x, bandwidth=6.0, return_dict=False)
+        a_hf = hf.decode(codes_hf, scales_hf, last_frame_pad_length=pad_hf, return_dict=False)[0]
+        for tag, up in (("upstream", {"D9"}), ("reference", set())):
+            ours.upstream = up
+            frames = ours.encode(x, want_dist=False)
+            out[f"{tag}_n_frames"] = len(frames)
+            out[f"{tag}_frame_lens"] = [int(f[0].shape[-1]) for f in frames]
+            if tag == "upstream":
+                out["hf_frame_lens"] = [int(codes_hf.shape[-1])] * (codes_hf.shape[0] - 1) + [int(codes_hf.shape[-1] - pad_hf)]
+                eq, tot, sc = 0, 0, 0.0
+                for i, (c, s_, _e, _d) in enumerate(frames):
+                    ch = codes_hf[i][..., : c.shape[-1]]
+                    eq += int((c == ch).sum()); tot += c.numel()
+                    sc = max(sc, float((s_ - scales_hf[i]).abs().max()))
+                out["codes_equal_frac"] = eq / tot
+                out["scale_max_abs"] = sc
+                # decode HF's own codes with our decoder + overlap-add: isolates the decoder / overlap-add from encoder-side near-ties
+                fr_hf = [(codes_hf[i][..., : frames[i][0].shape[-1]], scales_hf[i]) for i in range(len(frames))]
+                a = ours.decode(fr_hf)
+                n = min(a.shape[-1], a_hf.shape[-1])
+                out["decode_len"] = (int(a.shape[-1]), int(a_hf.shape[-1]))
+                out["decode_max_abs"] = float((a[..., :n] - a_hf[..., :n]).abs().max())
+                out["decode_scale"] = float(a_hf.abs().max())
+                # the encoder alone on one full chunk (normalised input), before any argmin
+                xs = x[..., :4000]
+                mono = xs.mean(1, keepdim=True)
+                xs = xs / (mono.pow(2).mean(-1, keepdim=True).sqrt() + 1e-8)
+                e_hf, e = hf.encoder(xs), ours.encoder(xs)
+                out["encoder_max_abs"] = float((e - e_hf).abs().max())
+                out["encoder_scale"] = float(e_hf.abs().max())
+    return out
+
+
 if __name__ == "__main__":
     print("dac    ", crosscheck_dac())
     print("encodec", crosscheck_encodec())
+    print("encodec48", crosscheck_encodec48())
