@@ -226,7 +226,7 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
     alts.clear();
     static const bool no_alts = std::getenv("NC_NO_TILE_ALTS") && std::getenv("NC_NO_TILE_ALTS")[0] == '1';
     if (!no_alts && rows() >= 128)
-        for (int tm = 3; tm >= 2; --tm) {   // (single-row-block tiles measured slower everywhere)
+        for (int tm = 3; tm >= 1; --tm) {   // (single-row-block tiles: slower on every filled grid, chosen only for the tiny grids of choose_tile)
             if (tm == cfg.TM || rows() % (32 * tm) != 0) continue;
             alts.emplace_back(new Alt());
             alts.back()->cfg = cfg;
@@ -307,6 +307,20 @@ static TileChoice choose_tile(const ConvLayer& L, int64_t blocks_per_rowtile, bo
     };
     TileChoice best{L.cfg, L.w.as<float>(), L.w_phase_stride};
     double bc = cost(L.cfg);
+    {   // Tiny grids (one-clip / short-row launches: even with 32-row tiles every workgroup gets a CU of its own): a workgroup's life is
+        // its serial reduction, TM matrix-core chains long per step, so the SMALLEST row tile finishes first -- SNAC 24 kHz at one clip:
+        // the 384 -> 768 k=16 down-convolution ran 8 workgroups of 96 rows for 450 us (C1: 2.85 ms in all).
+        static const bool no_tiny = std::getenv("NC_NO_TINY_TILES") && std::getenv("NC_NO_TINY_TILES")[0] == '1';
+        if (!no_tiny && blocks_per_rowtile * ((L.rows() + 31) / 32) <= 256) {
+            int tm = L.cfg.TM;
+            for (const auto& a : L.alts)
+                if (a->cfg.TM < tm) {
+                    tm = a->cfg.TM;
+                    best = TileChoice{a->cfg, a->w.as<float>(), a->w_phase_stride};
+                }
+            return best;
+        }
+    }
     static const int tm_pick = std::getenv("NC_TM_PICK") ? atoi(std::getenv("NC_TM_PICK")) : 0;   // experiment: force a packed variant
     if (tm_pick) {
         for (const auto& a : L.alts)
@@ -314,7 +328,7 @@ static TileChoice choose_tile(const ConvLayer& L, int64_t blocks_per_rowtile, bo
         return best;
     }
     for (const auto& a : L.alts) {
-        if (a->cfg.TM > 4) continue;   // whole-channel tiles of the wide fused units
+        if (a->cfg.TM > 4 || a->cfg.TM == 1) continue;   // whole-channel tiles of the wide fused units; 32-row tiles: tiny grids only (above)
         const double c = cost(a->cfg);
         if (c < bc) {
             bc = c;
@@ -341,6 +355,47 @@ static int pick_co_group(int n_co_tiles, double x_bytes, double w_bytes, double 
         if (g == 1 || t < bt) { bt = t; best = g; }
     }
     return best;
+}
+
+// Streaming k = 3 path of the Encodec residual branches (nc_conv3s.hip): reflect pad 1 + 1 of SConv1d folded into the lane exchange,
+// pending GroupNorm + ELU applied once per element in registers, no LDS for the activations.
+conv_kernel_fn conv3_stream_kernel_table(int, bool);
+static bool launch_conv3_stream(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream, Profiler* prof) {
+    static const bool off = std::getenv("NC_NO_CONV3S") && std::getenv("NC_NO_CONV3S")[0] == '1';
+    if (off || L.transposed || L.K != 3 || L.stride != 1 || L.dil != 1 || L.pad != 0 || L.cfg.CB != 16 || (L.Cin & 1) || L.Cin > 512) return false;
+    if (io.alpha_in || io.alpha_out || io.res || io.epi || io.fuse_k1 || io.x2 || io.noise) return false;
+    // the Encodec input mode with the non-causal pad of a k = 3, stride 1 SConv1d: one reflected sample on either side, no zero extension
+    const int64_t T = io.in_L;
+    if (T < 4 || (T & 1) || io.in_left != 1 || io.in_Lz != T || io.Tin != T + 2 || io.x_len != T + 2) return false;
+    if ((io.y_cstride & 1) || (io.y_bstride & 1)) return false;
+    auto al8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; };
+    if (!al8(io.y)) return false;
+    const bool x_aligned = al8(io.x) && !(io.x_cstride & 1) && !(io.x_bstride & 1);
+    if ((int64_t)(L.Cin + 1) * io.x_cstride + T >= ((int64_t)1 << 32)) return false;
+    const TileChoice tc = choose_tile(L, (int64_t)B * ((T + 255) / 256), true);
+    conv_kernel_fn fn = conv3_stream_kernel_table(tc.cfg.TM, x_aligned);
+    if (!fn) return false;
+    ConvArgs a{};
+    a.x = io.x; a.x_bstride = io.x_bstride; a.x_cstride = io.x_cstride; a.Cin = L.Cin; a.x_len = (int32_t)T;
+    a.w = tc.w;
+    a.bias = L.has_bias ? L.bias.as<float>() : nullptr;
+    a.y = io.y; a.y_bstride = io.y_bstride; a.y_cstride = io.y_cstride;
+    a.in_mode = (io.in_stats ? 1 : 0) | (io.in_elu ? 2 : 0);
+    a.in_stats = io.in_stats; a.in_gamma = io.in_gamma; a.in_beta = io.in_beta;
+    a.gn_part = io.gn_part; a.gn_nrb = io.gn_nrb; a.gn_ncb = io.gn_ncb;
+    a.Cout = L.Cout; a.B = B; a.Tout = (int32_t)T;
+    const int BM = tc.cfg.BM();
+    a.n_co_tiles = (L.Cout + BM - 1) / BM;
+    a.n_t_tiles = (int32_t)((T + 255) / 256);
+    a.n_cb = (L.Cin + 15) / 16;
+    a.co_group = pick_co_group(a.n_co_tiles, 4.0 * B * L.Cin * (double)T, 4.0 * 3 * L.Cin * (double)L.Cout, (double)B * a.n_t_tiles);
+    const int64_t grid = (int64_t)a.n_co_tiles * B * a.n_t_tiles;
+    if (prof && prof->on)
+        prof->begin(stream, L.kclass, 2.0 * L.Cin * L.Cout * 3 * (double)T * B, 4.0 * ((double)B * L.Cin * T + (double)B * L.Cout * T + 3.0 * L.Cin * L.Cout));
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    NC_HIP(hipGetLastError());
+    if (prof && prof->on) prof->end(stream);
+    return true;
 }
 
 // Pointwise fast path (nc_conv1x1.hip): B fragments straight from global memory, 2-wide vector loads/stores.
@@ -462,6 +517,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         }
     }
     if (launch_conv1x1(L, io, B, stream, prof)) return;
+    if (launch_conv3_stream(L, io, B, stream, prof)) return;
     const int64_t Tout = L.out_len(io.Tin);
     const int64_t n_cols_all = L.transposed ? io.Tin + L.Ktaps - 1 : Tout;
     TileChoice tsel{L.cfg, L.w.as<float>(), L.w_phase_stride};

@@ -49,9 +49,11 @@ __device__ __forceinline__ float c3_other_half(float v, int hi) {
     return __uint_as_float(hi ? r[0] : r[1]);
 }
 
-constexpr int conv3s_occupancy(int TM) { return TM == 1 ? 5 : TM == 2 ? 4 : 3; }
+constexpr int conv3s_occupancy(int TM) { return TM == 1 ? 5 : TM == 2 ? 4 : 2; }
 
-template <int TM>
+// XV2: the rows are 8-byte aligned at even columns (one 8-byte load per lane and channel); otherwise two 4-byte loads (a row view that
+// starts at an odd sample: the trimmed output of an odd-padded transposed convolution, SConvTranspose1d.cs:159-171)
+template <int TM, bool XV2>
 __global__ __launch_bounds__(256, conv3s_occupancy(TM)) void conv3_stream_kernel(const ConvArgs p) {
     constexpr int TN = 2, CB = 16, K = 3;
     constexpr int BM = 32 * TM, BNW = 32 * TN, BN = 4 * BNW;
@@ -112,7 +114,12 @@ __global__ __launch_bounds__(256, conv3s_occupancy(TM)) void conv3_stream_kernel
     const int last_pair = Cin / 2 - 1;
     auto load_pair = [&](int g, c3_f32x2& v, float& h) __attribute__((always_inline)) {
         const float* row = xb + (size_t)(2 * min(g, last_pair)) * x_cstride;
-        v = *reinterpret_cast<const c3_f32x2*>(row + x_lane_off);
+        if constexpr (XV2) {
+            v = *reinterpret_cast<const c3_f32x2*>(row + x_lane_off);
+        } else {
+            v[0] = row[x_lane_off];
+            v[1] = row[x_lane_off + 1];
+        }
         h = row[h_lane_off];
     };
 #pragma unroll
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(256, conv3s_occupancy(TM)) void conv3_stream_kernel
 
     auto act = [&](float t, float2 gb) __attribute__((always_inline)) -> float {
         if (in_mode & 1) t = ((t - in_mu) * in_rs) * gb.x + gb.y;    // GroupNorm(1,C) apply (NormConv1d.cs:155)
-        if (in_mode & 2) t = nc_eluf(t);
+        if (in_mode & 2) t = nc_eluf(t);   // (a branch-free ELU measured slower here: 138 -> 145 us on the 32 -> 16 layer)
         return t;
     };
 
@@ -242,11 +249,11 @@ __global__ __launch_bounds__(256, conv3s_occupancy(TM)) void conv3_stream_kernel
 }
 
 typedef void (*conv_kernel_fn)(const ConvArgs);
-conv_kernel_fn conv3_stream_kernel_table(int TM) {
+conv_kernel_fn conv3_stream_kernel_table(int TM, bool aligned) {
     switch (TM) {
-        case 1: return &conv3_stream_kernel<1>;
-        case 2: return &conv3_stream_kernel<2>;
-        case 4: return &conv3_stream_kernel<4>;
+        case 1: return aligned ? &conv3_stream_kernel<1, true> : &conv3_stream_kernel<1, false>;
+        case 2: return aligned ? &conv3_stream_kernel<2, true> : &conv3_stream_kernel<2, false>;
+        case 4: return aligned ? &conv3_stream_kernel<4, true> : &conv3_stream_kernel<4, false>;
     }
     return nullptr;
 }

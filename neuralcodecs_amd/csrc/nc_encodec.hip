@@ -1086,12 +1086,22 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
         // chunk*N columns with full 128-column tiles (cut out of [N,C,T], a chunk would fill a fifth of every tile: measured, the
         // per-chunk GEMMs then cost as much as the full one and 6 chunks made C3 2.2 ms slower).
         static const int want_chunks = [] { const char* e = std::getenv("NC_LSTM_CHUNKS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
-        int64_t chunk = T;
+        // chunk boundaries (even: chunk starts stay 8-byte aligned for the 1x1 path).  The layer above trails the layer below by its
+        // LAST chunk (+ that chunk's input-projection GEMM), so the last chunk is short (T/8) and the others share the rest: with 4
+        // chunks of 150 steps 44 / 44 / 44 / 18 instead of 38 / 38 / 38 / 36 -- the tail after layer 0 has finished shrinks from 36
+        // steps to 18 without a single extra cross-stream event.
+        std::vector<int64_t> cstart{0};
         if (nl >= 2 && want_chunks > 1 && T >= 32 && !on_side_group && (int64_t)4 * C * T * N < ((int64_t)1 << 31)) {
-            chunk = (((T + want_chunks - 1) / want_chunks) + 1) & ~(int64_t)1;   // even: chunk starts stay 8-byte aligned for the 1x1 path
-            chunk = std::max<int64_t>(chunk, 8);
+            static const bool even_chunks = std::getenv("NC_LSTM_EVEN_CHUNKS") && std::getenv("NC_LSTM_EVEN_CHUNKS")[0] == '1';
+            const int64_t last = even_chunks ? 0 : std::max<int64_t>(8, (T / 8) & ~(int64_t)1);
+            const int nbig = even_chunks ? want_chunks : want_chunks - 1;
+            int64_t big = ((((T - last) + nbig - 1) / nbig) + 1) & ~(int64_t)1;
+            big = std::max<int64_t>(big, 8);
+            for (int64_t t0 = big; t0 < T - last; t0 += big) cstart.push_back(t0);
+            if (last > 0 && T - last > cstart.back()) cstart.push_back(T - last);
         }
-        const int nch = (int)((T + chunk - 1) / chunk);
+        cstart.push_back(T);
+        const int nch = (int)cstart.size() - 1;
         const bool piped = nch > 1;
         const int nprod = C / 16, n_tiles = (N + 15) / 16, per_launch = std::max(1, 64 / nprod);
         const size_t lds = (size_t)4 * KS * 64 * 4 + 3 * 4 * 64 * 16;
@@ -1172,32 +1182,35 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
             io.y = g + t0 * N; io.y_bstride = 0; io.y_cstride = T * N;
             launch_conv(y.ih, io, 1, s, &prof);
         };
-        // layer 0's input projections depend on x alone: x goes to the [C][T][N] layout once and its chunk GEMMs run ahead on the second
-        // stream, chunk k releasing layer 0's chunk k -- the recurrence starts after the first chunk's GEMM, not after the whole one
-        std::vector<hipEvent_t> prev(nch, nullptr);   // prev[k]: chunk k of the layer below (for layer 0: of its input projection) is complete
+        // Layer 0's input projections depend on x alone: x goes to the [C][T][N] layout once and its chunk GEMMs run ahead on the second
+        // stream, chunk k releasing layer 0's chunk k (the recurrence starts after the first chunk's GEMM, not after the whole one).
+        // The projection GEMM of chunk k of a layer ABOVE runs on the stream of the layer BELOW, right behind that layer's chunk k:
+        // the layer above then runs its chunks back to back (on its own stream, GEMM and chunk alternating, it was the sum of both --
+        // ~1.0 ms for 0.78 ms of recurrence -- and bounded the whole LSTM), while the layer below, which finishes a short last chunk
+        // ahead anyway, absorbs the ~40 us per GEMM.  (A third stream for the GEMMs measured WORSE: the runtime multiplexes streams onto
+        // 4 hardware queues, the extra stream shared a queue with the tail-segment group or the other layer and serialised with it,
+        // +0.9 ms; with GPU_MAX_HW_QUEUES=8 every queue got slower gaps, +1.8 ms.)
+        std::vector<hipEvent_t> ready(nch, nullptr);   // ready[k]: the input projections of chunk k of the current layer are complete
         {
             float* xT = alloc((size_t)N * C * T);
             const int64_t n = (int64_t)N * C * T;
             hipLaunchKernelGGL(nct_to_ctn_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sB, x, xT, N, C, T);
             NC_HIP(hipGetLastError());
             for (int k = 0; k < nch; ++k) {
-                const int64_t t0 = (int64_t)k * chunk, t1 = std::min(T, t0 + chunk);
-                ih_gemm_chunk(*l.layers[0], xT, gi[0], t0, t1 - t0, sB);
-                prev[k] = next_event();
-                NC_HIP(hipEventRecord(prev[k], sB));
+                ih_gemm_chunk(*l.layers[0], xT, gi[0], cstart[(size_t)k], cstart[(size_t)k + 1] - cstart[(size_t)k], sB);
+                ready[k] = next_event();
+                NC_HIP(hipEventRecord(ready[k], sB));
             }
         }
         for (int li = 0; li < nl; ++li) {
             hipStream_t s = layer_stream(li);
             for (int k = 0; k < nch; ++k) {
-                const int64_t t0 = (int64_t)k * chunk, t1 = std::min(T, t0 + chunk);
-                NC_HIP(hipStreamWaitEvent(s, prev[k], 0));
-                if (li > 0) ih_gemm_chunk(*l.layers[li], out[li - 1], gi[li], t0, t1 - t0, s);
-                lstm_chunk(li, t0, t1);
+                NC_HIP(hipStreamWaitEvent(s, ready[k], 0));
+                lstm_chunk(li, cstart[(size_t)k], cstart[(size_t)k + 1]);
                 if (li + 1 < nl) {
-                    hipEvent_t e = next_event();
-                    NC_HIP(hipEventRecord(e, s));
-                    prev[k] = e;
+                    ih_gemm_chunk(*l.layers[li + 1], out[li], gi[li + 1], cstart[(size_t)k], cstart[(size_t)k + 1] - cstart[(size_t)k], s);
+                    ready[k] = next_event();
+                    NC_HIP(hipEventRecord(ready[k], s));
                 }
             }
         }
