@@ -19,10 +19,16 @@ namespace nc {
 constexpr int VQ_MAX_D = 16;
 constexpr int VQ_FRAMES_PER_WAVE = 4;   // 16 frames per workgroup: enough workgroups to spread a ~3 k-frame launch over the chip
 
+// DD > 0: the codebook dimension as a compile-time constant (DAC / SNAC: 8) -- with a run-time D every tap of the distance chain was a
+// predicated branch (16 per code: 112 us for ONE workgroup of SNAC's 4096-entry codebook; 75-110 us per launch at any size).  FPW: frames
+// per wavefront (4: 16 frames per workgroup, enough workgroups for a ~3 k-frame launch; 1 for launches of a few dozen frames).
+template <int DD, int FPW>
 __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict__ cbT, const float* __restrict__ c2,
-                                                        const float* __restrict__ cb_rm, int N, int D, const float* z_e,
+                                                        const float* __restrict__ cb_rm, int N, int Drt, const float* z_e,
                                                         int64_t ze_bstride, int B, int64_t T, int64_t* codes,
                                                         int64_t codes_bstride, float* st) {
+    constexpr int MAXD = DD > 0 ? DD : VQ_MAX_D;
+    const int D = DD > 0 ? DD : Drt;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_cb = smem;          // [D][N]
     float* s_c2 = smem + D * N;  // [N]
@@ -47,30 +53,31 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict_
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     const int64_t total = (int64_t)B * T;
-    const int64_t f0 = ((int64_t)blockIdx.x * 4 + wave) * VQ_FRAMES_PER_WAVE;
+    const int64_t f0 = ((int64_t)blockIdx.x * 4 + wave) * FPW;
     // all frames of the wave are fetched before any is searched: one global round trip instead of one per frame
-    float e[VQ_FRAMES_PER_WAVE][VQ_MAX_D];
+    float e[FPW][MAXD];
 #pragma unroll
-    for (int fi = 0; fi < VQ_FRAMES_PER_WAVE; ++fi) {
+    for (int fi = 0; fi < FPW; ++fi) {
         const int64_t f = min(f0 + fi, total - 1);
         const int64_t b = f / T, t = f - b * T;
         const float* zp = z_e + b * ze_bstride + t;
 #pragma unroll
-        for (int d = 0; d < VQ_MAX_D; ++d) e[fi][d] = d < D ? zp[(int64_t)d * T] : 0.0f;
+        for (int d = 0; d < MAXD; ++d) e[fi][d] = d < D ? zp[(int64_t)d * T] : 0.0f;
     }
-    int win[VQ_FRAMES_PER_WAVE];
+    int win[FPW];
 #pragma unroll
-    for (int fi = 0; fi < VQ_FRAMES_PER_WAVE; ++fi) {
+    for (int fi = 0; fi < FPW; ++fi) {
         float e2 = 0.0f;
 #pragma unroll
-        for (int d = 0; d < VQ_MAX_D; ++d)
+        for (int d = 0; d < MAXD; ++d)
             if (d < D) e2 = nc_fma(e[fi][d], e[fi][d], e2);
         float best = __builtin_inff();
         int bi = 0x7fffffff;
+#pragma unroll 4
         for (int n = lane; n < N; n += 64) {
             float cr = 0.0f;
 #pragma unroll
-            for (int d = 0; d < VQ_MAX_D; ++d)
+            for (int d = 0; d < MAXD; ++d)
                 if (d < D) cr = nc_fma(e[fi][d], s_cb[d * N + n], cr);
             const float dist = (e2 + s_c2[n]) - 2.0f * cr;
             if (dist < best) {
@@ -93,7 +100,7 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict_
     }
     // epilogue: codes and the straight-through values, restated literally (VectorQuantizer.cs:81): e + (q - e)
 #pragma unroll
-    for (int fi = 0; fi < VQ_FRAMES_PER_WAVE; ++fi) {
+    for (int fi = 0; fi < FPW; ++fi) {
         const int64_t f = f0 + fi;
         if (f >= total) break;
         const int64_t b = f / T, t = f - b * T;
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict_
             const float q = cb_rm[(int64_t)win[fi] * D + lane];
             float ev = 0.0f;
 #pragma unroll
-            for (int d = 0; d < VQ_MAX_D; ++d)
+            for (int d = 0; d < MAXD; ++d)
                 if (d == lane) ev = e[fi][d];
             st[(b * D + lane) * T + t] = ev + (q - ev);
         }
@@ -150,13 +157,23 @@ void launch_vq_argmin(const Codebook& cb, const float* z_e, int64_t ze_bstride, 
     if ((cb.D * cb.N) % 4 != 0) fail(NC_EUNSUPPORTED, "codebook of %d x %d entries is not a whole number of 16-byte words", cb.N, cb.D);
     const size_t lds = sizeof(float) * ((size_t)cb.D * cb.N + cb.N);
     if (lds > 160 * 1024) fail(NC_EUNSUPPORTED, "codebook of %d x %d does not fit LDS", cb.N, cb.D);
-    ensure_dynamic_lds((const void*)vq_argmin_kernel, 160 * 1024);
     const int64_t total = (int64_t)B * T;
-    const int64_t per_block = 4 * VQ_FRAMES_PER_WAVE;
+    const int fpw = total <= 256 ? 1 : VQ_FRAMES_PER_WAVE;   // a few dozen frames: one per wavefront, so that they spread over more CUs
+    const int64_t per_block = 4 * fpw;
     const int64_t grid = (total + per_block - 1) / per_block;
     if (prof && prof->on) prof->begin(s, NC_KC_RVQ, 3.0 * 2.0 * cb.D * cb.N * (double)total, 4.0 * total * (2.0 * cb.D + 2));
-    hipLaunchKernelGGL(vq_argmin_kernel, dim3((unsigned)grid), dim3(256), lds, s, cb.cbT.as<float>(), cb.c2.as<float>(),
-                       cb.cb.as<float>(), cb.N, cb.D, z_e, ze_bstride, B, T, codes, codes_bstride, st);
+    auto launch = [&](auto kern) {
+        ensure_dynamic_lds((const void*)kern, 160 * 1024);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, cb.cbT.as<float>(), cb.c2.as<float>(), cb.cb.as<float>(), cb.N, cb.D, z_e,
+                           ze_bstride, B, T, codes, codes_bstride, st);
+    };
+    if (cb.D == 8) {
+        if (fpw == 1) launch(vq_argmin_kernel<8, 1>);
+        else launch(vq_argmin_kernel<8, VQ_FRAMES_PER_WAVE>);
+    } else {
+        if (fpw == 1) launch(vq_argmin_kernel<0, 1>);
+        else launch(vq_argmin_kernel<0, VQ_FRAMES_PER_WAVE>);
+    }
     NC_HIP(hipGetLastError());
     if (prof && prof->on) prof->end(s);
 }
