@@ -719,9 +719,6 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     if (io.fuse_k1) lds_f = std::max(lds_f, fused_wide ? (size_t)2 * BM * 32 : (size_t)BM * BM);   // the 1x1 weights reuse the tile buffers
     a.ep_off = (int32_t)lds_f;
     size_t lds = sizeof(float) * (lds_f + 6 * (size_t)BM);
-#ifdef NC_DBG_TRACE
-    lds += 4 * 512 * c.NW;   // LDS staging of the diagnostic phase stamps
-#endif
     conv_kernel_fn fn = nullptr;
     if (io.fuse_k1) {
         if (!can_fuse_res_unit(L, *io.fuse_k1) || !io.alpha_out || !io.res || io.epi != 0)

@@ -14,14 +14,6 @@ namespace nc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-#ifdef NC_A_DMA
-// 16 bytes per lane global -> LDS by DMA (no registers, no LDS store instruction): lane l copies gbase[voff(l)] to lds_addr + 16*l.
-// Issued through inline assembly so that the compiler's wait-count insertion does not treat every later LDS read as dependent on it;
-// the kernel waits for vmcnt(0) itself before the barrier that publishes the buffer.
-__device__ __forceinline__ void nc_dma16(const void* gbase, unsigned voff_bytes, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff_bytes), "s"(gbase) : "memory");
-}
-#endif
 
 template <int N, class F, int... I>
 __device__ __forceinline__ void nc_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -38,16 +30,6 @@ struct nc_rt_flag {
     __device__ constexpr operator bool() const { return v; }
 };
 typedef __attribute__((address_space(1))) const void* nc_gptr;
-#ifdef NC_DBG_TRACE
-// diagnostic build only: per-wave phase timestamps of the workgroups that ran on one CU
-#define NC_TR_WAVES 96
-#define NC_TR_STAMPS 640
-extern __device__ unsigned long long nc_dbg_buf[NC_TR_WAVES * NC_TR_STAMPS];
-extern __device__ unsigned int nc_dbg_count;
-#define NC_TR() do { if (tr_on) { const unsigned t_ = (unsigned)__builtin_readcyclecounter(); if (lane == 0 && tr_n < 512) tr_l[tr_n] = t_; ++tr_n; } } while (0)
-#else
-#define NC_TR() do {} while (0)
-#endif
 typedef __attribute__((address_space(3))) void* nc_lptr;
 
 // Block = NW waves (4, or 8 for the wide variants).  Wave w owns all BM = 32*TM output channels of the tile and the
@@ -96,16 +78,8 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     constexpr int A_FLOATS = KB * BM;
     constexpr int A_VEC = A_FLOATS / 4;            // float4 words in the weight tile
     constexpr int NA = (A_VEC + SNT - 1) / SNT;    // float4 copies per staging thread
-#ifdef NC_A_DMA
-    constexpr bool A_DMA = A_VEC % 64 == 0;        // weight tile = whole wave-sized DMA rows: global -> LDS without registers
-#else
     constexpr bool A_DMA = false;
-#endif
-#ifdef NC_NSEG
-    constexpr int NSEG = SPEC ? 3 : DIST ? 2 : (KP >= 16 ? NC_NSEG : 2);
-#else
     constexpr int NSEG = SPEC ? 3 : DIST ? 2 : (KP >= 16 ? 4 : 2);   // (specialised: the producers stage a block in two groups)
-#endif
     constexpr int NG = NSEG - 1;
     constexpr int GA = (NA + NG - 1) / NG;         // per-group register footprint
     constexpr int GX = (NX + NG - 1) / NG;
@@ -124,36 +98,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     const bool producer = SPEC && wave >= NW;
     const int swave = SPEC ? wave - NW : wave;     // index among the staging waves (consumers of the specialised variant: unused)
     const int stid = SPEC ? tid - 64 * NW : tid;
-#ifdef NC_EXP_ASYMPRIO
-    // co-resident waves of one SIMD get different issue priorities (by hardware wave slot parity): the favoured wave runs its
-    // matrix-core segments at full rate and the other fills the gaps its staging leaves, instead of both stalling together
-    if (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1) __builtin_amdgcn_s_setprio(3);
-#endif
 
-#ifdef NC_DBG_TRACE
-    bool tr_on = false;
-    int tr_n = 0;
-    unsigned long long* tr_p = nullptr;
-    extern __shared__ __attribute__((aligned(16))) float smem_tr[];
-    unsigned* const tr_l = reinterpret_cast<unsigned*>(smem_tr + p.ep_off + 6 * 32 * TM) + 512 * wave;   // stamps staged in LDS
-    {
-        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));    // HW_ID
-        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // XCC_ID
-        const unsigned cu = (hw >> 8) & 15, se = (hw >> 13) & 7, sh = (hw >> 12) & 1;
-        if (xcc == 0 && se == 0 && sh == 0 && cu == 0) {
-            unsigned slot = 0;
-            if (lane == 0) slot = atomicAdd(&nc_dbg_count, 1u);
-            slot = __builtin_amdgcn_readfirstlane(slot);
-            if (slot < NC_TR_WAVES) {
-                tr_on = true;
-                tr_p = nc_dbg_buf + (size_t)slot * NC_TR_STAMPS;
-                if (lane == 0) { tr_p[0] = blockIdx.x; tr_p[1] = hw; tr_p[2] = wave; }
-                tr_p += 3;
-            }
-        }
-    }
-    NC_TR();
-#endif
     // ---- XCD-aware block -> tile map: block id b runs on XCD b%8 (observed; speed only).  Give each
     // XCD a contiguous range of the (phase, co_tile, clip, t_tile) order so the blocks resident on
     // one XCD share a weight panel in that XCD's L2.
@@ -251,45 +196,21 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     auto issue_group_to = [&](int cbn, auto gtag, f32x4 (&ra)[GA], float (&rx)[GXX]) __attribute__((always_inline)) {
         constexpr int g = decltype(gtag)::value;
         const f32x4* src = wbase + (size_t)cbn * A_VEC;
-#ifdef NC_A_DMA
-        // window reads first: the DMA rows go out behind them, so a wait the compiler places for its own reads never covers a DMA
-#endif
         nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value, i = g * GX + u;
             if constexpr (i < NX) {
                 const int ci = min(cbn * CB + xc[i], Cin - 1);           // wave-uniform
                 const float* row = xb + (size_t)((unsigned)ci * x_cstride);   // uniform base + 32-bit lane offset
-#ifdef NC_ABL_NOLOADX
-                rx[u] = (float)xg[i];
-#else
                 rx[u] = row[xg[i]];
                 if constexpr (IN2) rx[GX + u] = (xb2 + (size_t)((unsigned)ci * x_cstride))[xg[i]];
-#endif
             }
         });
         nc_static_for<GA>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value, n = g * GA + u;
             if constexpr (n < NA) {
-#ifdef NC_ABL_NOLOADA
-                ra[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-#elif defined(NC_A_DMA)
-                // weight vectors SNT*n + 64*swave .. +63 of block cbn straight into its LDS buffer (cbn & 1); whole waves only
-                if constexpr (A_DMA) {
-                    const int idx0 = SNT * n + 64 * swave;
-                    if (idx0 < A_VEC) {
-                        typedef __attribute__((address_space(3))) float* lds_fp;
-                        const unsigned lds0 = (unsigned)(uintptr_t)(lds_fp)(As0 + ((cbn & 1) ? A_FLOATS : 0));
-                        nc_dma16(src + idx0, (unsigned)lane * 16u, lds0 + (unsigned)idx0 * 16u);
-                    }
-                } else {
-                    const f32x4* srcn = src + SNT * n;
-                    ra[u] = srcn[(A_VEC % SNT == 0) ? (unsigned)stid : min((unsigned)stid, (unsigned)(A_VEC - 1 - SNT * n))];
-                }
-#else
                 // uniform pointer (scalar arithmetic) + the thread index: no per-read vector address arithmetic
                 const f32x4* srcn = src + SNT * n;
                 ra[u] = srcn[(A_VEC % SNT == 0) ? (unsigned)stid : min((unsigned)stid, (unsigned)(A_VEC - 1 - SNT * n))];
-#endif
             }
         });
     };
@@ -303,10 +224,8 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
             constexpr int u = decltype(ut)::value, n = g * GA + u;
             if constexpr (n < NA) {
                 const int idx = stid + SNT * n;
-#if !defined(NC_ABL_NOSTOREA)
                 if constexpr (!A_DMA)
                     if ((A_VEC % SNT == 0) || idx < A_VEC) reinterpret_cast<f32x4*>(Ad)[idx] = ra[u];
-#endif
             }
         });
         float2 al[GX];
@@ -364,11 +283,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         if constexpr (!FUSE && !SPEC && !DIST) {
             if (in_mode) { store_group(cbn, Ad, Xd, gtag, std::integral_constant<int, 2>{}); return; }
         }
-#ifdef NC_ABL_NOSNAKE
-        if (false)
-#else
         if (alpha_in != nullptr)
-#endif
             store_group(cbn, Ad, Xd, gtag, std::true_type{});
         else store_group(cbn, Ad, Xd, gtag, std::false_type{});
     };
@@ -426,18 +341,11 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 if constexpr (!FUSE && !SPEC && !DIST) {
                     if (in_mode) { store_group_from(0, As0, Xs0, g, std::integral_constant<int, 2>{}, ra0[gi], rx0[gi]); return; }
                 }
-#ifdef NC_ABL_NOSNAKE
-                if (false)
-#else
                 if (alpha_in != nullptr)
-#endif
                     store_group_from(0, As0, Xs0, g, std::true_type{}, ra0[gi], rx0[gi]);
                 else store_group_from(0, As0, Xs0, g, std::false_type{}, ra0[gi], rx0[gi]);
             });
     }
-#ifdef NC_A_DMA
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     __syncthreads();
 
     // window column of this lane's tile columns (one per 32-column block j): column + the halos of the segments before it
@@ -457,10 +365,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         xt[k] = x_lane + (hi ? d : 0);
     }
 
-#ifndef NC_FRAG_DEPTH
-#define NC_FRAG_DEPTH 1
-#endif
-    constexpr int FD = NC_FRAG_DEPTH;            // fragment reads run FD matrix-core steps ahead (FD + 1 register sets)
+    constexpr int FD = 1;            // fragment reads run FD matrix-core steps ahead (FD + 1 register sets)
     float fa[FD + 1][TM], fb[FD + 1][TN];
     // Ac = current weight buffer + hi*BM (the kk row of this lane half at step 0); xsc = scalar float index of the current window
     auto load_frag = [&](const float* Ac, int xsc, auto kp_tag) __attribute__((always_inline)) {
@@ -488,11 +393,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 const int cur = cb & 1;
                 float* const An = As0 + (cur ^ 1) * A_FLOATS;
                 float* const Xn = Xs0 + (cur ^ 1) * xbuf;
-#if !defined(NC_ABL_NOSTAGE)
                 if (cb + 1 < n_cb)
-#else
-                if (false)
-#endif
                     nc_static_for<NG>([&](auto g) __attribute__((always_inline)) {
                         constexpr int gi = decltype(g)::value;
                         // next group in flight: group gi+1 of this block, or group 0 of the block after
@@ -573,12 +474,8 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 __syncthreads();
             }
         };
-#ifdef NC_ABL_NOSNAKE
-        run_loop(std::false_type{});
-#else
         if (alpha_in != nullptr) run_loop(std::true_type{});
         else run_loop(std::false_type{});
-#endif
     } else
     for (int cb = 0; cb < n_cb; ++cb) {
         const int cur = cb & 1;
@@ -604,52 +501,30 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         } else
         nc_static_for<NSEG>([&](auto seg_tag) __attribute__((always_inline)) {
             constexpr int seg = decltype(seg_tag)::value;
-            NC_TR();
-#if !defined(NC_ABL_NOSTAGE)
             if (more) {
                 if constexpr (seg >= 1) store_group_any(cb + 1, An, Xn, std::integral_constant<int, (seg >= 1 ? seg - 1 : 0)>{});
                 if constexpr (seg < NG) issue_group(cb + 1, seg_tag);
             }
-#endif
             // ---- matrix-core steps of this segment, ascending kk; fragments of step kp+1 are read before
             //      the MFMAs of step kp are issued (register double buffer fa/fb)
-            NC_TR();
             constexpr int kp_lo = seg * KP / NSEG, kp_hi = (seg + 1) * KP / NSEG;
             if constexpr (seg == 0)
                 nc_static_for<FD>([&](auto d) __attribute__((always_inline)) {
                     if constexpr (decltype(d)::value < KP) load_frag(Ac, Xc, d);
                 });
-#ifdef NC_EXP_SETPRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
             nc_static_for<kp_hi - kp_lo>([&](auto d) __attribute__((always_inline)) {
                 constexpr int kp = kp_lo + decltype(d)::value;
-#if !defined(NC_ABL_NOFRAG)
                 if constexpr (kp + FD < KP) load_frag(Ac, Xc, std::integral_constant<int, kp + FD>{});
-#endif
-#ifdef NC_EXP_SCHED
                 __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of step kp+1 ahead of the MFMAs of step kp
-#endif
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp % (FD + 1)][i], fb[kp % (FD + 1)][j], acc[i][j], 0, 0, 0);
             });
-#ifdef NC_EXP_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
         });
-        NC_TR();
-#ifdef NC_A_DMA
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA rows of the next block have landed
-#endif
-#if !defined(NC_ABL_NOBAR)
         __syncthreads();
-#endif
-        NC_TR();
     }
-    NC_TR();
     // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*hi][col = l31]
     // Element (row block ib, register r, column j) of this lane lives at tile_base + lane_off[j] + R(ib,r)*cstride with
     // R = 32*ib + (r&3) + 8*(r>>2) a compile-time row: one uniform 64-bit base, 32-bit lane offsets (the host bounds them).
@@ -1035,16 +910,6 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         });
         }
     }
-    NC_TR();
-#ifdef NC_DBG_TRACE
-    if (tr_on) {
-        const unsigned long long tnow = __builtin_readcyclecounter();
-        for (int i = lane; i < min(tr_n, 512); i += 64) {   // widen the 32-bit LDS stamps against the final 64-bit reading
-            const unsigned lo = tr_l[i];
-            tr_p[i] = tnow - (unsigned long long)((unsigned)tnow - lo);
-        }
-    }
-#endif
 }
 
 typedef void (*conv_kernel_fn)(const ConvArgs);

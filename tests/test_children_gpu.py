@@ -70,3 +70,24 @@ def test_group_local_mode_two_devices_ragged():
 @pytest.mark.skipif(_n_gpus() < 4, reason="needs four GPUs")
 def test_group_local_mode_more_devices_than_clips():
     _finish([_run(["group_local", 4, 3])])
+
+
+# A three-row subset of tools/probe/envmatrix.sh: every fast path has a switch back to the path it replaced, and the parity tests must
+# hold on those paths too (fresh interpreters: the switches are read once per process).
+FALLBACK_ROWS = [
+    {"NC_NO_GN_FUSE": "1", "NC_NO_IN2": "1", "NC_NO_CONV3S": "1"},                     # stand-alone GroupNorm sums, summed copies, windowed k=3
+    {"NC_LSTM_STEPWISE": "1", "NC_NO_TINY_TILES": "1", "NC_NO_SUBPIXEL": "1"},         # step-wise LSTM, filled-grid tile rule, per-phase up-convs
+    {"NC_NO_FUSE": "1", "NC_ENCODEC_NO_FUSE": "1", "NC_DAC_RVQ_STAGEWISE": "1"},       # two-launch residual units, padded copies, stage-wise RVQ
+]
+
+
+@pytest.mark.parametrize("row", FALLBACK_ROWS, ids=lambda r: "+".join(sorted(r)))
+def test_parity_under_fallback_switches(row):
+    e = dict(os.environ, **row)
+    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+           os.path.join(ROOT, "tests", "test_encodec_gpu.py") + "::test_encodec_small_vs_golden_and_oracle",
+           os.path.join(ROOT, "tests", "test_encodec_gpu.py") + "::test_encodec48k_config_c3_shape",
+           os.path.join(ROOT, "tests", "test_dac_gpu.py") + "::test_small_bit_exact_vs_c_oracle",
+           os.path.join(ROOT, "tests", "test_snac_gpu.py")]
+    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])

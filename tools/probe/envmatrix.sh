@@ -1,5 +1,6 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: the parity suites under each fallback switch (the non-default code paths stay correct)
+# Runs ON THE GPU BOX: the parity suites under each fallback switch (the non-default code paths stay correct).  A three-row subset of
+# this matrix runs inside `pytest -m gpu` (tests/test_children_gpu.py::test_parity_under_fallback_switches).
 cd $GRAFT_REPO_ROOT
 run() { echo "== $*"; env "$@" timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_dac_gpu.py tests/test_encodec_gpu.py tests/test_snac_gpu.py -m gpu -x -q 2>&1 | grep -E "passed|failed|rror" | head -3; }
 run NC_DEFAULT=1
@@ -7,4 +8,7 @@ run NC_NO_FLAT=1
 run NC_CO_GROUP=1
 run NC_LSTM_CHUNKS=1 NC_EUCLID_NO_MFMA=1 NC_THIN_NO_VEC=1
 run NC_NO_WIDE_FUSE=1 NC_NO_TILE_ALTS=1
-run NC_WIDE_FUSE_192=1 NC_LSTM_CHUNKS=7
+run NC_WIDE_FUSE_192=1 NC_LSTM_CHUNKS=7 NC_LSTM_EVEN_CHUNKS=1
+run NC_NO_GN_FUSE=1 NC_NO_IN2=1 NC_NO_CONV3S=1
+run NC_LSTM_STEPWISE=1 NC_NO_TINY_TILES=1 NC_NO_SUBPIXEL=1
+run NC_NO_FUSE=1 NC_ENCODEC_NO_FUSE=1 NC_DAC_RVQ_STAGEWISE=1
