@@ -143,3 +143,85 @@ def test_dia_code_matrix_glue_vs_oracle_restatement():
     with pytest.raises(ValueError):
         m.decode_code_matrix(np.zeros((2, 5, cfg.n_codebooks + 1), np.int64))
     m.dispose()
+
+
+# ---- N1 for SNAC and Encodec on the ENGINE (VERDICT r2 "missing" 4): file -> converter -> blob -> C ABI == oracle fed the tensors directly ----
+def test_snac_checkpoint_files_run_on_the_engine(tmp_path):
+    """SNAC checkpoints carry the reference's own parameter names (`...parametrizations.weight.original0/1`, Modules/SNAC/WNConv1d.cs:66-70;
+    LoadWeights: Models/SNAC.cs:200-231 dispatches on the file type).  A safetensors file and a torch .pth of the same tensors must both load
+    and give, on the engine, exactly what the C oracle gives on the tensors themselves."""
+    import torch
+    from safetensors.numpy import save_file
+    from conftest import snac_cfg_from_meta
+    from neuralcodecs_amd import SNAC
+    from neuralcodecs_amd.weights import snac_noise, snac_synthetic_state_dict
+    g = load_golden("snac_small_attn")                                  # the LocalMHA variant: every parameter family is present
+    cfg = snac_cfg_from_meta(g["meta"])
+    sd = snac_synthetic_state_dict(cfg, seed=31)
+    assert any(k.endswith("parametrizations.weight.original1") for k in sd)
+    pcm = synthetic_pcm(2, 1, 2500, cfg.sampling_rate, seed=9)
+    ref = c_oracle.RefSNAC(cfg, save_blob(sd))
+    rz, rzq, rcodes = ref.encode(pcm)
+    p1, p2 = tmp_path / "snac.safetensors", tmp_path / "pytorch_model.bin"
+    save_file({k: np.ascontiguousarray(v) for k, v in sd.items()}, str(p1))
+    torch.save({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, str(p2))
+    for p in (p1, p2):
+        blob, meta = checkpoint.convert_checkpoint(str(p), "snac")
+        assert meta is None
+        m = SNAC(cfg)
+        m.load_blob(blob)
+        codes = m.encode(pcm)
+        for a, b in zip(codes, rcodes):
+            assert np.array_equal(a, b)
+        noise = snac_noise(cfg, 2, rz.shape[-1], seed=4)
+        assert np.array_equal(m.decode(codes, noise), ref.decode(rcodes, noise))
+        q = tmp_path / (p.name + ".ncwb")                                  # LoadWeights(path) through nc_codec_load_weights
+        q.write_bytes(blob)
+        m2 = SNAC(cfg)
+        m2.load_weights(str(q))
+        for a, b in zip(m2.encode(pcm), rcodes):
+            assert np.array_equal(a, b)
+        m.dispose()
+        m2.dispose()
+    with pytest.raises(FileNotFoundError):
+        checkpoint.convert_checkpoint(str(tmp_path / "nope.safetensors"), "snac")
+
+
+@pytest.mark.parametrize("name", ["encodec_small48", "encodec_small24"])
+def test_encodec_checkpoint_files_run_on_the_engine(tmp_path, name):
+    """Encodec checkpoints are keyed like the reference's modules (SConv1d.cs:110-128; LoadWeights: Models/Encodec.cs:348-385) and carry the
+    EuclideanCodebook training buffers (cluster_size / embed_avg / inited, EuclideanCodebook.cs:60-66), which the converter drops."""
+    import torch
+    from safetensors.numpy import save_file
+    from conftest import encodec_cfg_from_meta
+    from neuralcodecs_amd import Encodec
+    from neuralcodecs_amd.weights import encodec_synthetic_state_dict
+    g = load_golden(name)
+    cfg = encodec_cfg_from_meta(g["meta"])
+    sd = encodec_synthetic_state_dict(cfg, seed=33)
+    full = dict(sd)
+    rng = np.random.default_rng(5)
+    for k in [k for k in sd if k.endswith("codebook.embed")]:            # what a real checkpoint holds beside the embedding table
+        base = k[: -len("embed")]
+        full[base + "embed_avg"] = rng.standard_normal(sd[k].shape).astype(np.float32)
+        full[base + "cluster_size"] = rng.uniform(0, 5, sd[k].shape[0]).astype(np.float32)
+        full[base + "inited"] = np.ones(1, np.float32)
+    pcm = g["pcm"]
+    ref = c_oracle.RefEncodec(cfg, save_blob(sd))
+    rframes = ref.encode(pcm)
+    raudio = ref.decode(rframes)
+    p1, p2 = tmp_path / "model.safetensors", tmp_path / "encodec.th"
+    save_file({k: np.ascontiguousarray(v) for k, v in full.items()}, str(p1))
+    torch.save({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in full.items()}, str(p2))
+    for p in (p1, p2):
+        blob, _ = checkpoint.convert_checkpoint(str(p), "encodec")
+        m = Encodec(cfg)
+        m.load_blob(blob)
+        frames = m.encode(pcm)
+        assert len(frames) == len(rframes)
+        for f, (rc, rs) in zip(frames, rframes):
+            assert np.array_equal(f.codes, rc)
+            if rs is not None:
+                assert np.array_equal(f.scale, rs)
+        assert np.array_equal(m.decode(frames, pcm.shape[-1]), raudio)
+        m.dispose()

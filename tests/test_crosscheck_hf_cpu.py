@@ -41,3 +41,13 @@ def test_encodec_48k_layout_matches_hf_end_to_end_and_d9_is_reproduced():
     assert r["codes_equal_frac"] >= 0.995 and r["scale_max_abs"] < 1e-6                            # Euclidean RVQ + RMS scale
     assert r["decode_len"][0] == r["decode_len"][1]
     assert r["decode_max_abs"] <= 1e-5 * max(1.0, r["decode_scale"])                               # decoder + scale + linear overlap-add
+
+
+def test_snac_local_attention_matches_an_independent_composition():
+    """SNAC has no HF model; its LocalMHA (LocalMHA.cs:78-115) is checked against torch.nn modules + HF's Llama rotary embedding +
+    block-diagonal-masked full attention (tools/crosscheck_hf.py::crosscheck_snac_localmha)."""
+    import crosscheck_hf
+    r = crosscheck_hf.crosscheck_snac_localmha(seed=0)
+    assert r["inv_freq_max_abs"] == 0.0
+    assert r["max_abs"] <= 2e-6 * max(1.0, r["scale"])
+    assert r["without_rotary_max_abs"] > 1e-3

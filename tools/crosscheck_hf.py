@@ -168,7 +168,59 @@ def crosscheck_encodec48(seed=0, T=8064):
     return out
 
 
+def crosscheck_snac_localmha(seed=0, C=128, T=48, window=8):
+    """SNAC's LocalMHA (Modules/SNAC/LocalMHA.cs:78-115, SinusoidalEmbedding.cs:33-106, RotaryEmbedding.cs:46-68) as restated in
+    oracle/torch_ref/snac.py, against an INDEPENDENT composition: torch.nn.LayerNorm / nn.Linear modules, heads split in the
+    full-sequence layout, HF transformers' Llama rotary embedding (its own inv_freq table and rotate-half convention) evaluated at the
+    position INSIDE the window, and plain softmax attention over the whole sequence under a block-diagonal mask -- no window reshape
+    anywhere.  Agreement pins the window partition, the head / channel order of the fused qkv projection, the rotary convention and
+    positions, and the 1/sqrt(64) scale."""
+    import types
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaRotaryEmbedding, apply_rotary_pos_emb
+    from oracle.torch_ref.snac import TorchSNAC
+    torch.manual_seed(seed)
+    heads = C // 64
+    key = "mha"
+    norm = torch.nn.LayerNorm(C)
+    to_qkv = torch.nn.Linear(C, 3 * C, bias=False)
+    to_out = torch.nn.Linear(C, C, bias=False)
+    with torch.no_grad():
+        norm.weight.uniform_(0.8, 1.2)
+        norm.bias.normal_(0, 0.05)
+    rope = LlamaRotaryEmbedding(LlamaConfig(hidden_size=C, num_attention_heads=heads, head_dim=64, rope_theta=10000.0, max_position_embeddings=window))
+    sd = {key + ".norm.weight": norm.weight.detach(), key + ".norm.bias": norm.bias.detach(), key + ".to_qkv.weight": to_qkv.weight.detach(),
+          key + ".to_out.weight": to_out.weight.detach(),
+          key + ".rel_pos.inv_freq": (1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64)))}          # SinusoidalEmbedding.cs:52-54
+    ours = TorchSNAC.__new__(TorchSNAC)                       # only local_mha is exercised: no full model behind it
+    ours.sd, ours.attn = sd, window
+    x = torch.randn(2, C, T)
+    out = {"inv_freq_max_abs": float((sd[key + ".rel_pos.inv_freq"] - rope.inv_freq).abs().max())}
+    with torch.inference_mode():
+        y = ours.local_mha(x, key)
+        h = norm(x.transpose(1, 2))                                           # [B, T, C]
+        q, k, v = to_qkv(h).chunk(3, dim=-1)
+        q, k, v = (t.reshape(2, T, heads, 64).transpose(1, 2) for t in (q, k, v))   # [B, heads, T, 64]
+        pos = (torch.arange(T) % window)[None].expand(2, T)
+        cos, sin = rope(x, pos)
+        q, k = apply_rotary_pos_emb(q, k, cos, sin)
+        scores = torch.einsum("bhtd,bhsd->bhts", q, k) / 8.0
+        blk = torch.arange(T) // window
+        scores = scores.masked_fill(blk[:, None] != blk[None, :], float("-inf"))
+        a = torch.einsum("bhts,bhsd->bhtd", scores.softmax(-1), v)
+        y_ind = to_out(a.transpose(1, 2).reshape(2, T, C)).transpose(1, 2) + x
+        out["max_abs"] = float((y - y_ind).abs().max())
+        out["scale"] = float(y_ind.abs().max())
+        # and the check has teeth: the same composition WITHOUT the rotary embedding differs at O(0.1 .. 1)
+        q0, k0, _ = (t.reshape(2, T, heads, 64).transpose(1, 2) for t in to_qkv(h).chunk(3, dim=-1))
+        s2 = (torch.einsum("bhtd,bhsd->bhts", q0, k0) / 8.0).masked_fill(blk[:, None] != blk[None, :], float("-inf"))
+        y2 = to_out(torch.einsum("bhts,bhsd->bhtd", s2.softmax(-1), v).transpose(1, 2).reshape(2, T, C)).transpose(1, 2) + x
+        out["without_rotary_max_abs"] = float((y2 - y_ind).abs().max())
+    return out
+
+
 if __name__ == "__main__":
     print("dac    ", crosscheck_dac())
     print("encodec", crosscheck_encodec())
     print("encodec48", crosscheck_encodec48())
+    print("snac_mha", crosscheck_snac_localmha())
