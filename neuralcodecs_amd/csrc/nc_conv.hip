@@ -311,14 +311,16 @@ static TileChoice choose_tile(const ConvLayer& L, int64_t blocks_per_rowtile, bo
         // its serial reduction, TM matrix-core chains long per step, so the SMALLEST row tile finishes first -- SNAC 24 kHz at one clip:
         // the 384 -> 768 k=16 down-convolution ran 8 workgroups of 96 rows for 450 us (C1: 2.85 ms in all).
         static const bool no_tiny = std::getenv("NC_NO_TINY_TILES") && std::getenv("NC_NO_TINY_TILES")[0] == '1';
-        if (!no_tiny && blocks_per_rowtile * ((L.rows() + 31) / 32) <= 256) {
-            int tm = L.cfg.TM;
-            for (const auto& a : L.alts)
-                if (a->cfg.TM < tm) {
-                    tm = a->cfg.TM;
-                    best = TileChoice{a->cfg, a->w.as<float>(), a->w_phase_stride};
-                }
-            return best;
+        static const int tiny_blocks = std::getenv("NC_TINY_BLOCKS") ? atoi(std::getenv("NC_TINY_BLOCKS")) : 256;
+        if (!no_tiny) {
+            // the smallest packed row tile whose grid still stays under `tiny_blocks` workgroups
+            int tm = 0;
+            for (int cand = 1; cand < L.cfg.TM && !tm; ++cand) {
+                if (blocks_per_rowtile * ((L.rows() + 32 * cand - 1) / (32 * cand)) > tiny_blocks) continue;
+                for (const auto& a : L.alts)
+                    if (a->cfg.TM == cand) { tm = cand; best = TileChoice{a->cfg, a->w.as<float>(), a->w_phase_stride}; }
+            }
+            if (tm) return best;
         }
     }
     static const int tm_pick = std::getenv("NC_TM_PICK") ? atoi(std::getenv("NC_TM_PICK")) : 0;   // experiment: force a packed variant
