@@ -77,6 +77,11 @@ struct ConvArgs {
     // at gn_part[((clip*gn_nrb + row block)*gn_ncb + column block)*2]; null = off.  Plain epilogues only (bias, no residual / activation).
     double* gn_part;
     int32_t gn_nrb, gn_ncb;
+    // finishing inside the launch (nc_gn.h nc_gn_arrive_and_finish): per-sample arrival counters (self-resetting), the (mean, rstd)
+    // output [B][2] and the element count C*T; gn_count null = the caller runs gn_final_kernel afterwards
+    unsigned* gn_count;
+    float* gn_stats;
+    double gn_n;
 };
 
 // Position of row (32*i + r) of a weight tile inside one kk row of BM = 32*TM floats.  The TM values of one matrix-core lane
@@ -158,6 +163,9 @@ struct ConvIO {
     const float* in_beta2 = nullptr;
     double* gn_part = nullptr;                  // GroupNorm block sums of the output ([B][gn_nrb][gn_ncb][2], see ConvArgs::gn_part); needs conv_gn_fusable()
     int gn_nrb = 0, gn_ncb = 0;
+    unsigned* gn_count = nullptr;               // with gn_part: finish the statistics inside the launch (per-sample counters, zero between launches)
+    float* gn_stats = nullptr;                  // [B][2] (mean, rstd)
+    double gn_n = 0.0;                          // elements per sample (C * T of the normalised tensor)
     const float* alpha_out2 = nullptr;          // with fuse_k1: Snake applied to the unit's output y (consumer's activation)
     const struct ConvLayer* fuse_k1 = nullptr;  // fused residual unit: the 1x1 layer applied to snake(alpha_out)(this conv) + res
 };

@@ -384,7 +384,7 @@ static bool launch_conv3_stream(const ConvLayer& L, const ConvIO& io, int B, hip
     a.y = io.y; a.y_bstride = io.y_bstride; a.y_cstride = io.y_cstride;
     a.in_mode = (io.in_stats ? 1 : 0) | (io.in_elu ? 2 : 0);
     a.in_stats = io.in_stats; a.in_gamma = io.in_gamma; a.in_beta = io.in_beta;
-    a.gn_part = io.gn_part; a.gn_nrb = io.gn_nrb; a.gn_ncb = io.gn_ncb;
+    a.gn_part = io.gn_part; a.gn_nrb = io.gn_nrb; a.gn_ncb = io.gn_ncb; a.gn_count = io.gn_count; a.gn_stats = io.gn_stats; a.gn_n = io.gn_n;
     a.Cout = L.Cout; a.B = B; a.Tout = (int32_t)T;
     const int BM = tc.cfg.BM();
     a.n_co_tiles = (L.Cout + BM - 1) / BM;
@@ -426,7 +426,7 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
     a.res = io.res; a.noise = io.noise; a.noise_bstride = T; a.epi = io.epi; a.alpha_out = io.alpha_out;
     a.y = io.y; a.y_bstride = io.y_bstride; a.y_cstride = io.y_cstride;
     a.in_mode = in_mode; a.in_stats = io.in_stats; a.in_gamma = io.in_gamma; a.in_beta = io.in_beta;
-    a.gn_part = io.gn_part; a.gn_nrb = io.gn_nrb; a.gn_ncb = io.gn_ncb;
+    a.gn_part = io.gn_part; a.gn_nrb = io.gn_nrb; a.gn_ncb = io.gn_ncb; a.gn_count = io.gn_count; a.gn_stats = io.gn_stats; a.gn_n = io.gn_n;
     a.Cout = L.Cout; a.B = B; a.Tout = (int32_t)T;
     const int BM = tc.cfg.BM();
     a.n_co_tiles = (L.Cout + BM - 1) / BM;
@@ -671,7 +671,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     a.alpha_out = io.alpha_out; a.res = io.res;
     a.y = io.y; a.y_bstride = io.y_bstride; a.y_cstride = io.y_cstride;
     a.rvq_zq = io.rvq_zq; a.rvq_res = io.rvq_res;
-    a.gn_part = io.gn_part; a.gn_nrb = io.gn_nrb; a.gn_ncb = io.gn_ncb;
+    a.gn_part = io.gn_part; a.gn_nrb = io.gn_nrb; a.gn_ncb = io.gn_ncb; a.gn_count = io.gn_count; a.gn_stats = io.gn_stats; a.gn_n = io.gn_n;
     a.noise = io.noise; a.noise_bstride = L.out_len(io.Tin);
     if ((io.epi & EPI_NOISE) && (!io.noise || !io.res)) fail(NC_ESTATE, "internal: noise epilogue needs noise and residual");
     a.Cout = L.rows(); a.sub_shift = L.sub_shift; a.B = B; a.epi = io.epi;

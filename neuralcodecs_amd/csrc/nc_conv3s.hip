@@ -226,10 +226,11 @@ __global__ __launch_bounds__(256, conv3s_occupancy(TM)) void conv3_stream_kernel
             s1 = nc_gn_swap_add<true>(s1);
             s2 = nc_gn_swap_add<true>(s2);
             const int rbk = co_tile * TM + i, cbk = (col0 >> 5) + (l31 >> 4);
-            if ((lane & 47) == 0 && rbk < p.gn_nrb && cbk < p.gn_ncb)
-                *reinterpret_cast<double2*>(gp + ((int64_t)rbk * p.gn_ncb + cbk) * 2) = double2{s1, s2};
+            if ((lane & 47) == 0 && rbk < p.gn_nrb && cbk < p.gn_ncb) nc_gn_store_partial(gp + ((int64_t)rbk * p.gn_ncb + cbk) * 2, s1, s2);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (p.gn_count != nullptr)
+            nc_gn_arrive_and_finish(gp, p.gn_count + b, p.gn_stats + 2 * b, p.gn_nrb * p.gn_ncb, (unsigned)(p.n_co_tiles * p.n_t_tiles), p.gn_n);
     }
     if (col >= T) return;
     const int64_t tile_base = (int64_t)b * p.y_bstride + (int64_t)co_tile * BM * p.y_cstride;

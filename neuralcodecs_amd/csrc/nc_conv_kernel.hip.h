@@ -729,13 +729,16 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                         nc_gn_slot_sums<FULL>(vv, okm16, s1, s2);
                         nc_gn_butterfly(s1, s2);
                         const int rbk = co_tile * TM + i, cbk = (col0 + wave * BNW + j * 32) >> 5;
-                        if (lane == 0 && rbk < p.gn_nrb && cbk < p.gn_ncb)
-                            *reinterpret_cast<double2*>(gp + ((int64_t)rbk * p.gn_ncb + cbk) * 2) = double2{s1, s2};
+                        if (lane == 0 && rbk < p.gn_nrb && cbk < p.gn_ncb) nc_gn_store_partial(gp + ((int64_t)rbk * p.gn_ncb + cbk) * 2, s1, s2);
                         __builtin_amdgcn_sched_barrier(0);   // one block at a time: the sums of several blocks in flight spill
                     }
             };
             if (tile_full) gn_blocks(std::true_type{});
             else gn_blocks(std::false_type{});
+            // the last workgroup of the sample to arrive turns the block sums into (mean, rstd): no follow-up launch.  (Reads -- the
+            // arrival's returned count, the last arriver's loads -- all precede this workgroup's first output store.)
+            if (p.gn_count != nullptr)
+                nc_gn_arrive_and_finish(gp, p.gn_count + b, p.gn_stats + 2 * b, p.gn_nrb * p.gn_ncb, (unsigned)(p.n_co_tiles * p.n_t_tiles), p.gn_n);
         }
     }
     if constexpr (!FUSE) {

@@ -845,6 +845,8 @@ void EncodecModel::load(const Blob& b) {
     }
     snprintf(nm, sizeof nm, "decoder.layers.%d", n + 1);
     load_sconv(b, nm, dec_out, nf, cfg.channels, cfg.last_kernel_size, 1, false);
+    gn_counters.reserve((size_t)3 * GN_MAX_SAMPLES * sizeof(unsigned));
+    NC_HIP(hipMemset(gn_counters.p, 0, (size_t)3 * GN_MAX_SAMPLES * sizeof(unsigned)));
     if (!lstm_tmo_host) {
         void* hp = nullptr;
         NC_HIP(hipHostMalloc(&hp, 64, hipHostMallocMapped));
@@ -928,23 +930,33 @@ EncodecModel::GnJob EncodecModel::gn_begin(const ConvLayer& conv, ConvIO& io, in
     j.nrb = (int)(((int64_t)C * sub + 31) / 32);
     j.ncb = (int)(((L + sub - 1) / sub + 31) / 32);
     j.part = reinterpret_cast<double*>(alloc((size_t)N * j.nrb * j.ncb * 4));
+    j.stats = alloc((size_t)N * 2);
     if (conv_gn_fusable(conv, io)) {
         io.gn_part = j.part; io.gn_nrb = j.nrb; io.gn_ncb = j.ncb;
         j.fused = true;
+        // finish inside the launch: the last workgroup of a sample to arrive writes (mean, rstd).  One self-resetting counter per
+        // sample; the segment groups of a call run concurrently, so each has its own set.
+        static const bool no_finish = std::getenv("NC_NO_GN_FINISH") && std::getenv("NC_NO_GN_FINISH")[0] == '1';
+        if (!no_finish && N <= GN_MAX_SAMPLES) {
+            io.gn_count = gn_counters.as<unsigned>() + (size_t)cur_group * GN_MAX_SAMPLES;
+            io.gn_stats = j.stats;
+            io.gn_n = (double)C * (double)L;
+            j.finished = true;
+        }
     }
     return j;
 }
 const float* EncodecModel::gn_end(const GnJob& j, const float* raw, int N, int C, int64_t L) {
     if (!j.on) return nullptr;
-    float* stats = alloc((size_t)N * 2);
+    if (j.finished) return j.stats;
     const int64_t n = (int64_t)j.nrb * j.ncb;
     ProfScope ps(&prof, stream, NC_KC_NORM, 3.0 * N * C * (double)L, j.fused ? 16.0 * N * (double)n : 4.0 * N * C * (double)L);
     if (!j.fused)
         hipLaunchKernelGGL(gn_block_kernel, dim3((unsigned)(((int64_t)N * n + 3) / 4)), dim3(256), 0, stream, raw, j.part, (int64_t)N, C, L, j.sub, j.nrb,
                            j.ncb);
-    hipLaunchKernelGGL(gn_final_kernel, dim3((unsigned)N), dim3(64), 0, stream, j.part, stats, n, (double)C * (double)L);
+    hipLaunchKernelGGL(gn_final_kernel, dim3((unsigned)N), dim3(64), 0, stream, j.part, j.stats, n, (double)C * (double)L);
     NC_HIP(hipGetLastError());
-    return stats;
+    return j.stats;
 }
 
 // SConv1d.forward on an activated view: returns the raw conv output with its pending GroupNorm.
@@ -1344,6 +1356,7 @@ void EncodecModel::encode_dev(const float* pcm, int B, int64_t T, int64_t* codes
         const Seg& s = segs[f];
         const int side = (n_groups > 0 && !no_overlap) ? (n_groups - 1) % 2 : -1;   // groups after the first: side streams
         on_side_group = side >= 0;
+        cur_group = side + 1;
         if (side >= 0) {
             stream = side_stream[side];
             if (!side_used[side]) NC_HIP(hipStreamWaitEvent(stream, ev_fork, 0));
@@ -1360,6 +1373,7 @@ void EncodecModel::encode_dev(const float* pcm, int B, int64_t T, int64_t* codes
         emb_off += (int64_t)G * B * D * s.frames;
         stream = main_stream;
         on_side_group = false;
+        cur_group = 0;
         f = g;
     }
     for (int i = 0; i < 2; ++i)
@@ -1396,6 +1410,7 @@ void EncodecModel::decode_dev(const int64_t* codes, const float* scales, int B, 
         const int G = (int)(g - f);
         const int side = (n_groups > 0 && !no_overlap) ? (n_groups - 1) % 2 : -1;
         on_side_group = side >= 0;
+        cur_group = side + 1;
         if (side >= 0) {
             stream = side_stream[side];
             if (!side_used[side]) NC_HIP(hipStreamWaitEvent(stream, ev_fork, 0));
@@ -1411,6 +1426,7 @@ void EncodecModel::decode_dev(const int64_t* codes, const float* scales, int B, 
         code_off += (int64_t)G * B * nq * segs[f].frames;
         stream = main_stream;
         on_side_group = false;
+        cur_group = 0;
         f = g;
     }
     for (int i = 0; i < 2; ++i)

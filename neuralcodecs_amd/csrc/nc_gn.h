@@ -66,4 +66,51 @@ __device__ __forceinline__ void nc_gn_slot_sums(const float (&v)[16], unsigned o
     }
 }
 
+// ---- finishing the statistics inside the producing launch ------------------------------------------------------------------------------
+// Every workgroup of a launch belongs to ONE sample; after its block sums are stored it arrives on the sample's counter, and the
+// LAST workgroup to arrive adds the block sums of the sample (gn_final's order: 64 strided slots + butterfly) and writes (mean, rstd)
+// -- no follow-up launch.  Hand-off in the placement-independent form of cdna_hip_programming.md G16 / R1 (the form the persistent LSTM
+// uses): the block sums are stored WRITE-THROUGH (relaxed agent-scope stores, sc1), each wave drains them (vmcnt(0)) before the
+// workgroup barrier, ONE relaxed agent-scope fetch-add per workgroup publishes the arrival, and the last arriver reads the sums with
+// agent-scope (sc1) loads, which bypass its CU's L1.  The counter is reset by the last arriver (nothing touches it again before the
+// next launch on this stream), so it never needs a memset.  The (mean, rstd) pair is consumed by the NEXT kernel: a plain store.
+typedef __attribute__((address_space(1))) unsigned nc_gn_gu32;
+__device__ __forceinline__ void nc_gn_store_partial(double* q, double s1, double s2) {
+    __hip_atomic_store(q, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Called by EVERY thread of the workgroup (it holds barriers), after the writer lanes have issued nc_gn_store_partial.
+// part: the sample's block sums [n][2]; n_wg: workgroups of this launch that belong to the sample; count = C*T elements.
+__device__ __forceinline__ void nc_gn_arrive_and_finish(const double* part, unsigned* counter, float* stats, int n, unsigned n_wg, double count) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's block sums have reached memory
+    __syncthreads();
+    if (threadIdx.x >= 64) return;                     // the first wavefront arrives for the workgroup (and finishes, if it is the last)
+    unsigned prev = 0;
+    if (threadIdx.x == 0) prev = __hip_atomic_fetch_add((nc_gn_gu32*)counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    prev = __builtin_amdgcn_readfirstlane(prev);
+    if (prev + 1 != n_wg) return;
+    const int lane = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k0 = 0; k0 < n; k0 += 64 * 4) {
+        double a[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + lane + 64 * u;
+            a[u] = k < n ? __hip_atomic_load(part + 2 * (size_t)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            c[u] = k < n ? __hip_atomic_load(part + 2 * (size_t)k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s1 += a[u]; s2 += c[u]; }
+    }
+    nc_gn_butterfly(s1, s2);
+    if (lane == 0) {
+        const double mu = s1 / count;
+        double var = s2 / count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        stats[0] = (float)mu;
+        stats[1] = (float)(1.0 / sqrt(var + 1e-5));
+        __hip_atomic_store((nc_gn_gu32*)counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace nc

@@ -266,7 +266,10 @@ struct EncodecModel : Codec {
     void load_lstm(const Blob& b, const std::string& key, Lstm& l, int C);
     float* alloc(size_t n_floats);
     float* pad_act(const Act& a, const Act* b2, bool elu, int N, const Plan& pl);
-    struct GnJob { bool on = false, fused = false; int sub = 1, nrb = 0, ncb = 0; double* part = nullptr; };
+    struct GnJob { bool on = false, fused = false, finished = false; int sub = 1, nrb = 0, ncb = 0; double* part = nullptr; float* stats = nullptr; };
+    static constexpr int GN_MAX_SAMPLES = 4096;   // rows of a segment group (encode_dev caps a group at 4096)
+    DevBuf gn_counters;                           // [3 groups][GN_MAX_SAMPLES] arrival counters of the in-launch GroupNorm finish (zero between launches)
+    int cur_group = 0;
     GnJob gn_begin(const ConvLayer& conv, ConvIO& io, int N, int C, int64_t L, int sub);
     const float* gn_end(const GnJob& j, const float* raw, int N, int C, int64_t L);
     Act sconv(SConv& L, const Act& a, const Act* b2, bool elu, int N);
