@@ -271,8 +271,7 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
                 f32x2 v = {acc[i][0][r], acc[i][1][r]};
                 if constexpr (SNAKE) {   // Snake of the consuming layer, fused into the store
                     const float ao = Ep[BM + R + 4 * hi], ao_inv = Ep[2 * BM + R + 4 * hi];
-                    v[0] = nc_snakef(v[0], ao, ao_inv);
-                    v[1] = nc_snakef(v[1], ao, ao_inv);
+                    v = nc_snakef2(v, nc_f2{ao, ao}, nc_f2{ao_inv, ao_inv});   // two values per packed instruction (nc_math.h)
                 }
                 float* rowp = yt + (size_t)R * cstride;
                 *reinterpret_cast<f32x2*>(rowp + lane_off) = v;
@@ -319,8 +318,7 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
                     }
                     if constexpr (SNAKE) {
                         const float ao = Ep[BM + R + 4 * hi], ao_inv = Ep[2 * BM + R + 4 * hi];
-                        v[0] = nc_snakef(v[0], ao, ao_inv);
-                        v[1] = nc_snakef(v[1], ao, ao_inv);
+                        v = nc_snakef2(v, nc_f2{ao, ao}, nc_f2{ao_inv, ao_inv});   // two values per packed instruction (nc_math.h)
                     }
                     *reinterpret_cast<f32x2*>(yt + (size_t)R * cstride + lane_off) = v;
                 }
@@ -465,8 +463,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvArgs p
                     f32x2 v = {acc[i][0][r], acc[i][1][r]};
                     if constexpr (SNAKE) {
                         const float ao = Ep[BM + R + 4 * hi], ao_inv = Ep[2 * BM + R + 4 * hi];
-                        v[0] = nc_snakef(v[0], ao, ao_inv);
-                        v[1] = nc_snakef(v[1], ao, ao_inv);
+                        v = nc_snakef2(v, nc_f2{ao, ao}, nc_f2{ao_inv, ao_inv});   // two values per packed instruction (nc_math.h)
                     }
                     *reinterpret_cast<f32x2*>(yt + (size_t)R * cstride + lane_off) = v;
                 }

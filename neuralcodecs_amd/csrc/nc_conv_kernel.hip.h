@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                     if ((A_VEC % SNT == 0) || idx < A_VEC) reinterpret_cast<f32x4*>(Ad)[idx] = ra[u];
             }
         });
-        float2 al[GX];
+        float2 al[GX] = {};
         float2 al2[IN2 ? GX : 1];
         if (SNAKE || (IMODE == 2 && (in_mode & 1))) {
             nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 }
             });
         }
-        float v[GX];
+        float v[GX] = {};
         int off[GX];
         nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value, i = g * GX + u;
@@ -263,7 +263,6 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 } else {
                     v[u] = ok ? rx[u] : 0.0f;
                 }
-                if (SNAKE) v[u] = nc_snakef(v[u], al[u].x, al[u].y);
                 off[u] = item * 64 + lane;
                 if (s != 1) {
                     const int q = (j * stride_magic) >> 20;
@@ -271,6 +270,11 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 }
             }
         });
+        if constexpr (SNAKE) {   // Snake of the consumed tensor, two window values per packed instruction (nc_math.h; items past NX: unused)
+#pragma unroll
+            for (int u = 0; u + 1 < GX; u += 2) nc_snake_pair(v[u], v[u + 1], al[u].x, al[u].y, al[u + 1].x, al[u + 1].y);
+            if constexpr (GX & 1) v[GX - 1] = nc_snakef(v[GX - 1], al[GX - 1].x, al[GX - 1].y);
+        }
         nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value, i = g * GX + u;
             if constexpr (i < NX) Xd[off[u]] = v[u];
@@ -636,16 +640,28 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                     }
                 }
             }
+            float vq[4][TN];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) vq[rr][j] = v[j][4 * rq + rr];
+            if (snake) {   // Snake of the consuming layer, two rows per packed instruction (nc_math.h)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr += 2) {
+                    const int R = ib * 32 + rr + 8 * rq + 4 * hi;
+                    const float a0 = ao_t[R], i0 = ao_t[BM + R], a1 = ao_t[R + 1], i1 = ao_t[BM + R + 1];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) nc_snake_pair(vq[rr][j], vq[rr + 1][j], a0, i0, a1, i1);
+                }
+            }
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int R = ib * 32 + rr + 8 * rq;     // D row of register r = 4*rq + rr (plus 4*hi)
-                const float ao = ao_t[R + 4 * hi], ao_inv = ao_t[BM + R + 4 * hi];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if (!(FULL || okrow(j, R))) continue;
                     const unsigned o = lane_off_s[j] + roff(R);
-                    float val = v[j][4 * rq + rr];
-                    if (snake) val = nc_snakef(val, ao, ao_inv);
+                    float val = vq[rr][j];
                     if (decltype(gen_tag)::value && (p.epi & EPI_TANH)) val = nc_tanhf(val);
                     if (rvq) {
                         yt[o] = zv[rr][j] + val;
@@ -788,11 +804,17 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 16; r += 2) {   // rows r, r + 1 of a register quad: two values per packed instruction (nc_math.h)
                 const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float bias = Ep[row], ao = Ep[BM + row], ao_inv = Ep[2 * BM + row];
+                const float b0 = Ep[row], a0 = Ep[BM + row], i0 = Ep[2 * BM + row];
+                const float b1 = Ep[row + 1], a1 = Ep[BM + row + 1], i1 = Ep[2 * BM + row + 1];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j][r] = nc_snakef(acc[i][j][r] + bias, ao, ao_inv);
+                for (int j = 0; j < TN; ++j) {
+                    float x0 = acc[i][j][r] + b0, x1 = acc[i][j][r + 1] + b1;
+                    nc_snake_pair(x0, x1, a0, i0, a1, i1);
+                    acc[i][j][r] = x0;
+                    acc[i][j][r + 1] = x1;
+                }
             }
         // 2) accumulator layout -> B-operand layout, in place
 #pragma unroll

@@ -241,7 +241,11 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
         if (alpha_out) {
             const float a = al[2 * co], ai = al[2 * co + 1];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = nc_snakef(o[q], a, ai);
+            for (int q = 0; q < 4; q += 2) {
+                const nc_f2 r = nc_snakef2(nc_f2{o[q], o[q + 1]}, nc_f2{a, a}, nc_f2{ai, ai});   // two values per packed instruction (nc_math.h)
+                o[q] = r[0];
+                o[q + 1] = r[1];
+            }
         }
         float* yp = yr + (int64_t)co * y_cstride;
         if (vec_ok && t + 3 < Tout) {

@@ -6,6 +6,8 @@
 //   avg_pool1d       Modules/SNAC/VectorQuantizer.cs:88 ; repeat_interleave  VectorQuantizer.cs:100, ResidualVectorQuantizer.cs:120
 //   LayerNorm / SDPA Modules/SNAC/LocalMHA.cs:85,105 ; rotary  RotaryEmbedding.cs:46-68 ; randn  NoiseBlock.cs:41
 // Arithmetic is the canonical arithmetic of DESIGN.md (same sequences as oracle/c/nc_ref_snac.c).
+#include <cstdlib>
+
 #include "nc_elem.h"
 #include "nc_math.h"
 
@@ -38,11 +40,18 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
 #pragma unroll
         for (int u = 0; u < NJ; ++u) {
             asm volatile("" : "+v"(r[u]));
+            const int gp = t0 - pad + j0 + (int)threadIdx.x + 256 * u;
+            r[u] = (gp >= 0 && gp < T) ? r[u] : 0.0f;
+        }
+        if (alpha_in) {   // Snake on the way in, two values per packed instruction (nc_math.h)
+#pragma unroll
+            for (int u = 0; u + 1 < NJ; u += 2) nc_snake_pair(r[u], r[u + 1], ai, ai_inv, ai, ai_inv);
+            if (NJ & 1) r[NJ - 1] = nc_snakef(r[NJ - 1], ai, ai_inv);
+        }
+#pragma unroll
+        for (int u = 0; u < NJ; ++u) {
             const int j = j0 + threadIdx.x + 256 * u;
-            const int gp = t0 - pad + j;
-            float v = (gp >= 0 && gp < T) ? r[u] : 0.0f;
-            if (alpha_in) v = nc_snakef(v, ai, ai_inv);
-            if (j < span) win[j] = v;
+            if (j < span) win[j] = r[u];
         }
     }
     __syncthreads();
@@ -53,24 +62,116 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
     const float ao = alpha_out ? alpha_out[c] : 0.0f;
     const float ao_inv = nc_snake_inv(ao);
     float* yr = y + ((int64_t)b * C + c) * T;
+    float ov[DW_TT / 256];
 #pragma unroll
     for (int i = 0; i < DW_TT / 256; ++i) {
         const int lt = threadIdx.x + 256 * i;
-        const int t = t0 + lt;
-        if (t >= T) break;
         float a = 0.0f;
 #pragma unroll
         for (int k = 0; k < DW_MAXK; ++k)
             if (k < K) a = nc_fma(wk[k], win[lt + k * dil], a);
-        float v = a + bv;
-        if (alpha_out) v = nc_snakef(v, ao, ao_inv);
-        yr[t] = v;
+        ov[i] = a + bv;
+    }
+    if (alpha_out) {
+#pragma unroll
+        for (int i = 0; i < DW_TT / 256; i += 2) nc_snake_pair(ov[i], ov[i + 1], ao, ao_inv, ao, ao_inv);
+    }
+#pragma unroll
+    for (int i = 0; i < DW_TT / 256; ++i) {
+        const int t = t0 + (int)threadIdx.x + 256 * i;
+        if (t < T) yr[t] = ov[i];
+    }
+}
+
+// Vector form for the residual units' k = 7 depthwise convolutions (dilation 1 / 3 / 9, "same" padding 3*dil; rows 16-byte aligned,
+// T a multiple of 4): the window starts at a 16-byte boundary of the row (SH slots before position t0 - pad), is read with 16-byte
+// loads, activated two values per packed instruction and stored with ds_write_b128; a thread computes two groups of 4 consecutive
+// outputs (group stride 1024: the b128 LDS reads of a wavefront are 16 bytes apart, conflict-free) and writes 16-byte stores.
+// Same arithmetic per output as dwconv_kernel: fma chain over k ascending from +0, + bias, Snake.
+typedef float dw_f32x4 __attribute__((ext_vector_type(4)));
+template <int DIL>
+__global__ __launch_bounds__(256) void dwconv_vec_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         const float* __restrict__ alpha_in, const float* __restrict__ alpha_out,
+                                                         float* __restrict__ y, int C, int T) {
+    constexpr int K = 7, PAD = 3 * DIL, SH = (4 - (PAD & 3)) & 3;
+    constexpr int SPAN = DW_TT + (K - 1) * DIL + SH, NWORDS = (SPAN + 3) / 4;        // window slots / 16-byte words
+    constexpr int NW = (4 + (K - 1) * DIL + SH + 3) / 4;                              // words a group of 4 outputs reads
+    __shared__ __attribute__((aligned(16))) float win[NWORDS * 4 + 4];
+    const int tid = threadIdx.x, tile = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+    const int t0 = tile * DW_TT, g0 = t0 - PAD - SH;                                  // input position of window slot 0 (a multiple of 4)
+    const float* xr = x + ((int64_t)b * C + c) * T;
+    const int xw4 = T >> 2;
+    const float ai = alpha_in ? alpha_in[c] : 0.0f, ai_inv = nc_snake_inv(ai);
+    constexpr int NL = (NWORDS + 255) / 256;
+    dw_f32x4 r[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        const int wq = (g0 >> 2) + tid + 256 * u;
+        r[u] = reinterpret_cast<const dw_f32x4*>(xr)[min(max(wq, 0), xw4 - 1)];       // clamped: always in bounds
+    }
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        const int wq = (g0 >> 2) + tid + 256 * u;
+        if (wq < 0 || wq >= xw4) r[u] = dw_f32x4{0.0f, 0.0f, 0.0f, 0.0f};             // (T % 4 == 0: a word is all in or all out)
+        if (alpha_in) {
+            const nc_f2 lo = nc_snakef2(nc_f2{r[u][0], r[u][1]}, nc_f2{ai, ai}, nc_f2{ai_inv, ai_inv});
+            const nc_f2 hi = nc_snakef2(nc_f2{r[u][2], r[u][3]}, nc_f2{ai, ai}, nc_f2{ai_inv, ai_inv});
+            r[u] = dw_f32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+        if (tid + 256 * u < NWORDS) reinterpret_cast<dw_f32x4*>(win)[tid + 256 * u] = r[u];
+    }
+    __syncthreads();
+    float wk[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) wk[k] = w[c * K + k];
+    const float bv = bias ? bias[c] : 0.0f;
+    const float ao = alpha_out ? alpha_out[c] : 0.0f, ao_inv = nc_snake_inv(ao);
+    float* yr = y + ((int64_t)b * C + c) * T;
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+        const int lt = grp * 1024 + 4 * tid;                                          // first of this group's 4 outputs (tile-local)
+        float wv[4 * NW];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const dw_f32x4 v = reinterpret_cast<const dw_f32x4*>(win)[(lt >> 2) + q];
+            wv[4 * q] = v[0]; wv[4 * q + 1] = v[1]; wv[4 * q + 2] = v[2]; wv[4 * q + 3] = v[3];
+        }
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float a = 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) a = nc_fma(wk[k], wv[i + SH + k * DIL], a);
+            o[i] = a + bv;
+        }
+        if (alpha_out) {
+            const nc_f2 lo = nc_snakef2(nc_f2{o[0], o[1]}, nc_f2{ao, ao}, nc_f2{ao_inv, ao_inv});
+            const nc_f2 hi = nc_snakef2(nc_f2{o[2], o[3]}, nc_f2{ao, ao}, nc_f2{ao_inv, ao_inv});
+            o[0] = lo[0]; o[1] = lo[1]; o[2] = hi[0]; o[3] = hi[1];
+        }
+        const int t = t0 + lt;
+        if (t < T) *reinterpret_cast<dw_f32x4*>(yr + t) = dw_f32x4{o[0], o[1], o[2], o[3]};   // (T % 4 == 0: a group is all in or all out)
     }
 }
 
 void launch_dwconv(const DwConvLayer& L, const float* x, const float* alpha_in, const float* alpha_out, float* y, int B, int64_t T,
                    hipStream_t s, Profiler* prof) {
     if (L.K > DW_MAXK) fail(NC_EUNSUPPORTED, "depthwise kernel size %d > %d", L.K, DW_MAXK);
+    {
+        static const bool no_vec = std::getenv("NC_DW_NO_VEC") && std::getenv("NC_DW_NO_VEC")[0] == '1';
+        const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+        if (!no_vec && L.K == 7 && L.pad == 3 * L.dil && (L.dil == 1 || L.dil == 3 || L.dil == 9) && (T & 3) == 0 && T >= 4 && al) {
+            dim3 grid((unsigned)((T + DW_TT - 1) / DW_TT), (unsigned)L.C, (unsigned)B);
+            if (prof && prof->on) prof->begin(s, NC_KC_DWCONV, 2.0 * L.K * L.C * (double)T * B, 8.0 * L.C * (double)T * B);
+            const float* bp = L.has_bias ? L.bias.as<float>() : nullptr;
+            if (L.dil == 1) hipLaunchKernelGGL(dwconv_vec_kernel<1>, grid, dim3(256), 0, s, x, L.w.as<float>(), bp, alpha_in, alpha_out, y, L.C, (int)T);
+            else if (L.dil == 3) hipLaunchKernelGGL(dwconv_vec_kernel<3>, grid, dim3(256), 0, s, x, L.w.as<float>(), bp, alpha_in, alpha_out, y, L.C, (int)T);
+            else hipLaunchKernelGGL(dwconv_vec_kernel<9>, grid, dim3(256), 0, s, x, L.w.as<float>(), bp, alpha_in, alpha_out, y, L.C, (int)T);
+            NC_HIP(hipGetLastError());
+            if (prof && prof->on) prof->end(s);
+            return;
+        }
+    }
     const size_t lds = sizeof(float) * (DW_TT + (L.K - 1) * L.dil);
     dim3 grid((unsigned)((T + DW_TT - 1) / DW_TT), (unsigned)L.C, (unsigned)B);
     if (prof && prof->on) prof->begin(s, NC_KC_DWCONV, 2.0 * L.K * L.C * (double)T * B, 8.0 * L.C * (double)T * B);

@@ -84,3 +84,39 @@ NC_HD float nc_snakef(float x, float alpha, float inv) {
 // ELU (alpha = 1) and the logistic function of the Encodec layers, on the canonical exp (SEANetEncoder.cs ELU, SLSTM.cs gates)
 NC_HD float nc_eluf(float x) { return x > 0.0f ? x : nc_expf(x) - 1.0f; }
 NC_HD float nc_sigmoidf(float x) { return 1.0f / (1.0f + nc_expf(-x)); }
+
+#if defined(__HIPCC__)
+// Two-at-a-time forms for the device kernels: the SAME operation sequences on a pair of values, written on 2-vectors so that the
+// multiplies / fmas / adds compile to the packed fp32 instructions of gfx950 (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two
+// IEEE operations per lane and issue slot -- the Snake activation is ~25 vector instructions per element and bounds the depthwise
+// kernel and the residual units' epilogues).  Bit-identical to nc_sinf / nc_snakef per element.
+typedef float nc_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ nc_f2 nc_fma2(nc_f2 a, nc_f2 b, nc_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ nc_f2 nc_sinf2(nc_f2 x) {
+    const nc_f2 n = __builtin_elementwise_rint(x * 0x1.45f306p-2f);
+    nc_f2 r = nc_fma2(n, (nc_f2)(-3.140625f), x);
+    r = nc_fma2(n, (nc_f2)(-9.67502593994140625e-4f), r);
+    r = nc_fma2(n, (nc_f2)(-1.509957990978376432e-7f), r);
+    const nc_f2 u = r * r;
+    nc_f2 p = (nc_f2)(-0x1.9d5778p-26f);
+    p = nc_fma2(p, u, (nc_f2)(0x1.71936ap-19f));
+    p = nc_fma2(p, u, (nc_f2)(-0x1.a018f4p-13f));
+    p = nc_fma2(p, u, (nc_f2)(0x1.111110p-7f));
+    p = nc_fma2(p, u, (nc_f2)(-0x1.555556p-3f));
+    nc_f2 s = nc_fma2(r * u, p, r);
+    const int n0 = (int)n[0], n1 = (int)n[1];
+    s[0] = (n0 & 1) ? -s[0] : s[0];
+    s[1] = (n1 & 1) ? -s[1] : s[1];
+    return s;
+}
+__device__ __forceinline__ nc_f2 nc_snakef2(nc_f2 x, nc_f2 alpha, nc_f2 inv) {
+    const nc_f2 s = nc_sinf2(alpha * x);
+    return x + (s * s) * inv;
+}
+// in-place on two scalars
+__device__ __forceinline__ void nc_snake_pair(float& x0, float& x1, float a0, float i0, float a1, float i1) {
+    const nc_f2 r = nc_snakef2(nc_f2{x0, x1}, nc_f2{a0, a1}, nc_f2{i0, i1});
+    x0 = r[0];
+    x1 = r[1];
+}
+#endif
