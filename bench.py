@@ -332,7 +332,8 @@ def main():
                 "bound": "mfma", "achieved": round(ach_tflops, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": round(tk7["hbm_bytes_per_launch"]) if tk7 else None,
-                "traffic_unit": "HBM bytes per launch of this class (PMC FETCH_SIZE x2 + WRITE_SIZE over exactly the launches the class counts; profiles/traffic.json)",
+                "traffic_unit": "HBM bytes per launch of this class (PMC FETCH_SIZE x2 + WRITE_SIZE over exactly the launches the class counts)",
+                "traffic_source": "profiles/traffic.json: separate rocprofv3 --pmc passes of this bench command on this build (tools/profile_round.sh); a committed constant, NOT measured in this run (counters need the profiler)",
                 "traffic_over_algorithmic": round(tk7["hbm_bytes_per_launch"] / algo_b, 3) if tk7 and algo_b else None,
                 "mfma_busy": tk7.get("mfma_busy"),
                 "algorithmic_bytes_per_launch": round(algo_b),
