@@ -170,6 +170,24 @@ struct ConvIO {
     const struct ConvLayer* fuse_k1 = nullptr;  // fused residual unit: the 1x1 layer applied to snake(alpha_out)(this conv) + res
 };
 
+// arguments of the thin-output convolution in the Encodec input mode (nc_conv_thin.hip conv_thin_inm_kernel)
+struct ThinInmArgs {
+    const float* xa;
+    const float* xb2;            // nullable second operand (same geometry)
+    int64_t x_bstride, x_cstride;
+    int Cin, L, left, Lz, Lp;    // rows of L samples; padded position j in [0, Lp) reads q = reflect(j - left) over [0, Lz); q >= L is zero
+    const float* stats_a; const float* gamma_a; const float* beta_a;
+    const float* stats_b; const float* gamma_b; const float* beta_b;
+    int elu;
+    const float* w;              // dense [COUT][Cin][7]
+    const float* bias;
+    float* y;
+    int64_t y_bstride, y_cstride;
+    int Tout, n_t_tiles;
+    double* gn_part; int gn_ncb; unsigned* gn_count; float* gn_stats; double gn_n;
+};
+bool launch_conv_thin_inm(const ThinInmArgs& a, int B, int Cout, hipStream_t s);
+
 TileCfg pick_tile(int Cout, int Ktaps);
 // true when `k7` followed by `k1` can run as one fused residual-unit launch
 bool can_fuse_res_unit(const ConvLayer& k7, const ConvLayer& k1);  // TN is chosen per launch from the column count

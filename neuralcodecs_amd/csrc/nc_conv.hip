@@ -460,9 +460,16 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
     return true;
 }
 
+// thin-output layers the input-mode streaming kernel serves: Conv1d(C -> 1|2, k = 7), stride 1, no dilation, explicit padding
+static bool thin_inm_layer(const ConvLayer& L) {
+    static const bool off = std::getenv("NC_NO_THIN_INM") && std::getenv("NC_NO_THIN_INM")[0] == '1';
+    return !off && L.w_thin.p && !L.transposed && L.K == 7 && L.stride == 1 && L.dil == 1 && L.pad == 0 && L.Cout <= 2;
+}
+
 bool conv_in2_available(const ConvLayer& L) {
     static const bool off = std::getenv("NC_NO_IN2") && std::getenv("NC_NO_IN2")[0] == '1';
-    if (off || L.w_thin.p || L.w_stem.p || L.w_skinny.p) return false;
+    if (off || L.w_stem.p || L.w_skinny.p) return false;
+    if (L.w_thin.p) return thin_inm_layer(L);   // the PCM head in the input mode takes both operands (conv_thin_inm_kernel)
     // Only where ONE row tile covers all output rows: every row tile re-stages (normalises twice, adds, activates) the window it
     // shares with the others, and on the matrix-core-bound deep layers that vector work sits on the critical path -- measured on C3:
     // 64 -> 128 k8 419 -> 432 us, 128 -> 256 k10 493 -> 1224 us, 256 -> 512 k16 +370 us against the summed copy + one-input launch,
@@ -477,7 +484,8 @@ bool conv_gn_fusable(const ConvLayer& L, const ConvIO& io) {
     // stem / skinny kernels keep the stand-alone statistics pass (launch_conv skips them when gn_part is set, so the answer here only
     // has to say which layers are WORTH routing through the matrix-core template: all but those three)
     if (off || io.res || io.alpha_out || io.alpha_in || io.epi || io.fuse_k1 || L.n_phase != 1) return false;
-    if (L.w_thin.p || L.w_stem.p || L.w_skinny.p) return false;
+    if (L.w_thin.p) return thin_inm_layer(L) && io.in_L > 0;   // (the input-mode head kernel emits its sums; the plain head does not)
+    if (L.w_stem.p || L.w_skinny.p) return false;
     return true;
 }
 
@@ -495,6 +503,24 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
                            io.y_bstride, io.y_cstride, B, L.Cin, L.Cout, io.Tin, stream);
         if (prof && prof->on) prof->end(stream);
         return;
+    }
+    if (thin_inm_layer(L) && io.in_L > 0 && !io.alpha_in && !io.alpha_out && !io.res && !io.fuse_k1 && io.epi == 0 &&
+        (!io.x2 || (io.in_stats != nullptr) == (io.in_stats2 != nullptr))) {
+        // the PCM head in the Encodec input mode: both operands, normalise + add + ELU + reflect pad while staging, GroupNorm sums of the output
+        ThinInmArgs t{};
+        t.xa = io.x; t.xb2 = io.x2; t.x_bstride = io.x_bstride; t.x_cstride = io.x_cstride;
+        t.Cin = L.Cin; t.L = (int)io.in_L; t.left = (int)io.in_left; t.Lz = (int)io.in_Lz; t.Lp = (int)io.Tin;
+        t.stats_a = io.in_stats; t.gamma_a = io.in_gamma; t.beta_a = io.in_beta;
+        t.stats_b = io.in_stats2; t.gamma_b = io.in_gamma2; t.beta_b = io.in_beta2;
+        t.elu = io.in_elu ? 1 : 0;
+        t.w = L.w_thin.as<float>(); t.bias = L.has_bias ? L.bias.as<float>() : nullptr;
+        t.y = io.y; t.y_bstride = io.y_bstride; t.y_cstride = io.y_cstride;
+        t.Tout = (int)L.out_len(io.Tin);
+        t.gn_part = io.gn_part; t.gn_ncb = io.gn_ncb; t.gn_count = io.gn_count; t.gn_stats = io.gn_stats; t.gn_n = io.gn_n;
+        if (io.gn_part && io.gn_nrb != 1) fail(NC_ESTATE, "internal: thin head with more than one GroupNorm row block");
+        ProfScope ps(prof, stream, L.kclass, L.flops(B, io.Tin),
+                     4.0 * ((double)B * L.Cin * io.in_L * (io.x2 ? 2 : 1) + (double)B * L.Cout * t.Tout + (double)L.Cin * L.Cout * L.K));
+        if (launch_conv_thin_inm(t, B, L.Cout, stream)) return;
     }
     {   // thin-output layers (PCM heads): streaming kernel instead of a 32-row matrix tile with 1-2 live rows
         static const bool no_thin = std::getenv("NC_NO_THIN") && std::getenv("NC_NO_THIN")[0] == '1';

@@ -8,6 +8,7 @@
 #include <type_traits>
 
 #include "nc_conv.h"
+#include "nc_gn.h"
 #include "nc_math.h"
 
 namespace nc {
@@ -191,6 +192,155 @@ bool launch_conv_thin(const float* x, int64_t x_bstride, int64_t x_cstride, int 
                         : launch_thin_k<2>(K, vec, grid, lds, s, x, x_bstride, x_cstride, Cin, x_len, w_dense, bias, y, y_bstride, y_cstride, (int)Tout, pad, dil, ntt, tanh_out);
     if (ok) NC_HIP(hipGetLastError());
     return ok;
+}
+
+// Thin-output convolution in the Encodec input mode (the decoder's last SConv1d(32 -> 2, k = 7), SEANetDecoder.cs:140-148, fed by the sum
+// of a residual block's shortcut and branch, each a raw conv output with a pending GroupNorm; SConv1d.cs:144-173 reflect pad 3 + 3;
+// NormConv1d.cs:155 GroupNorm(1, 2) over its own output).  Everything the summed / activated / padded copy and the stand-alone statistics
+// pass did happens here: a window slot reads sample q = reflect(j - left) of both operands, normalises each with its own statistics,
+// adds, applies the ELU (the zero extension stays zero) and goes to LDS; the outputs' GroupNorm block sums (nc_gn.h: the two live rows
+// of a 32-row block, 32-column blocks = 8 consecutive threads) are reduced in registers and finished in the launch.
+constexpr int THIN_INM_CC = 4;
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_thin_inm_kernel(const ThinInmArgs a) {
+    constexpr int K = 7, NJ = 5, ROW = (THIN_TILE + K - 1 + 3 + 4) & ~3;
+    __shared__ __attribute__((aligned(16))) float xs[THIN_INM_CC * ROW];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / a.n_t_tiles, tt = blockIdx.x - b * a.n_t_tiles;
+    const int t0 = tt * THIN_TILE;
+    const float* xa = a.xa + (int64_t)b * a.x_bstride;
+    const float* xb = a.xb2 ? a.xb2 + (int64_t)b * a.x_bstride : nullptr;
+    const bool gn = a.stats_a != nullptr;
+    const float mu_a = gn ? a.stats_a[2 * b] : 0.0f, rs_a = gn ? a.stats_a[2 * b + 1] : 1.0f;
+    const float mu_b = (gn && xb) ? a.stats_b[2 * b] : 0.0f, rs_b = (gn && xb) ? a.stats_b[2 * b + 1] : 1.0f;
+    // this thread's window slots: padded positions t0 + tid + 256*u -> source sample (SConv1d.Pad1d as an index map)
+    int qs[NJ];
+    bool ok[NJ];
+#pragma unroll
+    for (int u = 0; u < NJ; ++u) {
+        const int j = t0 + tid + 256 * u;
+        int q = j - a.left;
+        q = q < 0 ? -q : q;
+        if (q >= a.Lz) q = 2 * (a.Lz - 1) - q;
+        ok[u] = j < a.Lp && q >= 0 && q < a.L;
+        qs[u] = min(max(q, 0), a.L - 1);
+    }
+    float acc[COUT][4];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[c][o] = 0.0f;
+    for (int c0 = 0; c0 < a.Cin; c0 += THIN_INM_CC) {
+        const int nc = min(THIN_INM_CC, a.Cin - c0);
+        float ra[THIN_INM_CC][NJ], rb[THIN_INM_CC][NJ];
+#pragma unroll
+        for (int c = 0; c < THIN_INM_CC; ++c) {
+            const int64_t ro = (int64_t)min(c0 + c, a.Cin - 1) * a.x_cstride;
+#pragma unroll
+            for (int u = 0; u < NJ; ++u) {
+                ra[c][u] = xa[ro + qs[u]];
+                rb[c][u] = xb ? xb[ro + qs[u]] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < THIN_INM_CC; ++c) {
+            const int ci = min(c0 + c, a.Cin - 1);
+            const float ga = gn ? a.gamma_a[ci] : 1.0f, ba = gn ? a.beta_a[ci] : 0.0f;
+            const float gb = (gn && xb) ? a.gamma_b[ci] : 1.0f, bb = (gn && xb) ? a.beta_b[ci] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < NJ; ++u) {
+                float v = ra[c][u];
+                if (gn) v = ((v - mu_a) * rs_a) * ga + ba;
+                if (xb) {
+                    float w2 = rb[c][u];
+                    if (gn) w2 = ((w2 - mu_b) * rs_b) * gb + bb;
+                    v = v + w2;
+                }
+                if (a.elu) v = nc_eluf(v);
+                ra[c][u] = ok[u] ? v : 0.0f;
+            }
+        }
+        __syncthreads();   // the previous round's arithmetic has finished reading the window
+#pragma unroll
+        for (int c = 0; c < THIN_INM_CC; ++c)
+#pragma unroll
+            for (int u = 0; u < NJ; ++u) {
+                const int j = tid + 256 * u;
+                if (j < ROW) xs[c * ROW + j] = ra[c][u];
+            }
+        __syncthreads();
+        for (int c = 0; c < nc; ++c) {
+            const float* xl = xs + c * ROW + 4 * tid;
+            float wv[COUT][K];
+#pragma unroll
+            for (int co = 0; co < COUT; ++co)
+#pragma unroll
+                for (int k = 0; k < K; ++k) wv[co][k] = a.w[((int64_t)co * a.Cin + (c0 + c)) * K + k];   // uniform: scalar loads
+            constexpr int NV = (K + 3 + 3) / 4;
+            float xw[4 * NV];
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const thin_f32x4 v = *reinterpret_cast<const thin_f32x4*>(xl + 4 * q);
+                xw[4 * q] = v[0]; xw[4 * q + 1] = v[1]; xw[4 * q + 2] = v[2]; xw[4 * q + 3] = v[3];
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co)
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) acc[co][o] = fmaf(wv[co][k], xw[k + o], acc[co][o]);
+        }
+    }
+    const int t = t0 + 4 * tid;
+    float yv[COUT][4];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        const float bv = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) yv[co][o] = acc[co][o] + bv;
+    }
+    if (a.gn_part != nullptr) {
+        // block sums: slot (h = 0, column c) adds rows 0 .. COUT-1 of column c in binary64 from +0; butterfly 1, 2 in this thread's 4
+        // columns, 4 / 8 / 16 over the 8 threads of a 32-column block (the h = 1 half of the block holds no rows: + 0)
+        double p1[4], p2[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                const double d = (t + o < a.Tout) ? (double)yv[co][o] : 0.0;
+                s1 += d;
+                s2 = __builtin_fma(d, d, s2);
+            }
+            p1[o] = s1; p2[o] = s2;
+        }
+        double s1 = (p1[0] + p1[1]) + (p1[2] + p1[3]), s2 = (p2[0] + p2[1]) + (p2[2] + p2[3]);
+        s1 += nc_gn_dpp<0xB1>(s1); s2 += nc_gn_dpp<0xB1>(s2);
+        s1 += nc_gn_dpp<0x4E>(s1); s2 += nc_gn_dpp<0x4E>(s2);
+        s1 += nc_gn_dpp<0x141>(s1); s2 += nc_gn_dpp<0x141>(s2);
+        double* const gp = a.gn_part + (int64_t)b * a.gn_ncb * 2;
+        const int cbk = t >> 5;
+        if ((tid & 7) == 0 && cbk < a.gn_ncb) nc_gn_store_partial(gp + (int64_t)cbk * 2, s1, s2);
+        if (a.gn_count != nullptr) nc_gn_arrive_and_finish(gp, a.gn_count + b, a.gn_stats + 2 * b, a.gn_ncb, (unsigned)a.n_t_tiles, a.gn_n);
+    }
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        float* yr = a.y + (int64_t)b * a.y_bstride + (int64_t)co * a.y_cstride;
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (t + o < a.Tout) yr[t + o] = yv[co][o];
+    }
+}
+
+bool launch_conv_thin_inm(const ThinInmArgs& a, int B, int Cout, hipStream_t s) {
+    if (Cout < 1 || Cout > 2 || a.Tout <= 0) return false;
+    ThinInmArgs k = a;
+    k.n_t_tiles = (int)((a.Tout + THIN_TILE - 1) / THIN_TILE);
+    const dim3 grid((unsigned)(B * k.n_t_tiles));
+    if (Cout == 1) hipLaunchKernelGGL(conv_thin_inm_kernel<1>, grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL(conv_thin_inm_kernel<2>, grid, dim3(256), 0, s, k);
+    NC_HIP(hipGetLastError());
+    return true;
 }
 
 // Thin-INPUT convolution: the encoders' stem Conv1d(1, C, k=7, pad 3) (Encoder.cs:31, Modules/SNAC/Encoder.cs:33).  On the matrix-core
