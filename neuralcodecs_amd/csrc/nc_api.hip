@@ -598,6 +598,27 @@ nc_status nc_op_conv1d_bench(int device_index, const nc_conv_desc* d, int32_t fu
         io.res = (fuse & 4) ? dr.as<float>() : nullptr;
         io.y = dy.as<float>(); io.y_bstride = (int64_t)d->Cout * Tout; io.y_cstride = Tout;
         io.epi = d->tanh_out ? EPI_TANH : 0;
+        // fuse & 8: Encodec GroupNorm block sums from the epilogue, finished in the launch; fuse & 16: Encodec input mode (pending
+        // GroupNorm + ELU applied while staging)
+        DevBuf gpart, gcnt, gstats, istats, igam;
+        if (fuse & 8) {
+            const int sub = conv_gn_sub(d->K, d->stride, d->Cout, d->transposed != 0);
+            const int nrb = (int)(((int64_t)d->Cout * sub + 31) / 32), ncb = (int)(((Tout + sub - 1) / sub + 31) / 32);
+            gpart.reserve((size_t)d->B * nrb * ncb * 16); gcnt.reserve((size_t)d->B * 4); gstats.reserve((size_t)d->B * 8);
+            NC_HIP(hipMemset(gcnt.p, 0, (size_t)d->B * 4));
+            if (!conv_gn_fusable(L, io)) fail(NC_EINVAL, "this layer cannot emit GroupNorm sums");
+            io.gn_part = gpart.as<double>(); io.gn_nrb = nrb; io.gn_ncb = ncb;
+            io.gn_count = gcnt.as<unsigned>(); io.gn_stats = gstats.as<float>(); io.gn_n = (double)d->Cout * (double)Tout;
+        }
+        if (fuse & 16) {
+            std::vector<float> st((size_t)d->B * 2), g((size_t)d->Cin * 2);
+            for (int b = 0; b < d->B; ++b) { st[(size_t)2 * b] = 0.01f * rnd(); st[(size_t)2 * b + 1] = 1.0f + 0.1f * rnd(); }
+            for (int c = 0; c < d->Cin; ++c) { g[(size_t)c] = 1.0f + 0.1f * rnd(); g[(size_t)d->Cin + c] = 0.1f * rnd(); }
+            istats.reserve(st.size() * 4); igam.reserve(g.size() * 4);
+            NC_HIP(hipMemcpy(istats.p, st.data(), st.size() * 4, hipMemcpyHostToDevice));
+            NC_HIP(hipMemcpy(igam.p, g.data(), g.size() * 4, hipMemcpyHostToDevice));
+            io.in_stats = istats.as<float>(); io.in_gamma = igam.as<float>(); io.in_beta = igam.as<float>() + d->Cin; io.in_elu = true;
+        }
         hipEvent_t e0, e1;
         NC_HIP(hipEventCreate(&e0)); NC_HIP(hipEventCreate(&e1));
         for (int i = 0; i < 2; ++i) launch_conv(L, io, d->B, nullptr, nullptr);
@@ -610,6 +631,7 @@ nc_status nc_op_conv1d_bench(int device_index, const nc_conv_desc* d, int32_t fu
         *avg_ms = (double)ms / iters;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         dx.release(); dy.release(); dai.release(); dao.release(); dr.release(); L.release_all();
+        gpart.release(); gcnt.release(); gstats.release(); istats.release(); igam.release();
     });
 }
 

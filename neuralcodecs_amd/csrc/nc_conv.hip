@@ -581,11 +581,15 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     // the staging registers, and 32-bit offsets that reach 3 clips ahead.
     bool flat = false;
     int flat_S = 0, flat_hc = 0;
+    int64_t flat_pitch = 0;   // columns per clip on the flattened axis (>= n_cols_all)
     {
         static const bool no_flat = std::getenv("NC_NO_FLAT") && std::getenv("NC_NO_FLAT")[0] == '1';
         const int sx0 = L.transposed ? 1 : L.stride, ad0 = L.transposed ? 1 : L.dil;
         const int hc = ((L.Ktaps - 1) * ad0) / sx0;
-        const int64_t Tq = n_cols_all;
+        // clip pitch on the flattened axis: the row length, or -- when the epilogue emits GroupNorm block sums -- the row length rounded up
+        // to whole 32-column blocks (= 32 * gn_ncb), so that every 32x32 accumulator tile is one canonical block of one sample
+        static const bool no_flat_gn = std::getenv("NC_NO_FLAT_GN") && std::getenv("NC_NO_FLAT_GN")[0] == '1';
+        const int64_t Tq = io.gn_part ? (int64_t)32 * io.gn_ncb : n_cols_all;
         auto segs = [&](int BN) { return (int)((BN - 2) / Tq) + 2; };
         auto fits = [&](int TN) {
             const int BN = 128 * TN, S = segs(BN);
@@ -593,15 +597,16 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
             const int xw = (BN - 1 + (S - 1) * hc) * sx0 + (L.Ktaps - 1) * ad0 + 1;
             return c.CB * ((xw + 63) / 64) <= 4 * nx_for_k(c.K);
         };
-        const bool cand = !no_flat && B > 1 && L.n_phase == 1 && !io.fuse_k1 && !(in_mode & 1) && !io.gn_part && !io.x2 && !(io.epi & EPI_NOISE) && Tq >= 32 && L.Cin * L.Ktaps >= 64 &&
+        const bool cand = !no_flat && B > 1 && L.n_phase == 1 && !io.fuse_k1 && !(in_mode & 1) && !(io.gn_part && (no_flat_gn || Tq < n_cols_all)) && !io.x2 &&
+                          !(io.epi & EPI_NOISE) && Tq >= 32 && L.Cin * L.Ktaps >= 64 &&
                           3 * io.x_bstride + io.x_len < ((int64_t)1 << 32) &&
                           (int64_t)(c.BM() + 4) * io.y_cstride + Tout + 3 * io.y_bstride < ((int64_t)1 << 31) &&
                           (Tq + hc) * sx0 < (1 << 28);
         int ftn = 0;
         if (cand) ftn = ((int64_t)B * Tq >= 192 && fits(2)) ? 2 : fits(1) ? 1 : 0;
-        if (ftn < c.TN && Tq >= 192) ftn = 0;   // (dilation-9 windows: the extra halo would halve the tile width -- keep the one-clip tiles)
+        if (ftn < c.TN && n_cols_all >= 192) ftn = 0;   // (dilation-9 windows: the extra halo would halve the tile width -- keep the one-clip tiles)
         if (ftn) {
-            const int64_t bn_nf = c.BN(), cols_nf = (int64_t)B * ((Tq + bn_nf - 1) / bn_nf) * bn_nf;
+            const int64_t bn_nf = c.BN(), cols_nf = (int64_t)B * ((n_cols_all + bn_nf - 1) / bn_nf) * bn_nf;
             const int64_t bn_f = 128 * ftn, cols_f = (((int64_t)B * Tq + bn_f - 1) / bn_f) * bn_f;
             if ((double)cols_f <= 0.97 * (double)cols_nf) {
                 flat = true;
@@ -610,6 +615,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
                 c.TN = ftn;
                 narrow = false;
                 flat_S = segs(c.BN());
+                flat_pitch = Tq;
                 flat_hc = hc;
             }
         }
@@ -624,12 +630,12 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
             static const int bpc_gen[5] = {0, 4, 3, 2, 2};
             const double slots = 256.0 * bpc_gen[c.TM];
             const int64_t n_co = (L.rows() + c.BM() - 1) / c.BM();
-            auto ntiles = [&](int64_t bn) { return flat ? ((int64_t)B * n_cols_all + bn - 1) / bn : (int64_t)B * ((n_cols_all + bn - 1) / bn); };
+            auto ntiles = [&](int64_t bn) { return flat ? ((int64_t)B * flat_pitch + bn - 1) / bn : (int64_t)B * ((n_cols_all + bn - 1) / bn); };
             const double r2 = std::ceil((double)(L.n_phase * n_co * ntiles(256)) / slots), r1 = std::ceil((double)(L.n_phase * n_co * ntiles(128)) / slots);
             const double w_bytes = 4.0 * L.rows() * (double)L.Cin * L.Ktaps;
             if (r2 <= 3 && r1 * 1.08 < 2.0 * r2 && w_bytes <= 4.0 * 1024 * 1024) {
                 c.TN = 1;
-                if (flat) flat_S = (int)((128 - 2) / n_cols_all) + 2;
+                if (flat) flat_S = (int)((128 - 2) / flat_pitch) + 2;
             }
         }
     }
@@ -726,8 +732,8 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     a.n_t_tiles = (a.n_cols + BN - 1) / BN;
     a.Bc = B; a.flat = 0; a.flat_px = a.flat_pc = 0x1fffffff; a.flat_hc = 0;
     if (flat) {   // one column axis over all clips: B = 1 in the tile map
-        a.flat = 1; a.flat_pc = a.n_cols; a.flat_hc = flat_hc; a.flat_px = (a.n_cols + flat_hc) * sx;
-        a.n_t_tiles = (int32_t)(((int64_t)B * a.n_cols + BN - 1) / BN);
+        a.flat = 1; a.flat_pc = (int32_t)flat_pitch; a.flat_hc = flat_hc; a.flat_px = (int32_t)(flat_pitch + flat_hc) * sx;
+        a.n_t_tiles = (int32_t)(((int64_t)B * flat_pitch + BN - 1) / BN);
         a.B = 1;
     }
     a.n_cb = (L.Cin + CB - 1) / CB;
@@ -780,6 +786,10 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         if (!fn) fail(NC_EUNSUPPORTED, "no light conv kernel for TM=%d TN=%d", c.TM, c.TN);
     } else {
         fn = lookup_kernel(c);
+    }
+    {   // experiment: NC_LDS_MIN=<bytes> raises the LDS request (fewer co-resident workgroups per CU)
+        static const size_t lds_min = std::getenv("NC_LDS_MIN") ? (size_t)atol(std::getenv("NC_LDS_MIN")) : 0;
+        lds = std::max(lds, std::min<size_t>(lds_min, 160 * 1024));
     }
     if (lds > 160 * 1024) fail(NC_EUNSUPPORTED, "conv tile needs %zu B of LDS", lds);
     ensure_dynamic_lds((const void*)fn, 160 * 1024);

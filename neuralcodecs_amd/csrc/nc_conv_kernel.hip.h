@@ -130,8 +130,10 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     // n + m*flat_hc, i.e. clips are laid out at a pitch of n_cols + flat_hc columns (flat_px x-slots), and the segment of a window
     // slot / tile column is found by comparing against multiples of the pitch.  Without p.flat both pitches are huge (segment 0 always)
     // and every formula below reduces to the one-clip tile: b = clip of the tile, col0 = its first column.
-    const int b = __builtin_amdgcn_readfirstlane(p.flat ? (t_tile * BN) / p.n_cols : lin % p.B);   // first clip of the tile
-    const int col0 = p.flat ? t_tile * BN - b * p.n_cols : t_tile * BN;                              // first column, within clip b
+    // (With GroupNorm sums in the epilogue the clip pitch p.flat_pc is n_cols rounded up to whole 32-column blocks, so every 32x32
+    // accumulator tile is ONE canonical block of ONE sample; the columns between n_cols and the pitch are padding.)
+    const int b = __builtin_amdgcn_readfirstlane(p.flat ? (t_tile * BN) / p.flat_pc : lin % p.B);   // first clip of the tile
+    const int col0 = p.flat ? t_tile * BN - b * p.flat_pc : t_tile * BN;                              // first column, within clip b
     const int flat_px = p.flat_px, flat_pc = p.flat_pc;
     auto seg_of = [&](int r, int pitch) __attribute__((always_inline)) -> int { return (int)(r >= pitch) + (int)(r >= 2 * pitch) + (int)(r >= 3 * pitch); };
 
@@ -725,7 +727,8 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         // GroupNorm(1,C) block sums of the output (Encodec's NormConv1d, NormConv1d.cs:155): every 32x32 accumulator tile is reduced in
         // registers in the canonical order of nc_gn.h and leaves ONE (S1, S2) pair -- the tensor is not read back for its statistics.
         if (p.gn_part != nullptr) {
-            double* const gp = p.gn_part + (int64_t)b * p.gn_nrb * p.gn_ncb * 2;
+            const int gn_n = p.gn_nrb * p.gn_ncb;
+            double* const gp = p.gn_part + (int64_t)b * gn_n * 2;
             auto gn_blocks = [&](auto full_tag) __attribute__((always_inline)) {
                 constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
@@ -744,8 +747,11 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                         double s1, s2;
                         nc_gn_slot_sums<FULL>(vv, okm16, s1, s2);
                         nc_gn_butterfly(s1, s2);
-                        const int rbk = co_tile * TM + i, cbk = (col0 + wave * BNW + j * 32) >> 5;
-                        if (lane == 0 && rbk < p.gn_nrb && cbk < p.gn_ncb) nc_gn_store_partial(gp + ((int64_t)rbk * p.gn_ncb + cbk) * 2, s1, s2);
+                        // (flattened axis: the tile's 32 columns belong to sample b + sg, wave-uniform since the pitch is a multiple of 32)
+                        const int sg = __builtin_amdgcn_readfirstlane(sgc[j]);
+                        const int rbk = co_tile * TM + i, cbk = (col0 + wave * BNW + j * 32 - sg * flat_pc) >> 5;
+                        if (lane == 0 && rbk < p.gn_nrb && cbk < p.gn_ncb && b + sg < p.Bc)
+                            nc_gn_store_partial(gp + ((int64_t)sg * gn_n + (int64_t)rbk * p.gn_ncb + cbk) * 2, s1, s2);
                         __builtin_amdgcn_sched_barrier(0);   // one block at a time: the sums of several blocks in flight spill
                     }
             };
@@ -753,8 +759,20 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
             else gn_blocks(std::false_type{});
             // the last workgroup of the sample to arrive turns the block sums into (mean, rstd): no follow-up launch.  (Reads -- the
             // arrival's returned count, the last arriver's loads -- all precede this workgroup's first output store.)
-            if (p.gn_count != nullptr)
-                nc_gn_arrive_and_finish(gp, p.gn_count + b, p.gn_stats + 2 * b, p.gn_nrb * p.gn_ncb, (unsigned)(p.n_co_tiles * p.n_t_tiles), p.gn_n);
+            if (p.gn_count != nullptr) {
+                if (p.flat) {   // arrivals counted in block sums: this tile holds inc[m] of them for sample b + m
+                    const int rb = min(TM, p.gn_nrb - co_tile * TM), f0 = t_tile * BN;
+                    unsigned inc[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int lo = max(f0, (b + m) * flat_pc), hi_c = min(f0 + BN, (b + m + 1) * flat_pc);
+                        inc[m] = (b + m < p.Bc && hi_c > lo && rb > 0) ? (unsigned)(((hi_c - lo) >> 5) * rb) : 0u;
+                    }
+                    nc_gn_arrive_blocks(gp, p.gn_count + b, p.gn_stats + 2 * b, gn_n, p.gn_n, inc[0], inc[1], inc[2], inc[3]);
+                } else {
+                    nc_gn_arrive_and_finish(gp, p.gn_count + b, p.gn_stats + 2 * b, gn_n, (unsigned)(p.n_co_tiles * p.n_t_tiles), p.gn_n);
+                }
+            }
         }
     }
     if constexpr (!FUSE) {

@@ -171,11 +171,12 @@ __global__ void scale_kernel(ActView a, const float* __restrict__ scale, int mod
 
 // One LSTM time step of one layer (SLSTM.cs:31,40-57; gate order i,f,g,o).  Block j = hidden unit, thread = clip.
 //   gi   [B,4C,T]  input projection incl. b_ih (matrix-core 1x1 conv)         hprev/hnext, cst  [C][B] (unit-major)
-//   out  [B,C,T]   h_t (+ skip[b,j,t] for the last layer: output.add(permuted), SLSTM.cs:50-53)
+//   out  [B,C,T]   h_t (+ skip[b,j,t] for the last layer: output.add(permuted), SLSTM.cs:50-53; elu_out: the ELU every consumer of an
+//                  SLSTM applies first -- SEANetEncoder.cs / SEANetDecoder.cs: [.., SLSTM, ELU, conv] -- is applied here, once)
 __global__ __launch_bounds__(64) void lstm_step_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
                                                        const float* __restrict__ bhh, const float* __restrict__ hprev,
                                                        float* __restrict__ hnext, float* __restrict__ cst, const float* __restrict__ skip,
-                                                       float* __restrict__ out, int B, int C, int64_t T, int64_t t) {
+                                                       float* __restrict__ out, int B, int C, int64_t T, int64_t t, int elu_out) {
     extern __shared__ float wrow[];   // [4][C]
     const int j = blockIdx.x;
     for (int i = threadIdx.x; i < 4 * C; i += 64) wrow[i] = whh[(int64_t)((i / C) * C + j) * C + (i % C)];
@@ -219,7 +220,8 @@ __global__ __launch_bounds__(64) void lstm_step_kernel(const float* __restrict__
     const float h = og * nc_tanhf(cn);
     hnext[(int64_t)j * B + b] = h;
     const int64_t o = ((int64_t)b * C + j) * T + t;
-    out[o] = skip ? h + skip[o] : h;
+    const float y = skip ? h + skip[o] : h;
+    out[o] = elu_out ? nc_eluf(y) : y;
 }
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -252,6 +254,7 @@ struct LstmSeqArgs {
     const float* bhh;     // [4C]
     const float* skip;    // nullable [N,C,T]: added to the last layer's output (SLSTM.cs:50-53)
     float* out;           // [N,C,T]
+    int elu_out;          // ELU applied to the stored value (the activation in front of the consuming convolution)
     float* hx;            // [2][tiles][C][16] exchange buffers
     unsigned* flags;      // [tiles][C/16] steps published per workgroup (zeroed before the launch)
     unsigned* tmo;        // timeout word (zeroed at model creation)
@@ -377,7 +380,10 @@ __global__ __launch_bounds__(1024, 1) void lstm_seq_kernel(const LstmSeqArgs a) 
                 __hip_atomic_store(hq, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if (b < N) orow_out[t * a.out_t] = a.skip ? h + csk : h;
+            if (b < N) {
+                const float yo = a.skip ? h + csk : h;
+                orow_out[t * a.out_t] = a.elu_out ? nc_eluf(yo) : yo;
+            }
         }
         if (t + 1 < T) {
             __syncthreads();   // the four publishing waves have drained their stores (and the partial tiles are free again)
@@ -1069,8 +1075,14 @@ __global__ void nct_to_ctn_kernel(const float* __restrict__ x, float* __restrict
     y[i] = x[((int64_t)n * C + c) * T + t];
 }
 
-// SLSTM.forward (SLSTM.cs:40-57) on a dense x [N,C,T]; returns lstm(x) + x
-float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
+// true when run_lstm should apply the consumer's ELU in its output store (NC_LSTM_NO_ELU=1: the consumer applies it while staging)
+static bool lstm_applies_elu(const EncodecModel::Lstm& l) {
+    static const bool off = std::getenv("NC_LSTM_NO_ELU") && std::getenv("NC_LSTM_NO_ELU")[0] == '1';
+    return !off && !l.layers.empty();
+}
+
+// SLSTM.forward (SLSTM.cs:40-57) on a dense x [N,C,T]; returns lstm(x) + x (elu_out: ELU of it)
+float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool elu_out) {
     const int C = l.C;
     if (l.layers.empty()) return const_cast<float*>(x);
     static const bool stepwise_env = std::getenv("NC_LSTM_STEPWISE") && std::getenv("NC_LSTM_STEPWISE")[0] == '1';
@@ -1154,7 +1166,7 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
             for (int tl = 0; tl < n_tiles; tl += per_launch) {
                 const int nt = std::min(per_launch, n_tiles - tl);
                 LstmSeqArgs a{};
-                a.gi = gi[li]; a.whhp = y.whhp.as<float>(); a.bhh = y.bhh.as<float>(); a.skip = last ? x : nullptr; a.out = out[li];
+                a.gi = gi[li]; a.whhp = y.whhp.as<float>(); a.bhh = y.bhh.as<float>(); a.skip = last ? x : nullptr; a.out = out[li]; a.elu_out = (last && elu_out) ? 1 : 0;
                 if (piped) { a.gi_b = 1; a.gi_c = T * N; a.gi_t = N; }
                 else { a.gi_b = (int64_t)4 * C * T; a.gi_c = T; a.gi_t = 1; }
                 if (between(li)) { a.out_b = 1; a.out_c = T * N; a.out_t = N; }
@@ -1248,7 +1260,7 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T) {
         NC_HIP(hipMemsetAsync(cs, 0, (size_t)C * N * 4, stream));
         for (int64_t t = 0; t < T; ++t)
             hipLaunchKernelGGL(lstm_step_kernel, dim3((unsigned)C, (unsigned)((N + 63) / 64)), dim3(64), (size_t)4 * C * sizeof(float), stream,
-                               gi, y.whh.as<float>(), y.bhh.as<float>(), (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, cs, last ? x : nullptr, out, N, C, T, t);
+                               gi, y.whh.as<float>(), y.bhh.as<float>(), (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, cs, last ? x : nullptr, out, N, C, T, t, (last && elu_out) ? 1 : 0);
         NC_HIP(hipGetLastError());
         if (prof.on) prof.end(stream);
         in = out;
@@ -1276,8 +1288,11 @@ void EncodecModel::encode_batch(const float* x, int N, int64_t L, int64_t Tz, in
     }
     const float* xl = materialize(cur, N, nullptr, 0);
     Act a;
-    a.p = run_lstm(enc_lstm, xl, N, cur.L); a.C = cur.C; a.L = cur.L; a.rs = cur.L; a.off = 0; a.stats = nullptr; a.gamma = a.beta = nullptr;
-    Act e = sconv(enc_out, a, nullptr, true, N);
+    // (the ELU in front of the last convolution is applied by the LSTM's output store: once per element instead of once per row tile
+    //  of the consumer's staging, and the consumer runs as a plain convolution)
+    const bool lstm_elu = lstm_applies_elu(enc_lstm);
+    a.p = run_lstm(enc_lstm, xl, N, cur.L, lstm_elu); a.C = cur.C; a.L = cur.L; a.rs = cur.L; a.off = 0; a.stats = nullptr; a.gamma = a.beta = nullptr;
+    Act e = sconv(enc_out, a, nullptr, !lstm_elu, N);
     if (e.L != Tz) fail(NC_ESTATE, "internal: encoder produced %lld frames, expected %lld", (long long)e.L, (long long)Tz);
     float* residual = materialize(e, N, nullptr, 0);
     const int D = cfg.dimension;
@@ -1317,11 +1332,12 @@ float* EncodecModel::decode_batch(const int64_t* codes, int N, int nq, int64_t T
     cur = sconv(dec_in, cur, nullptr, false, N);
     const float* xl = materialize(cur, N, nullptr, 0);
     Act a;
-    a.p = run_lstm(dec_lstm, xl, N, cur.L); a.C = cur.C; a.L = cur.L; a.rs = cur.L; a.off = 0; a.stats = nullptr; a.gamma = a.beta = nullptr;
+    const bool lstm_elu = lstm_applies_elu(dec_lstm);
+    a.p = run_lstm(dec_lstm, xl, N, cur.L, lstm_elu); a.C = cur.C; a.L = cur.L; a.rs = cur.L; a.off = 0; a.stats = nullptr; a.gamma = a.beta = nullptr;
     Act s = a, y;
     bool dual = false;
     for (int i = 0; i < cfg.n_ratios; ++i) {
-        Act u = sconvT(dec_up[i], s, dual ? &y : nullptr, true, N);
+        Act u = sconvT(dec_up[i], s, dual ? &y : nullptr, !(i == 0 && lstm_elu), N);
         resblock(dec_res[i], u, N, s, y);
         dual = true;
     }

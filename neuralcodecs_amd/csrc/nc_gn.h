@@ -79,6 +79,8 @@ __device__ __forceinline__ void nc_gn_store_partial(double* q, double s1, double
     __hip_atomic_store(q, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(q + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The last arriver's part: the sample's n block sums -> (mean, rstd), counter back to zero.  Called by one whole wavefront.
+__device__ __forceinline__ void nc_gn_finish_sample(const double* part, unsigned* counter, float* stats, int n, double count);
 // Called by EVERY thread of the workgroup (it holds barriers), after the writer lanes have issued nc_gn_store_partial.
 // part: the sample's block sums [n][2]; n_wg: workgroups of this launch that belong to the sample; count = C*T elements.
 __device__ __forceinline__ void nc_gn_arrive_and_finish(const double* part, unsigned* counter, float* stats, int n, unsigned n_wg, double count) {
@@ -89,7 +91,28 @@ __device__ __forceinline__ void nc_gn_arrive_and_finish(const double* part, unsi
     if (threadIdx.x == 0) prev = __hip_atomic_fetch_add((nc_gn_gu32*)counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     prev = __builtin_amdgcn_readfirstlane(prev);
     if (prev + 1 != n_wg) return;
+    nc_gn_finish_sample(part, counter, stats, n, count);
+}
+// Flattened column axis: a workgroup's tile covers up to 4 consecutive samples and has written inc[m] block sums of sample m (of the
+// samples part0 / counter0 / stats0 point at); arrivals are counted in BLOCK SUMS, a sample is complete at n of them.
+__device__ __forceinline__ void nc_gn_arrive_blocks(const double* part0, unsigned* counter0, float* stats0, int n, double count, unsigned inc0, unsigned inc1,
+                                                    unsigned inc2, unsigned inc3) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
     const int lane = threadIdx.x;
+    const unsigned inc = lane == 0 ? inc0 : lane == 1 ? inc1 : lane == 2 ? inc2 : lane == 3 ? inc3 : 0u;
+    unsigned prev = 0;
+    if (inc) prev = __hip_atomic_fetch_add((nc_gn_gu32*)(counter0 + lane), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long done = __builtin_amdgcn_ballot_w64(inc != 0 && prev + inc == (unsigned)n);
+    while (done) {   // (wave-uniform)
+        const int m = __builtin_ctzll(done);
+        done &= done - 1;
+        nc_gn_finish_sample(part0 + (size_t)m * n * 2, counter0 + m, stats0 + 2 * m, n, count);
+    }
+}
+__device__ __forceinline__ void nc_gn_finish_sample(const double* part, unsigned* counter, float* stats, int n, double count) {
+    const int lane = threadIdx.x & 63;
     double s1 = 0.0, s2 = 0.0;
     for (int k0 = 0; k0 < n; k0 += 64 * 4) {
         double a[4], c[4];

@@ -276,7 +276,7 @@ struct EncodecModel : Codec {
     Act sconvT(SConv& L, const Act& a, const Act* b2, bool elu, int N);
     void resblock(ResBlock& r, const Act& x, int N, Act& s, Act& y);
     float* materialize(const Act& a, int N, const float* scale, int mode);
-    float* run_lstm(Lstm& l, const float* x, int N, int64_t T);
+    float* run_lstm(Lstm& l, const float* x, int N, int64_t T, bool elu_out);
     void encode_batch(const float* x, int N, int64_t L, int64_t Tz, int64_t* codes, float* scale_out, float* emb_out);
     float* decode_batch(const int64_t* codes, int N, int nq, int64_t Tz, const float* scale, int64_t* Lout);
 };
