@@ -56,6 +56,8 @@ static conv_kernel_fn conv_kernel_table_dist_k7(int, int) { return nullptr; }
 static int experiment_mode(const char*) { return 0; }
 #endif
 conv_kernel_fn conv_kernel_table_sub_k2(int, int);
+conv_kernel_fn conv_kernel_table_dist_k16(int, int);
+conv_kernel_fn conv_kernel_table_dist_sub_k2(int, int);
 conv_kernel_fn conv_kernel_table_sub_narrow_k2(int);
 conv_kernel_fn conv_kernel_table_fusedw_k7(int, int);
 conv_kernel_fn conv_kernel_table_slim_k3(int, int);
@@ -690,6 +692,21 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         static const int dist_mode = experiment_mode("NC_DIST");
         if (dist_mode == 1 && !n_prod && !light && !narrow && !flat && !wide && !io.fuse_k1 && c.K == 7 && c.TN == 2 && c.TM >= 2) dist = true;
     }
+    // Distributed staging for the grids that leave a workgroup alone on its CU (the deep strided / sub-pixel layers of Encodec at
+    // 150 frames: 20 GFLOP per launch): nobody feeds the matrix pipe during the staging runs of the segmented pipeline -- measured
+    // 58 % pipe duty for a lone workgroup against 71 % for a co-resident pair -- so the runs are dealt into the matrix-core shadows.
+    conv_kernel_fn dist_small_fn = nullptr;
+    {
+        static const bool off = std::getenv("NC_NO_DIST_SMALL") && std::getenv("NC_NO_DIST_SMALL")[0] == '1';
+        static const int64_t max_grid = std::getenv("NC_DIST_MAX_GRID") ? atol(std::getenv("NC_DIST_MAX_GRID")) : 768;
+        const int64_t n_co = (L.rows() + c.BM() - 1) / c.BM();
+        const int64_t n_tt = flat ? ((int64_t)B * flat_pitch + c.BN() - 1) / c.BN() : (int64_t)B * ((n_cols_all + c.BN() - 1) / c.BN());
+        if (!off && !dist && !n_prod && !light && !narrow && !wide && !slim && !in_mode && !io.x2 && !io.fuse_k1 && io.epi == 0 && L.n_phase == 1 &&
+            n_co * n_tt <= max_grid) {
+            if (L.sub_shift && c.K == 2) dist_small_fn = conv_kernel_table_dist_sub_k2(c.TM, c.TN);
+            else if (!L.sub_shift && !L.transposed && c.K == 16) dist_small_fn = conv_kernel_table_dist_k16(c.TM, c.TN);
+        }
+    }
     const int NW = n_prod ? n_prod : c.NW;   // waves that stage the input window
     const int BM = c.BM(), BN = c.BN(), CB = c.CB, KB = c.KB();
     ConvArgs a{};
@@ -762,6 +779,8 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         a.alpha_out2 = io.alpha_out2;
         fn = fused_wide ? conv_kernel_table_fusedw_k7(c.TM, c.TN) : conv_kernel_table_fused_k7(c.TM, c.TN);
         if (!fn) fail(NC_EUNSUPPORTED, "no fused residual-unit kernel for TM=%d TN=%d", c.TM, c.TN);
+    } else if (dist_small_fn) {
+        fn = dist_small_fn;
     } else if (dist) {
         fn = conv_kernel_table_dist_k7(c.TM, c.TN);
         if (!fn) fail(NC_EUNSUPPORTED, "no distributed-staging conv kernel for TM=%d TN=%d", c.TM, c.TN);

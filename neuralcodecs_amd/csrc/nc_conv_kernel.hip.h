@@ -723,7 +723,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         });
     };
 
-    if constexpr (!FUSE && !SPEC && !DIST) {
+    if constexpr (!FUSE && !SPEC) {
         // GroupNorm(1,C) block sums of the output (Encodec's NormConv1d, NormConv1d.cs:155): every 32x32 accumulator tile is reduced in
         // registers in the canonical order of nc_gn.h and leaves ONE (S1, S2) pair -- the tensor is not read back for its statistics.
         if (p.gn_part != nullptr) {
@@ -1139,6 +1139,22 @@ inline conv_kernel_fn get_conv_kernel() {
             case 22: return get_conv_kernel<2, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, true>();             \
             case 32: return get_conv_kernel<3, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, true>();             \
             case 42: return get_conv_kernel<4, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, true>();             \
+        }                                                                                                  \
+        return nullptr;                                                                                    \
+    }                                                                                                      \
+    }
+
+// Distributed staging for the one-workgroup-per-CU grids of the deep strided / sub-pixel layers (Encodec at 150 frames): with no
+// co-resident partner to feed the matrix pipe during a workgroup's staging runs, the runs are dealt into the matrix-core shadows.
+#define NC_INSTANTIATE_CONV_DIST_SMALL(NAME, KVAL, CBVAL, NXVAL, SUBV)                                     \
+    namespace nc {                                                                                         \
+    conv_kernel_fn conv_kernel_table_##NAME(int TM, int TN) {                                              \
+        switch (TM * 10 + TN) {                                                                            \
+            case 11: return get_conv_kernel<1, 1, KVAL, CBVAL, NXVAL, false, 2, 4, 0, true, SUBV>();       \
+            case 12: return get_conv_kernel<1, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, true, SUBV>();       \
+            case 21: return get_conv_kernel<2, 1, KVAL, CBVAL, NXVAL, false, 2, 4, 0, true, SUBV>();       \
+            case 22: return get_conv_kernel<2, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, true, SUBV>();       \
+            case 41: return get_conv_kernel<4, 1, KVAL, CBVAL, NXVAL, false, 2, 4, 0, true, SUBV>();       \
         }                                                                                                  \
         return nullptr;                                                                                    \
     }                                                                                                      \
