@@ -62,6 +62,7 @@ struct ConvArgs {
     const float* in_gamma;         // [Cin]
     const float* in_beta;          // [Cin]
     int32_t sub_shift;             // SUB kernels: log2(stride) of the sub-pixel transposed convolution (rows = co*stride + phase; Cout = rows)
+    int32_t sub_stride, sub_magic, sub_cout;   // SUB == 2 kernels (any stride): row x is channel (x * sub_magic) >> 20 = x / sub_stride of sub_cout, phase x % sub_stride
     // flattened (clip, column) axis (see the kernel's tile map).  flat = 0: one clip per tile (B clips in the tile map, both pitches
     // 0x1fffffff).  flat = 1: B = 1 in the tile map, n_t_tiles covers Bc*n_cols columns, flat_pc = n_cols, flat_hc = halo columns per
     // segment, flat_px = (n_cols + flat_hc) * stride window slots per clip.  Bc = number of clips (both modes).
@@ -107,8 +108,9 @@ struct ConvLayer {
     bool transposed = false;
     TileCfg cfg{};
     int n_phase = 1, Ktaps = 0;  // taps per phase (== K for conv, ceil(K/stride) for conv-transpose)
-    int sub_shift = 0;           // > 0: transposed conv packed in sub-pixel form (rows = (channel, phase) pairs, one launch, n_phase == 1)
-    int rows() const { return Cout << sub_shift; }   // GEMM rows of the packed image
+    int sub_stride = 0;          // > 0: transposed conv packed in sub-pixel form (rows = (channel, phase) pairs, one launch, n_phase == 1)
+    int sub_shift = 0;           // log2(sub_stride) when that is a power of two (the shift / mask kernels), else 0 (the multiply-shift kernels)
+    int rows() const { return sub_stride ? Cout * sub_stride : Cout; }   // GEMM rows of the packed image
     DevBuf w, bias;
     // additional row-tile heights (32*TM dividing Cout) packed at load; the launch picks the one that fills the chip best
     struct Alt {

@@ -56,6 +56,7 @@ static conv_kernel_fn conv_kernel_table_dist_k7(int, int) { return nullptr; }
 static int experiment_mode(const char*) { return 0; }
 #endif
 conv_kernel_fn conv_kernel_table_sub_k2(int, int);
+conv_kernel_fn conv_kernel_table_subg_k2(int, int);
 conv_kernel_fn conv_kernel_table_dist_k16(int, int);
 conv_kernel_fn conv_kernel_table_dist_sub_k2(int, int);
 conv_kernel_fn conv_kernel_table_sub_narrow_k2(int);
@@ -175,6 +176,7 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
                       int out_pad_, bool transposed_) {
     Cin = Cin_; Cout = Cout_; K = K_; stride = stride_; pad = pad_; dil = dil_; out_pad = out_pad_; transposed = transposed_;
     sub_shift = 0;
+    sub_stride = 0;
     if (transposed) {
         if (dil != 1) fail(NC_EUNSUPPORTED, "dilated conv_transpose1d is not on the hot path");
         n_phase = stride;
@@ -184,6 +186,16 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
         static const bool no_sub = std::getenv("NC_NO_SUBPIXEL") && std::getenv("NC_NO_SUBPIXEL")[0] == '1';
         if (!no_sub && (stride == 2 || stride == 4 || stride == 8) && K == 2 * stride && (Cout * stride) % 32 == 0 && out_pad == 0) {
             sub_shift = stride == 2 ? 1 : stride == 4 ? 2 : 3;
+            sub_stride = stride;
+            n_phase = 1;
+        }
+        // ... and the same form for the other strides (SNAC's stride-3 and Encodec's stride-5 up-convolutions, k = 2s): one launch with
+        // full row tiles instead of s launches that each write every s-th sample (NC_NO_SUBPIXEL_ANY=1: per-phase launches)
+        static const bool no_sub_any = std::getenv("NC_NO_SUBPIXEL_ANY") && std::getenv("NC_NO_SUBPIXEL_ANY")[0] == '1';
+        // (output_padding -- stride % 2 in SNAC's DecoderBlock -- only moves the right crop: the extra samples lie inside the (Tin + 1) * s
+        // samples the rows cover as long as out_pad <= pad, and the store bounds come from out_len())
+        if (!no_sub && !no_sub_any && !sub_stride && stride >= 3 && stride <= 16 && K == 2 * stride && (Cout * stride) % 32 == 0 && out_pad <= pad) {
+            sub_stride = stride;
             n_phase = 1;
         }
     } else {
@@ -208,7 +220,7 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
                         for (int r = 0; r < BM; ++r) {
                             int co = ct * BM + r, php = ph;
                             if (co >= rows()) continue;
-                            if (sub_shift) { php = co & (stride - 1); co >>= sub_shift; }   // row = co*stride + phase
+                            if (sub_stride) { php = co % stride; co /= stride; }   // row = co*stride + phase
                             float v;
                             if (transposed) {
                                 const int kt = php + k * stride;  // tap of this phase, ascending (canonical order)
@@ -477,6 +489,7 @@ bool conv_in2_available(const ConvLayer& L) {
     // 64 -> 128 k8 419 -> 432 us, 128 -> 256 k10 493 -> 1224 us, 256 -> 512 k16 +370 us against the summed copy + one-input launch,
     // while the single-tile layers gain (32 -> 64 k4: 314 -> 275 us, 64 -> 32 up-conv: 368 -> 311 us).
     if (L.rows() > 64 || L.cfg.TM == 3) return false;
+    if (L.sub_stride && !L.sub_shift) return false;   // (the multiply-shift sub-pixel form has no two-input instance)
     return in2_kernel(L.Ktaps, L.sub_shift != 0, L.cfg.TM, 1) != nullptr;
 }
 
@@ -485,7 +498,7 @@ bool conv_gn_fusable(const ConvLayer& L, const ConvIO& io) {
     // plain epilogues only; one launch covering the whole output (no per-phase transposed launches); the streaming thin-output /
     // stem / skinny kernels keep the stand-alone statistics pass (launch_conv skips them when gn_part is set, so the answer here only
     // has to say which layers are WORTH routing through the matrix-core template: all but those three)
-    if (off || io.res || io.alpha_out || io.alpha_in || io.epi || io.fuse_k1 || L.n_phase != 1) return false;
+    if (off || io.res || io.alpha_out || io.alpha_in || io.epi || io.fuse_k1 || L.n_phase != 1 || (L.sub_stride && !L.sub_shift)) return false;
     if (L.w_thin.p) return thin_inm_layer(L) && io.in_L > 0;   // (the input-mode head kernel emits its sums; the plain head does not)
     if (L.w_stem.p || L.w_skinny.p) return false;
     return true;
@@ -571,7 +584,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         const int sx0 = L.transposed ? 1 : L.stride, ad0 = L.transposed ? 1 : L.dil;
         const int xw96 = 95 * sx0 + (L.Ktaps - 1) * ad0 + 1;
         const bool fits = c.CB * ((xw96 + 63) / 64) <= 3 * nx_for_k(c.K);
-        if (!no_narrow && fits && !io.fuse_k1 && !io.x2 && c.TN == 1 && n_cols_all <= 96 && rem > 64 && narrow_kernel(c.K, c.TM)) {
+        if (!no_narrow && fits && !io.fuse_k1 && !io.x2 && !(L.sub_stride && !L.sub_shift) && c.TN == 1 && n_cols_all <= 96 && rem > 64 && narrow_kernel(c.K, c.TM)) {
             narrow = true;
             c.NW = 3;
         }
@@ -662,7 +675,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         // 215 -> 145 us (32->16 k3, 48000 steps x 32 clips), 152 -> 118 us (64->32), 80 -> 51 us (2->32 k7).  Measured neutral or
         // slower for the strided k=4 / k=8 layers and the sub-pixel up-convolutions, which keep the standard blocks.
         static const bool no_slim = std::getenv("NC_NO_SLIM") && std::getenv("NC_NO_SLIM")[0] == '1';
-        if (!no_slim && !flat && !light && !narrow && !io.fuse_k1 && !io.x2 && !L.sub_shift && !L.transposed && c.TM <= 2 && n_cols_all >= 1024) {
+        if (!no_slim && !flat && !light && !narrow && !io.fuse_k1 && !io.x2 && !L.sub_stride && !L.transposed && c.TM <= 2 && n_cols_all >= 1024) {
             int cb2 = 0, nx2 = 0;
             if (c.K == 3 && c.CB == 16) { slim_fn = conv_kernel_table_slim_k3(c.TM, c.TN); cb2 = 8; nx2 = 10; }
             else if (c.K == 7 && c.CB == 8 && L.Cin <= 4 && L.stride == 1 && L.dil == 1) { slim_fn = conv_kernel_table_slim_k7(c.TM, c.TN); cb2 = 4; nx2 = 5; }
@@ -704,7 +717,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         if (!off && !dist && !n_prod && !light && !narrow && !wide && !slim && !in_mode && !io.x2 && !io.fuse_k1 && io.epi == 0 && L.n_phase == 1 &&
             n_co * n_tt <= max_grid) {
             if (L.sub_shift && c.K == 2) dist_small_fn = conv_kernel_table_dist_sub_k2(c.TM, c.TN);
-            else if (!L.sub_shift && !L.transposed && c.K == 16) dist_small_fn = conv_kernel_table_dist_k16(c.TM, c.TN);
+            else if (!L.sub_stride && !L.transposed && c.K == 16) dist_small_fn = conv_kernel_table_dist_k16(c.TM, c.TN);
         }
     }
     const int NW = n_prod ? n_prod : c.NW;   // waves that stage the input window
@@ -724,6 +737,12 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     a.noise = io.noise; a.noise_bstride = L.out_len(io.Tin);
     if ((io.epi & EPI_NOISE) && (!io.noise || !io.res)) fail(NC_ESTATE, "internal: noise epilogue needs noise and residual");
     a.Cout = L.rows(); a.sub_shift = L.sub_shift; a.B = B; a.epi = io.epi;
+    if (L.sub_stride && !L.sub_shift) {
+        if (io.epi & EPI_NOISE) fail(NC_ESTATE, "internal: noise epilogue on the multiply-shift sub-pixel form");
+        a.sub_stride = L.sub_stride; a.sub_cout = L.Cout; a.sub_magic = magic_div(L.sub_stride, L.rows() + 256);
+        if ((int64_t)(L.Cout + 4) * io.y_cstride + Tout + 3 * io.y_bstride >= (int64_t)1 << 31)
+            fail(NC_EUNSUPPORTED, "conv output of %lld samples per row exceeds the 32-bit offsets of the sub-pixel form", (long long)io.y_cstride);
+    }
     a.Tout = (int32_t)Tout;
     if ((int64_t)(c.BM() + 4) * io.y_cstride + Tout >= (int64_t)1 << 31)
         fail(NC_EUNSUPPORTED, "conv output rows of %lld samples exceed the 32-bit tile offsets", (long long)io.y_cstride);
@@ -790,6 +809,9 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     } else if (io.x2) {
         fn = in2_kernel(c.K, L.sub_shift != 0, c.TM, c.TN);
         if (!fn) fail(NC_EUNSUPPORTED, "no two-input conv kernel for K=%d TM=%d TN=%d", c.K, c.TM, c.TN);
+    } else if (L.sub_stride && !L.sub_shift) {
+        fn = c.K != 2 ? nullptr : conv_kernel_table_subg_k2(c.TM, c.TN);
+        if (!fn) fail(NC_EUNSUPPORTED, "no sub-pixel conv kernel for K=%d TM=%d TN=%d (stride %d)", c.K, c.TM, c.TN, L.sub_stride);
     } else if (L.sub_shift) {
         fn = c.K != 2 ? nullptr : narrow ? conv_kernel_table_sub_narrow_k2(c.TM) : conv_kernel_table_sub_k2(c.TM, c.TN);
         if (!fn) fail(NC_EUNSUPPORTED, "no sub-pixel conv kernel for K=%d TM=%d TN=%d", c.K, c.TM, c.TN);

@@ -60,10 +60,13 @@ typedef __attribute__((address_space(3))) void* nc_lptr;
 // R = co*s + r, whose element (R, q) is output sample t = q*s + r - pad of channel co.  The 4 consecutive D rows a lane holds are
 // then consecutive samples of one channel, and the 32 columns x 2 lane halves of a store instruction cover a contiguous run of the
 // output row -- where the per-phase launches wrote every s-th sample from different workgroups (3x write amplification in HBM).
+// SUB == 2: the same for ANY stride with two taps per phase (k = 2s; SNAC's stride-3 and Encodec's stride-5 up-convolutions): channel and
+// phase of a packed row come from a multiply-shift division (ConvArgs::sub_stride / sub_magic) instead of a shift and a mask, and a
+// lane half's 4 extra rows no longer fold into one lane offset -- each row's offset is picked per lane half from two scalar values.
 // IN2: two-input form of the Encodec input mode (the sum of a residual block's shortcut and branch, each a raw conv output with its own
 // pending GroupNorm: SEANetResnetBlock.cs:72-85 feeding the next SConv1d / SConvTranspose1d): both operands are read with the same
 // window addresses, normalised separately, added, then ELU + pad -- the summed / activated / padded copy is never written.
-template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0, bool DIST = false, bool SUB = false,
+template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0, bool DIST = false, int SUB = 0,
           bool IN2 = false>
 __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const ConvArgs p) {
     constexpr bool SPEC = NP > 0;
@@ -328,7 +331,8 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 for (int i = tid; i < n_al; i += NT) Al2[i] = make_float2(p.in_gamma2[min(i, Cin - 1)], p.in_beta2[min(i, Cin - 1)]);
         }
         for (int i = tid; i < BM; i += NT) {
-            const int co = SUB ? min((co_tile * BM + i) >> p.sub_shift, (p.Cout >> p.sub_shift) - 1) : min(co_tile * BM + i, p.Cout - 1);
+            const int co = SUB == 2 ? min(((co_tile * BM + i) * p.sub_magic) >> 20, p.sub_cout - 1)
+                           : SUB ? min((co_tile * BM + i) >> p.sub_shift, (p.Cout >> p.sub_shift) - 1) : min(co_tile * BM + i, p.Cout - 1);
             const float ao = p.alpha_out ? p.alpha_out[co] : 0.0f;
             Ep[i] = p.bias ? p.bias[co] : 0.0f;
             Ep[BM + i] = ao;
@@ -534,13 +538,22 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*hi][col = l31]
     // Element (row block ib, register r, column j) of this lane lives at tile_base + lane_off[j] + R(ib,r)*cstride with
     // R = 32*ib + (r&3) + 8*(r>>2) a compile-time row: one uniform 64-bit base, 32-bit lane offsets (the host bounds them).
-    const int sh = SUB ? p.sub_shift : 0, smask = (1 << sh) - 1;
-    const int64_t tile_base = (int64_t)b * p.y_bstride + (int64_t)((co_tile * BM) >> sh) * p.y_cstride;
+    constexpr bool SUBG = SUB == 2;
+    const int sh = SUB == 1 ? p.sub_shift : 0, smask = SUBG ? p.sub_stride - 1 : (1 << sh) - 1;   // smask: last phase of a packed channel
+    const int64_t tile_base = (int64_t)b * p.y_bstride + (SUBG ? (int64_t)0 : (int64_t)((co_tile * BM) >> sh) * p.y_cstride);
+    // SUBG: (channel, phase) of packed row x -- scalar arithmetic on compile-time tile rows
+    const int sub_s = SUBG ? p.sub_stride : 1, sub_m = SUBG ? p.sub_magic : 0, row0 = co_tile * BM;
+    auto sub_ch = [&](int x) __attribute__((always_inline)) -> int { return (x * sub_m) >> 20; };
+    auto sub_ph = [&](int x) __attribute__((always_inline)) -> int { return x - sub_ch(x) * sub_s; };
     const unsigned cstride = (unsigned)p.y_cstride;
     const int rows_left = p.Cout - co_tile * BM - 4 * hi;   // row R of this lane half is inside the tensor iff R < rows_left
     // offset of tile row R (lane half 0) from the tile base; the lane half's 4 extra rows are folded into lane_off
     auto roff = [&](int R) __attribute__((always_inline)) -> unsigned {
-        if constexpr (SUB) return (unsigned)(R >> sh) * cstride + (unsigned)(R & smask);
+        if constexpr (SUBG) {   // row R of lane half 0, row R + 4 of lane half 1
+            const unsigned o0 = (unsigned)sub_ch(row0 + R) * cstride + (unsigned)sub_ph(row0 + R);
+            const unsigned o1 = (unsigned)sub_ch(row0 + R + 4) * cstride + (unsigned)sub_ph(row0 + R + 4);
+            return hi ? o1 : o0;
+        } else if constexpr (SUB != 0) return (unsigned)(R >> sh) * cstride + (unsigned)(R & smask);
         else return (unsigned)R * cstride;
     };
     unsigned lane_off[TN];
@@ -553,10 +566,11 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         const int t = col * p.y_tstride + p.y_toff + phase;
         const bool clip_ok = (col < p.n_cols) & (b + sgc[j] < p.Bc);
         const unsigned clip_off = (unsigned)min(sgc[j], p.Bc - 1 - b) * (unsigned)p.y_bstride;   // (clamped: masked reads stay inside the tensor)
-        if constexpr (SUB) {   // t = sample of sub-row r = 0; row R adds (R + 4*hi) & smask.  Time bounds are checked per row.
+        if constexpr (SUB != 0) {   // t = sample of sub-row r = 0; row R adds (R + 4*hi) & smask.  Time bounds are checked per row.
             okc[j] = clip_ok;
             tcol[j] = t;
-            lane_off[j] = clip_off + (unsigned)((4 * hi) >> sh) * cstride + (unsigned)((4 * hi) & smask) + (unsigned)t;
+            if constexpr (SUBG) lane_off[j] = clip_off + (unsigned)t;
+            else lane_off[j] = clip_off + (unsigned)((4 * hi) >> sh) * cstride + (unsigned)((4 * hi) & smask) + (unsigned)t;
             cols_ok = cols_ok & okc[j] & (t >= 0) & (t + smask < p.Tout);
         } else {
             okc[j] = clip_ok & (t >= 0) & (t < p.Tout);
@@ -567,8 +581,10 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     }
     // element (row R of lane half hi, column j) is inside the tensor
     auto okrow = [&](int j, int R) __attribute__((always_inline)) -> bool {
-        if constexpr (SUB) {
-            const int tq = tcol[j] + ((R + 4 * hi) & smask);
+        if constexpr (SUB != 0) {
+            int tq;
+            if constexpr (SUBG) tq = tcol[j] + (hi ? sub_ph(row0 + R + 4) : sub_ph(row0 + R));
+            else tq = tcol[j] + ((R + 4 * hi) & smask);
             return okc[j] & (R < rows_left) & (tq >= 0) & (tq < p.Tout);
         } else {
             return okc[j] & (R < rows_left);
@@ -587,7 +603,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
             for (int j = 0; j < TN; ++j) {
                 if constexpr (FULL) {
                     rv[r][j] = rt[lane_off[j] + roff(R)];
-                } else if constexpr (SUB) {
+                } else if constexpr (SUB != 0) {
                     rv[r][j] = okrow(j, R) ? rt[lane_off[j] + roff(R)] : 0.0f;
                 } else {   // branch-free: the address is clamped into the tile's valid rows / columns, the value masked
                     const float val = rt[lane_off[j] + (unsigned)max(min(R, rows_left - 1), -4 * hi) * cstride];
@@ -708,7 +724,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                     if (!okrow(j, R)) continue;
                     const unsigned o = lane_off[j] + roff(R);
                     float val = v[j][4 * rq + rr] + bias;
-                    if (noise) val = rv[rr][j] + p.noise[(int64_t)b * p.noise_bstride + tcol[j] + (SUB ? ((R + 4 * hi) & smask) : 0)] * val;
+                    if (noise) val = rv[rr][j] + p.noise[(int64_t)b * p.noise_bstride + tcol[j] + (SUB == 1 ? ((R + 4 * hi) & smask) : 0)] * val;   // (the host keeps noise rows off the SUB == 2 form)
                     else if (rt) val = val + rv[rr][j];
                     if (snake) val = nc_snakef(val, ao, ao_inv);
                     if (p.epi & EPI_TANH) val = nc_tanhf(val);
@@ -957,7 +973,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
 
 typedef void (*conv_kernel_fn)(const ConvArgs);
 
-template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0, bool DIST = false, bool SUB = false,
+template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0, bool DIST = false, int SUB = 0,
           bool IN2 = false>
 inline conv_kernel_fn get_conv_kernel() {
     return &conv_mfma_kernel<TM, TN, K, CB, NX, FUSE, OCC, NW, NP, DIST, SUB, IN2>;
@@ -1155,6 +1171,24 @@ inline conv_kernel_fn get_conv_kernel() {
             case 21: return get_conv_kernel<2, 1, KVAL, CBVAL, NXVAL, false, 2, 4, 0, true, SUBV>();       \
             case 22: return get_conv_kernel<2, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, true, SUBV>();       \
             case 41: return get_conv_kernel<4, 1, KVAL, CBVAL, NXVAL, false, 2, 4, 0, true, SUBV>();       \
+        }                                                                                                  \
+        return nullptr;                                                                                    \
+    }                                                                                                      \
+    }
+
+// Sub-pixel transposed convolution for ANY stride with two taps per phase (SUB == 2: multiply-shift row -> (channel, phase) map).
+#define NC_INSTANTIATE_CONV_SUBG(KVAL, CBVAL, NXVAL)                                                       \
+    namespace nc {                                                                                         \
+    conv_kernel_fn conv_kernel_table_subg_k##KVAL(int TM, int TN) {                                        \
+        switch (TM * 10 + TN) {                                                                            \
+            case 11: return get_conv_kernel<1, 1, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, 2>();         \
+            case 12: return get_conv_kernel<1, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, 2>();         \
+            case 21: return get_conv_kernel<2, 1, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, 2>();         \
+            case 22: return get_conv_kernel<2, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, 2>();         \
+            case 31: return get_conv_kernel<3, 1, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, 2>();         \
+            case 32: return get_conv_kernel<3, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, 2>();         \
+            case 41: return get_conv_kernel<4, 1, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, 2>();         \
+            case 42: return get_conv_kernel<4, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, 2>();         \
         }                                                                                                  \
         return nullptr;                                                                                    \
     }                                                                                                      \

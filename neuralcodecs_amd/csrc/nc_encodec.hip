@@ -269,21 +269,23 @@ struct LstmSeqArgs {
     int tile0;            // first column tile of this launch
 };
 typedef __attribute__((address_space(1))) unsigned lstm_gu32;
-template <int KS>
-__global__ __launch_bounds__(1024, 1) void lstm_seq_kernel(const LstmSeqArgs a) {
+// UB = unit blocks (of 4 hidden units) per workgroup: 4 (16 wavefronts, C/16 workgroups per column tile) or 2 (8 wavefronts, C/8
+// workgroups per tile: two chains per SIMD instead of four -- the matrix-core part of a step halves, twice the CUs take part)
+template <int KS, int UB = 4>
+__global__ __launch_bounds__(256 * UB, 1) void lstm_seq_kernel(const LstmSeqArgs a) {
     constexpr int QS = KS / 4;                                          // k-steps per quarter
-    extern __shared__ __attribute__((aligned(16))) float lstm_lds[];   // [16 waves][QS][64] weights | [3][4][64] f32x4 partial tiles
+    extern __shared__ __attribute__((aligned(16))) float lstm_lds[];   // [4 UB waves][QS][64] weights | [3][UB][64] f32x4 partial tiles
     __shared__ int dead;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ubl = wave & 3, q = wave >> 2;        // unit block within the workgroup, reduction quarter
+    const int ubl = wave % UB, q = wave / UB;       // unit block within the workgroup, reduction quarter
     const int C = a.C, N = a.N;
     const int64_t T = a.T;
-    const int nprod = C / 16;                       // workgroups per column tile
+    const int nprod = C / (4 * UB);                 // workgroups per column tile
     const int ubw = blockIdx.x, tile = blockIdx.y;  // tile: local index within this launch
-    const int ub = ubw * 4 + ubl;                   // unit block of this wave: hidden units 4*ub .. 4*ub+3
+    const int ub = ubw * UB + ubl;                   // unit block of this wave: hidden units 4*ub .. 4*ub+3
     float* Aw = lstm_lds + wave * QS * 64;
-    f32x4v* const part = reinterpret_cast<f32x4v*>(lstm_lds + 16 * QS * 64);
+    f32x4v* const part = reinterpret_cast<f32x4v*>(lstm_lds + 4 * UB * QS * 64);
     const float* wsrc = a.whhp + ((int64_t)ub * KS + q * QS) * 64;
 #pragma unroll
     for (int i = 0; i < QS / 4; ++i)
@@ -355,10 +357,10 @@ __global__ __launch_bounds__(1024, 1) void lstm_seq_kernel(const LstmSeqArgs a) 
             }
 #pragma unroll
             for (int i = 0; i < QS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[i * 64 + lane], hb[i], acc, 0, 0, 0);
-            if (q > 0) part[((q - 1) * 4 + ubl) * 64 + lane] = acc;
+            if (q > 0) part[((q - 1) * UB + ubl) * 64 + lane] = acc;
             __syncthreads();
             if (q == 0) {
-                const f32x4v p1 = part[(0 * 4 + ubl) * 64 + lane], p2 = part[(1 * 4 + ubl) * 64 + lane], p3 = part[(2 * 4 + ubl) * 64 + lane];
+                const f32x4v p1 = part[(0 * UB + ubl) * 64 + lane], p2 = part[(1 * UB + ubl) * 64 + lane], p3 = part[(2 * UB + ubl) * 64 + lane];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[r] = (acc[r] + p1[r]) + (p2[r] + p3[r]);
             }
@@ -1127,8 +1129,15 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
         cstart.push_back(T);
         const int nch = (int)cstart.size() - 1;
         const bool piped = nch > 1;
-        const int nprod = C / 16, n_tiles = (N + 15) / 16, per_launch = std::max(1, 64 / nprod);
-        const size_t lds = (size_t)4 * KS * 64 * 4 + 3 * 4 * 64 * 16;
+        // Unit blocks per workgroup: 2 at C = 512 with ONE column tile (64 workgroups of 8 wavefronts, 72 KB of LDS each -- the
+        // matrix-core part of a step is 2 chains per SIMD instead of 4: 1.8 -> 0.9 us of the ~5.7; Encodec 24 kHz at 16 clips
+        // 6.24 -> 6.13 ms), 4 otherwise: with two tiles the 2 x 64-producer exchange costs more than the chains save (C3 9.59 -> 9.70 ms).
+        // NC_LSTM_UB=4 / 2 force one form.
+        static const int ub_env = std::getenv("NC_LSTM_UB") ? atoi(std::getenv("NC_LSTM_UB")) : 0;
+        const int n_tiles = (N + 15) / 16;
+        const int UBW = (KS == 128 && (ub_env == 2 || (ub_env != 4 && n_tiles == 1))) ? 2 : 4;
+        const int nprod = C / (4 * UBW), per_launch = std::max(1, (UBW == 2 ? 128 : 64) / nprod);
+        const size_t lds = (size_t)4 * UBW * (KS / 4) * 64 * 4 + 3 * UBW * 64 * 16;
         unsigned* sync = lstm_tmo_dev;                                                 // timeout word (host-visible)
         {   // NC_LSTM_FAKE_TIMEOUT=1 (tests): the first persistent launch of the process is reported as timed out
             static bool fake = std::getenv("NC_LSTM_FAKE_TIMEOUT") && std::getenv("NC_LSTM_FAKE_TIMEOUT")[0] == '1';
@@ -1177,10 +1186,11 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
                 a.N = N; a.C = C; a.T = T; a.t0 = t0; a.t1 = t1; a.tile0 = tl;
                 auto launch = [&](auto kern) {
                     ensure_dynamic_lds((const void*)kern, lds);
-                    hipLaunchKernelGGL(kern, dim3((unsigned)nprod, (unsigned)nt), dim3(1024), lds, s, a);
+                    hipLaunchKernelGGL(kern, dim3((unsigned)nprod, (unsigned)nt), dim3(256 * UBW), lds, s, a);
                 };
-                if (KS == 128) launch(lstm_seq_kernel<128>);
-                else launch(lstm_seq_kernel<16>);
+                if (KS == 128 && UBW == 2) launch(lstm_seq_kernel<128, 2>);
+                else if (KS == 128) launch(lstm_seq_kernel<128, 4>);
+                else launch(lstm_seq_kernel<16, 4>);
             }
             NC_HIP(hipGetLastError());
             if (prof.on) prof.end(s);

@@ -72,12 +72,13 @@ def test_group_local_mode_more_devices_than_clips():
     _finish([_run(["group_local", 4, 3])])
 
 
-# A three-row subset of tools/probe/envmatrix.sh: every fast path has a switch back to the path it replaced, and the parity tests must
+# A four-row subset of tools/probe/envmatrix.sh: every fast path has a switch back to the path it replaced, and the parity tests must
 # hold on those paths too (fresh interpreters: the switches are read once per process).
 FALLBACK_ROWS = [
     {"NC_NO_GN_FUSE": "1", "NC_NO_IN2": "1", "NC_NO_CONV3S": "1"},                     # stand-alone GroupNorm sums, summed copies, windowed k=3
     {"NC_LSTM_STEPWISE": "1", "NC_NO_TINY_TILES": "1", "NC_NO_SUBPIXEL": "1"},         # step-wise LSTM, filled-grid tile rule, per-phase up-convs
     {"NC_NO_FUSE": "1", "NC_ENCODEC_NO_FUSE": "1", "NC_DAC_RVQ_STAGEWISE": "1"},       # two-launch residual units, padded copies, stage-wise RVQ
+    {"NC_NO_FLAT_GN": "1", "NC_LSTM_NO_ELU": "1", "NC_NO_DIST_SMALL": "1", "NC_LSTM_UB": "2", "NC_NO_SUBPIXEL_ANY": "1"},   # one-clip GroupNorm tiles, ELU in the consumer, segmented staging, 8-wave LSTM
 ]
 
 

@@ -288,3 +288,22 @@ def test_conv_transpose_short_rows_bit_exact(cin, cout, s, T, B):
     want = c_oracle.snake(c_oracle.conv_transpose1d(x, w, b, s, pad, s % 2), ao)
     got = ops.conv1d(x, w, b, s, pad, 1, alpha_out=ao, transposed=True, out_pad=s % 2)
     assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+
+
+@pytest.mark.parametrize("cin,cout,s,pad,T,B,snake_out", [(96, 64, 3, 2, 200, 2, True), (64, 32, 5, 0, 150, 3, False), (128, 32, 6, 3, 77, 2, True),
+                                                          (256, 128, 5, 0, 150, 4, False), (64, 32, 7, 4, 50, 1, False), (384, 192, 3, 2, 300, 2, True)])
+def test_conv_transpose_subpixel_any_stride_bit_exact(cin, cout, s, pad, T, B, snake_out):
+    """Sub-pixel form for strides that are not a power of two (SNAC's stride-3 block with output_padding = 1, Encodec's stride-5
+    SConvTranspose1d with no padding): rows = (channel, phase) through the multiply-shift map, row tiles that do not start on a channel
+    boundary, partial last row tiles, Snake of the consumer in the epilogue."""
+    rng = np.random.default_rng(cin + 17 * s)
+    op = s % 2 if pad else 0
+    x = _rand(rng, B, cin, T)
+    w = _rand(rng, cin, cout, 2 * s, scale=1.0 / np.sqrt(cin * 2)); b = _rand(rng, cout, scale=0.1)
+    ao = _alpha(rng, cout) if snake_out else None
+    want = c_oracle.conv_transpose1d(x, w, b, s, pad, op)
+    if snake_out:
+        want = c_oracle.snake(want, ao)
+    got = ops.conv1d(x, w, b, s, pad, 1, alpha_out=ao, transposed=True, out_pad=op)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
