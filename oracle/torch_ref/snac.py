@@ -37,15 +37,22 @@ class TorchSNAC:
         self.hop = cfg.hop_length
         self.latent = cfg.resolved_latent_dim
         self.attn = cfg.attn_window_size
+        # Deviations of the C# port that can be UNDONE to reproduce upstream SNAC semantics, for the structural cross-check against an
+        # independent composition only (tools/crosscheck_hf.py::crosscheck_snac_blocks).  Empty = the reference's behaviour.
+        self.upstream = set()
 
     # ---- leaves ---------------------------------------------------------------------------
     def snake(self, x, key):
         alpha = self.sd[key + ".alpha"]
+        if "D4" in self.upstream:                                                  # upstream: x + sin^2(ax) / (a + 1e-9)
+            return x + (alpha + 1e-9).reciprocal() * torch.sin(alpha * x).pow(2)
         return torch.where(alpha == 0, x, torch.addcdiv(x, torch.sin(alpha * x).pow_(2), alpha, value=1))
 
     def _w(self, key):
         v, g = self.sd[key + G1], self.sd[key + G0]
         v_norm = v.contiguous().pow(2).sum([1, 2], keepdim=True, dtype=torch.float32).sqrt()
+        if "D3" in self.upstream:                                                  # upstream: v * g / ||v||
+            return torch.mul(v.div(v_norm), g.reshape(v.shape[0], 1, 1)).contiguous()
         return torch.mul(v.div(v_norm), g.reshape(v.shape[0], 1, 1).sub(1e-7)).contiguous()
 
     def conv(self, x, key, stride=1, padding=0, dilation=1, groups=1):
@@ -162,9 +169,12 @@ class TorchSNAC:
         B, D, T = z_e.shape
         enc = z_e.transpose(1, 2).reshape(-1, D).contiguous()
         cb = self.sd[p + ".codebook.weight"]
+        cb_full = cb
+        if "D1" in self.upstream:                                  # upstream: lookup on l2-normalised vectors (VectorQuantizer.cs:125 says so, the code does not)
+            enc, cb = F.normalize(enc), F.normalize(cb)
         dist = enc.pow(2).sum(1, keepdim=True) + cb.pow(2).sum(1, keepdim=True).t() - torch.einsum("bd,nd->bn", enc, cb).mul_(2.0)
         idx = dist.argmin(1).reshape(B, T)
-        z_q = F.embedding(idx, cb).transpose(1, 2).contiguous()
+        z_q = F.embedding(idx, cb_full).transpose(1, 2).contiguous()
         z_q = z_e + (z_q - z_e)
         z_q = self.conv(z_q, p + ".out_proj")
         if s > 1:

@@ -51,3 +51,17 @@ def test_snac_local_attention_matches_an_independent_composition():
     assert r["inv_freq_max_abs"] == 0.0
     assert r["max_abs"] <= 2e-6 * max(1.0, r["scale"])
     assert r["without_rotary_max_abs"] > 1e-3
+
+
+def test_snac_conv_graph_and_quantizer_stage_match_an_independent_composition():
+    """VERDICT r2 "SNAC has no independent check": encoder, decoder (depthwise units, stride-3 block with output_padding, noise block) and
+    the quantizer stages against torch.nn modules under PyTorch's weight_norm + HF's Snake1d / DacVectorQuantize
+    (tools/crosscheck_hf.py::crosscheck_snac_blocks)."""
+    import crosscheck_hf
+    for seed in (0, 1):
+        r = crosscheck_hf.crosscheck_snac_blocks(seed=seed)
+        assert r["encoder_max_abs"] <= 5e-6 * max(1.0, r["encoder_scale"])                 # float32 round-off of two weight-norm evaluation orders
+        assert r["decoder_len"][0] == r["decoder_len"][1]
+        assert r["decoder_max_abs"] <= 5e-6 * max(1.0, r["decoder_pre_tanh_scale"])        # ... carried through the tanh (slope <= 1)
+        assert r["codes_equal_frac"] >= 0.995 and r["zq_max_abs_same_frames"] < 1e-5       # the quantizer stage once D1 is undone
+        assert r["codes_equal_frac_with_D1_as_in_reference"] < 0.95                        # and D1 is a behavioural difference of the port
