@@ -1,3 +1,4 @@
+// Build: hipcc --offload-arch=gfx950 -O2 -o tools/probe/placeprobe tools/probe/placeprobe.hip   (the binary is git-ignored; it travels with gpurun)
 // Workgroup placement probe: every workgroup of a grid records (XCC_ID, HW_ID) and spins for `spin_ticks` of the 100 MHz wall clock, so that
 // all workgroups of the grid are resident at once.  Answers: how many workgroups share a CU at a given grid size / LDS request?
 #include <hip/hip_runtime.h>
