@@ -121,6 +121,7 @@ struct ConvLayer {
     std::vector<std::unique_ptr<Alt>> alts;
     DevBuf w_thin;   // Cout <= 2, stride 1: dense [Cout][Cin][K] image for the streaming thin-output kernel (nc_conv_thin.hip)
     DevBuf w_stem;   // Cin == 1, K == 7, stride 1: dense [Cout][K] image for the streaming stem kernel (nc_conv_thin.hip)
+    DevBuf w_small;  // strided, K >= 4, Cin*K % 16 == 0: A-fragment image of conv_small_kernel (nc_conv_small.hip: short rows of few-clip batches)
     DevBuf w_skinny; // K==1, Cout<=16, Cin%64==0: [Cin/4][64 lanes] A-fragment image of skinny_proj_kernel (rows >= Cout zero)
     DevBuf w_fused;  // K==1, Cin==Cout<=128: [row block][ci][32 rows] image consumed by the fused residual-unit kernel
     bool has_bias = false;
@@ -130,7 +131,7 @@ struct ConvLayer {
     void build(const float* dense_w, const float* bias_h, int Cin, int Cout, int K, int stride, int pad, int dil, int out_pad,
                bool transposed);
     void release_all() {   // op-level hooks build throw-away layers
-        w.release(); bias.release(); w_skinny.release(); w_fused.release(); w_thin.release(); w_stem.release();
+        w.release(); bias.release(); w_skinny.release(); w_fused.release(); w_thin.release(); w_stem.release(); w_small.release();
         for (auto& a : alts) a->w.release();
         alts.clear();
     }
@@ -189,6 +190,12 @@ struct ThinInmArgs {
     double* gn_part; int gn_ncb; unsigned* gn_count; float* gn_stats; double gn_n;
 };
 bool launch_conv_thin_inm(const ThinInmArgs& a, int B, int Cout, hipStream_t s);
+
+// short-row strided convolution on v_mfma_f32_16x16x4_f32 (nc_conv_small.hip): plain input, bias-only epilogue
+bool conv_small_eligible(int Cin, int Cout, int K, int stride, int dil, bool transposed);
+void pack_conv_small(const float* dense_w, int Cin, int Cout, int K, std::vector<float>& out);
+bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int x_len, const float* wp, const float* bias, float* y, int64_t y_bstride,
+                       int64_t y_cstride, int B, int Cin, int Cout, int K, int stride, int pad, int dil, int Tout, hipStream_t s);
 
 TileCfg pick_tile(int Cout, int Ktaps);
 // true when `k7` followed by `k1` can run as one fused residual-unit launch

@@ -280,6 +280,15 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
         w_stem.reserve(sizeof(float) * (size_t)Cout * K);
         NC_HIP(hipMemcpy(w_stem.p, dense_w, sizeof(float) * (size_t)Cout * K, hipMemcpyHostToDevice));
     }
+    {   // image for the short-row kernel (nc_conv_small.hip): the strided down-convolutions, taken when a launch has few columns
+        static const bool no_small = std::getenv("NC_NO_CONV_SMALL") && std::getenv("NC_NO_CONV_SMALL")[0] == '1';
+        if (!no_small && conv_small_eligible(Cin, Cout, K, stride, dil, transposed)) {
+            std::vector<float> img;
+            pack_conv_small(dense_w, Cin, Cout, K, img);
+            w_small.reserve(img.size() * sizeof(float));
+            NC_HIP(hipMemcpy(w_small.p, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
     if (!transposed && stride == 1 && Cout <= 2 && (K == 7 || K == 3 || K == 1)) {
         w_thin.reserve(sizeof(float) * (size_t)Cout * Cin * K);
         NC_HIP(hipMemcpy(w_thin.p, dense_w, sizeof(float) * (size_t)Cout * Cin * K, hipMemcpyHostToDevice));
@@ -562,6 +571,19 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     if (launch_conv1x1(L, io, B, stream, prof)) return;
     if (launch_conv3_stream(L, io, B, stream, prof)) return;
     const int64_t Tout = L.out_len(io.Tin);
+    {   // Short rows of a few-clip batch (one-clip SNAC / DAC: the deep down-convolutions over 47 .. 375 frames): the 16x16x4 kernel of
+        // nc_conv_small.hip -- 16-column tiles, a four times shorter dependent chain -- while the launch stays a grid of lone workgroups.
+        static const int64_t max_grid = std::getenv("NC_SMALL_MAX_GRID") ? atol(std::getenv("NC_SMALL_MAX_GRID")) : 2048;
+        const int64_t grid = (int64_t)B * ((Tout + 15) / 16) * ((L.Cout + 63) / 64);
+        if (L.w_small.p && !in_mode && !io.alpha_in && !io.alpha_out && !io.res && !io.fuse_k1 && io.epi == 0 && !io.gn_part && grid <= max_grid &&
+            (int64_t)(L.Cin) * io.x_cstride + io.x_len < ((int64_t)1 << 40)) {
+            ProfScope ps(prof, stream, L.kclass, L.flops(B, io.Tin),
+                         4.0 * ((double)B * L.Cin * io.Tin + (double)B * L.Cout * Tout + (double)L.Cin * L.Cout * L.K));
+            if (launch_conv_small(io.x, io.x_bstride, io.x_cstride, io.x_len, L.w_small.as<float>(), L.has_bias ? L.bias.as<float>() : nullptr, io.y, io.y_bstride,
+                                  io.y_cstride, B, L.Cin, L.Cout, L.K, L.stride, L.pad, L.dil, (int)Tout, stream))
+                return;
+        }
+    }
     const int64_t n_cols_all = L.transposed ? io.Tin + L.Ktaps - 1 : Tout;
     TileChoice tsel{L.cfg, L.w.as<float>(), L.w_phase_stride};
     if (!io.fuse_k1) tsel = choose_tile(L, (int64_t)L.n_phase * B * ((n_cols_all + 255) / 256), false);

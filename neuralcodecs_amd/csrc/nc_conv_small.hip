@@ -1,0 +1,299 @@
+// Short-row strided convolution on v_mfma_f32_16x16x4_f32: the deep down-convolutions of a ONE-clip (or few-clip) batch -- SNAC 24 kHz
+// at one second: 384 -> 768, k = 16, stride 8 over 47 output frames (EncoderBlock.cs:42-47) -- are a skinny GEMM, 768 x 6144 weights
+// against 47 columns.  On the 32x32x2 template such a launch is a handful of lone workgroups, each walking its reduction as ONE dependent
+// chain of 3072 matrix-core instructions of 64 cycles (245 us measured, 8 % of the whole C1 step per layer).  The 16x16x4 instruction
+// retires four reduction steps per 32 cycles -- the same canonical chain (bitwise a k-ordered fmaf chain, as in the persistent LSTM),
+// four times shorter -- and 16-column tiles turn 47 frames into three workgroups per row block instead of one.
+//   * workgroup = 4 wavefronts = 64 output rows x 16 output columns of one clip; wave w owns rows 16w .. 16w+15;
+//   * weights never touch LDS: every wave streams its own A fragments from a packed image ([16-row tile][group of 4 steps][lane][4],
+//     one 16-byte load per lane and group) through a ring of SMALL_PF groups in flight;
+//   * the input window of the 16 columns (15*stride + (K-1)*dil + 1 samples per channel) is staged through LDS, SMALL_CB channels per
+//     block, double-buffered, one barrier per block; zero padding by predicate;
+//   * per output: fmaf over kk = ci*K + k ascending from +0 (four kk per instruction), then + bias -- the canonical chain.
+// Plain input, bias-only epilogue (the callers' Snake arrives applied by the producer).
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "nc_conv.h"
+
+namespace nc {
+
+typedef float small_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int N, class F, int... I>
+__device__ __forceinline__ void nc_static_for_small_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void nc_static_for_small(F&& f) {
+    nc_static_for_small_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+constexpr int SMALL_CB = 8;    // input channels per LDS block
+constexpr int SMALL_PF = 12;   // weight groups (4 matrix-core steps each) in flight per wave
+
+struct ConvSmallArgs {
+    const float* x;
+    int64_t x_bstride, x_cstride;
+    int x_len;
+    const float* wp;     // packed image, see pack_small()
+    const float* bias;   // nullable
+    float* y;
+    int64_t y_bstride, y_cstride;
+    int Cin, Cout, K, stride, pad, dil, Tout;
+    int n_t_tiles, n_row_tiles;   // 16-column tiles per clip, 64-row tiles
+    int W;                         // window samples per channel: 15*stride + (K-1)*dil + 1
+    int groups;                    // Cin*K / 16: groups of 4 steps in the whole reduction
+};
+
+__global__ __launch_bounds__(256) void conv_small_kernel(const ConvSmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [2][SMALL_CB][W]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    const int rt = bid % a.n_row_tiles; bid /= a.n_row_tiles;        // row tiles of one column tile are adjacent: they share the window in L2
+    const int tt = bid % a.n_t_tiles;
+    const int b = bid / a.n_t_tiles;
+    const int K = a.K, W = a.W, dil = a.dil;
+    const int col = lane & 15, kq = lane >> 4;
+    const int g0 = tt * 16 * a.stride - a.pad;                       // input position of window slot 0
+    const float* xb = a.x + (int64_t)b * a.x_bstride;
+    // this wave's weight stream: 16-row tile (4*rt + wave), groups in reduction order
+    const small_f32x4* wsrc = reinterpret_cast<const small_f32x4*>(a.wp) + ((int64_t)(4 * rt + wave) * a.groups) * 64 + lane;
+    const int groups = a.groups;
+    small_f32x4 ring[SMALL_PF];
+#pragma unroll
+    for (int i = 0; i < SMALL_PF; ++i) ring[i] = wsrc[(int64_t)min(i, groups - 1) * 64];
+    // window staging: block cbk = channels [cbk*CB, cbk*CB + CB), slot i of the block = channel i / W, position i % W
+    const int n_blocks = (a.Cin + SMALL_CB - 1) / SMALL_CB;
+    const int n_slots = SMALL_CB * W;
+    constexpr int NS = 6;                                            // slots per thread (CB * W <= 6 * 256)
+    float rx[NS];
+    auto issue = [&](int cbk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int i = tid + 256 * u;
+            const int c = i / W, j = i - c * W;
+            const int ci = cbk * SMALL_CB + c, g = g0 + j;
+            const bool ok = (i < n_slots) & (ci < a.Cin) & (g >= 0) & (g < a.x_len);
+            rx[u] = ok ? xb[(int64_t)ci * a.x_cstride + g] : 0.0f;
+        }
+    };
+    auto store = [&](float* dst) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int i = tid + 256 * u;
+            if (i < n_slots) dst[i] = rx[u];
+        }
+    };
+    issue(0);
+    store(xs);
+    __syncthreads();
+    small_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    // This lane's reduction index inside a block is kk_local = 4*step + kq -> (channel c, tap k), i.e. window offset c*W + col*stride + k*dil.
+    // (k, off) is the READ cursor: the four B values of a group are read one group ahead of the matrix-core steps that consume them.
+    const int groups_per_block = SMALL_CB * K / 16;                  // (host: CB*K % 16 == 0, blocks are whole groups)
+    int cbk = 0, gblk = 0;
+    const float* xc = xs;
+    if (n_blocks > 1) issue(1);
+    int k = kq, off = col * a.stride + kq * dil;                     // (K >= 4: kq < K)
+    auto read_group = [&](float (&bv)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bv[j] = xc[off];
+            k += 4; off += 4 * dil;
+            if (k >= K) { k -= K; off += W - K * dil; }              // next channel row of the block
+        }
+    };
+    float bc[4], bn[4];
+    read_group(bc);
+    for (int gbase = 0; gbase < groups; gbase += SMALL_PF) {
+        nc_static_for_small<SMALL_PF>([&](auto it) __attribute__((always_inline)) {
+            constexpr int i = decltype(it)::value;
+            if (gbase + i < groups) {                                // (wave-uniform)
+                const small_f32x4 wv = ring[i];
+                ring[i] = wsrc[(int64_t)min(gbase + i + SMALL_PF, groups - 1) * 64];
+                const bool last_of_block = gblk + 1 == groups_per_block;
+                if (!last_of_block) read_group(bn);                  // next group of this block: its reads land under this group's steps
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], bc[j], acc, 0, 0, 0);
+                if (last_of_block) {
+                    ++cbk;
+                    gblk = 0;
+                    if (cbk < n_blocks) {                            // publish the staged block, start staging the one after
+                        store(xs + (cbk & 1) * n_slots);
+                        __syncthreads();
+                        xc = xs + (cbk & 1) * n_slots;
+                        if (cbk + 1 < n_blocks) issue(cbk + 1);
+                        k = kq; off = col * a.stride + kq * dil;
+                        read_group(bn);
+                    }
+                } else {
+                    ++gblk;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bc[j] = bn[j];
+            }
+        });
+    }
+    // D: lane holds rows 4*kq + r (r = 0..3) of its wave's 16-row tile, column col
+    const int t = tt * 16 + col;
+    if (t < a.Tout) {
+        float* yb = a.y + (int64_t)b * a.y_bstride + t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (4 * rt + wave) * 16 + 4 * kq + r;
+            if (row < a.Cout) yb[(int64_t)row * a.y_cstride] = acc[r] + (a.bias ? a.bias[row] : 0.0f);
+        }
+    }
+}
+
+// Straight-line form: NB blocks of GPB weight groups per loop iteration, the ring position of every group a compile-time constant.
+// In the rolled kernel above the compiler cannot see, across its branches, how many weight loads were issued after a block's window
+// loads, and drains the whole ring in front of every block barrier (s_waitcnt vmcnt(1): one memory latency per 8 channels -- 48 of
+// them in the 384 -> 768 layer, 98 us).  Here the window loads of block n+1 are followed by exactly GPB ring loads before the barrier
+// that needs them, the wait is vmcnt(GPB), and the weight stream never stops.  Needs n_blocks % NB == 0 (the host checks).
+template <int GPB, int NB>
+__global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmallArgs a) {
+    constexpr int PF = GPB * NB;                                      // ring depth = groups per loop iteration
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    const int rt = bid % a.n_row_tiles; bid /= a.n_row_tiles;
+    const int tt = bid % a.n_t_tiles;
+    const int b = bid / a.n_t_tiles;
+    const int K = a.K, W = a.W, dil = a.dil;
+    const int col = lane & 15, kq = lane >> 4;
+    const int g0 = tt * 16 * a.stride - a.pad;
+    const float* xb = a.x + (int64_t)b * a.x_bstride;
+    const small_f32x4* wsrc = reinterpret_cast<const small_f32x4*>(a.wp) + ((int64_t)(4 * rt + wave) * a.groups) * 64 + lane;
+    const int groups = a.groups;
+    small_f32x4 ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) ring[i] = wsrc[(int64_t)min(i, groups - 1) * 64];
+    const int n_blocks = a.Cin / SMALL_CB;
+    const int n_slots = SMALL_CB * W;
+    constexpr int NS = 6;
+    float rx[NS];
+    // loop-invariant part of the window reads: slot -> (channel of the block, position), predicate of the position
+    int xo[NS];
+    unsigned okm = 0;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int i = tid + 256 * u;
+        const int c = i / W, j = i - c * W, g = g0 + j;
+        const bool ok = (i < n_slots) & (g >= 0) & (g < a.x_len);
+        if (ok) okm |= 1u << u;
+        xo[u] = ok ? c * (int)a.x_cstride + g : 0;                   // (host: Cin * x_cstride fits 31 bits)
+    }
+    auto issue = [&](int cbk) __attribute__((always_inline)) {
+        const float* xr = xb + (int64_t)cbk * SMALL_CB * a.x_cstride;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) rx[u] = xr[xo[u]];               // branch-free: masked slots read a valid word and are zeroed at the store
+    };
+    auto store = [&](float* dst) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int i = tid + 256 * u;
+            if (i < n_slots) dst[i] = ((okm >> u) & 1u) ? rx[u] : 0.0f;
+        }
+    };
+    issue(0);
+    store(xs);
+    __syncthreads();
+    small_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int off0 = col * a.stride + kq * dil;
+    for (int cb0 = 0; cb0 < n_blocks; cb0 += NB) {
+        nc_static_for_small<NB>([&](auto bt) __attribute__((always_inline)) {
+            constexpr int nb = decltype(bt)::value;
+            const int cbk = cb0 + nb;
+            const float* xc = xs + (cbk & 1) * n_slots;
+            const int nxt = min(cbk + 1, n_blocks - 1);              // (the last block re-reads itself: branch-free, never stored)
+            issue(nxt);
+            int k = kq, off = off0;
+            float bv[2][4];
+            auto read_group = [&](float (&v)[4]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = xc[off];
+                    k += 4; off += 4 * dil;
+                    if (k >= K) { k -= K; off += W - K * dil; }
+                }
+            };
+            read_group(bv[0]);
+            nc_static_for_small<GPB>([&](auto gt) __attribute__((always_inline)) {
+                constexpr int g = decltype(gt)::value, ri = nb * GPB + g;
+                const small_f32x4 wv = ring[ri];
+                ring[ri] = wsrc[(int64_t)min((cbk + NB) * GPB + g, groups - 1) * 64];
+                if constexpr (g + 1 < GPB) read_group(bv[(g + 1) & 1]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], bv[g & 1][j], acc, 0, 0, 0);
+            });
+            store(xs + ((cbk + 1) & 1) * n_slots);                    // (after the last block: a dead store into the free buffer)
+            __syncthreads();
+        });
+    }
+    const int t = tt * 16 + col;
+    if (t < a.Tout) {
+        float* yb = a.y + (int64_t)b * a.y_bstride + t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (4 * rt + wave) * 16 + 4 * kq + r;
+            if (row < a.Cout) yb[(int64_t)row * a.y_cstride] = acc[r] + (a.bias ? a.bias[row] : 0.0f);
+        }
+    }
+}
+
+// packed image for conv_small_kernel: float index ((tile*groups + g)*64 + lane)*4 + j = W[row = 16*tile + (lane & 15)][kk = 16g + 4j + (lane >> 4)]
+void pack_conv_small(const float* dense_w, int Cin, int Cout, int K, std::vector<float>& out) {
+    const int tiles = ((Cout + 63) / 64) * 4, groups = Cin * K / 16;
+    out.assign((size_t)tiles * groups * 256, 0.0f);
+    for (int tile = 0; tile < tiles; ++tile)
+        for (int g = 0; g < groups; ++g)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 4; ++j) {
+                    const int row = 16 * tile + (l & 15), kk = 16 * g + 4 * j + (l >> 4);
+                    if (row < Cout) out[(((size_t)tile * groups + g) * 64 + l) * 4 + j] = dense_w[(size_t)row * Cin * K + kk];   // [Cout][Cin][K]: kk = ci*K + k
+                }
+}
+
+bool conv_small_eligible(int Cin, int Cout, int K, int stride, int dil, bool transposed) {
+    if (transposed || K < 4 || stride < 2 || Cout < 64) return false;
+    if ((Cin * K) % 16 != 0 || (SMALL_CB * K) % 16 != 0 || Cin % SMALL_CB != 0) return false;
+    const int W = 15 * stride + (K - 1) * dil + 1;
+    return SMALL_CB * W <= 6 * 256 && (size_t)2 * SMALL_CB * W * 4 <= 64 * 1024;
+}
+
+bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int x_len, const float* wp, const float* bias, float* y, int64_t y_bstride,
+                       int64_t y_cstride, int B, int Cin, int Cout, int K, int stride, int pad, int dil, int Tout, hipStream_t s) {
+    ConvSmallArgs a{};
+    a.x = x; a.x_bstride = x_bstride; a.x_cstride = x_cstride; a.x_len = x_len; a.wp = wp; a.bias = bias;
+    a.y = y; a.y_bstride = y_bstride; a.y_cstride = y_cstride;
+    a.Cin = Cin; a.Cout = Cout; a.K = K; a.stride = stride; a.pad = pad; a.dil = dil; a.Tout = Tout;
+    a.n_t_tiles = (Tout + 15) / 16; a.n_row_tiles = (Cout + 63) / 64;
+    a.W = 15 * stride + (K - 1) * dil + 1;
+    a.groups = Cin * K / 16;
+    const size_t lds = (size_t)2 * SMALL_CB * a.W * sizeof(float);
+    const int64_t grid = (int64_t)B * a.n_t_tiles * a.n_row_tiles;
+    if (grid <= 0 || grid > 0x7fffffff) return false;
+    // the straight-line form where the block count is a multiple of its unroll; the rolled kernel otherwise
+    static const bool rolled_only = std::getenv("NC_SMALL_ROLLED") && std::getenv("NC_SMALL_ROLLED")[0] == '1';
+    const int gpb = SMALL_CB * K / 16, n_blocks = Cin / SMALL_CB;
+    const bool fits31 = (int64_t)Cin * x_cstride + x_len < ((int64_t)1 << 31);
+    void (*fn)(const ConvSmallArgs) = conv_small_kernel;
+    if (!rolled_only && fits31 && Cin % SMALL_CB == 0) {
+        if (gpb == 8 && n_blocks % 2 == 0) fn = conv_small_unrolled_kernel<8, 2>;
+        else if (gpb == 4 && n_blocks % 4 == 0) fn = conv_small_unrolled_kernel<4, 4>;
+        else if (gpb == 5 && n_blocks % 4 == 0) fn = conv_small_unrolled_kernel<5, 4>;
+        else if (gpb == 3 && n_blocks % 6 == 0) fn = conv_small_unrolled_kernel<3, 6>;
+        else if (gpb == 2 && n_blocks % 8 == 0) fn = conv_small_unrolled_kernel<2, 8>;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, s, a);
+    NC_HIP(hipGetLastError());
+    return true;
+}
+
+}  // namespace nc
