@@ -194,8 +194,9 @@ bool launch_conv_thin_inm(const ThinInmArgs& a, int B, int Cout, hipStream_t s);
 // short-row strided convolution on v_mfma_f32_16x16x4_f32 (nc_conv_small.hip): plain input, bias-only epilogue
 bool conv_small_eligible(int Cin, int Cout, int K, int stride, int dil, bool transposed);
 void pack_conv_small(const float* dense_w, int Cin, int Cout, int K, std::vector<float>& out);
-bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int x_len, const float* wp, const float* bias, float* y, int64_t y_bstride,
-                       int64_t y_cstride, int B, int Cin, int Cout, int K, int stride, int pad, int dil, int Tout, hipStream_t s);
+int conv_small_max_tn(int Cin, int K, int stride, int dil);
+bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int x_len, const float* wp, const float* bias, const float* alpha_out, float* y,
+                       int64_t y_bstride, int64_t y_cstride, int B, int Cin, int Cout, int K, int stride, int pad, int dil, int Tout, int want_tn, hipStream_t s);
 
 TileCfg pick_tile(int Cout, int Ktaps);
 // true when `k7` followed by `k1` can run as one fused residual-unit launch
@@ -203,7 +204,7 @@ bool can_fuse_res_unit(const ConvLayer& k7, const ConvLayer& k1);  // TN is chos
 void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream, Profiler* prof);
 // true when launch_conv can emit the GroupNorm block sums of this launch's output from the kernel epilogue (ConvIO::gn_part); the
 // streaming thin / stem / skinny kernels and the per-phase transposed launches cannot (the caller then runs the stand-alone pass)
-bool conv_gn_fusable(const ConvLayer& L, const ConvIO& io);
+bool conv_gn_fusable(const ConvLayer& L, const ConvIO& io, int B = -1);   // B: clips of the launch (the short-row kernel, which has no such epilogue, is chosen per launch)
 // true when launch_conv has a two-input (ConvIO::x2) kernel for this layer
 bool conv_in2_available(const ConvLayer& L);
 // block view of a [C][T] GroupNorm input behind layer L (sub-pixel transposed convolutions: rows = (channel, phase) pairs)

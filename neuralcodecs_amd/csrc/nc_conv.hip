@@ -502,7 +502,24 @@ bool conv_in2_available(const ConvLayer& L) {
     return in2_kernel(L.Ktaps, L.sub_shift != 0, L.cfg.TM, 1) != nullptr;
 }
 
-bool conv_gn_fusable(const ConvLayer& L, const ConvIO& io) {
+// Short-row kernel (nc_conv_small.hip) for this launch?  0 = no, 1 = 16-column tiles (latency-bound launches: few workgroups of any
+// shape), 2 = 32-column tiles (k = 16 layers whose template grid would not fill the chip twice: 256 -> 512 at 150 frames x 32 rows
+// 365 -> 272 us, 512 -> 1024 at 87 frames x 32 clips 713 -> 572 us; with >= 512 template workgroups the template wins).
+static int conv_small_choice(const ConvLayer& L, const ConvIO& io, int B) {
+    if (!L.w_small.p || B <= 0) return 0;
+    const int in_mode = (io.in_stats ? 1 : 0) | (io.in_elu ? 2 : 0) | (io.in_L > 0 ? 4 : 0) | (io.x2 ? 8 : 0);
+    if (in_mode || io.alpha_in || io.res || io.fuse_k1 || io.epi != 0) return 0;
+    static const int64_t max_grid = std::getenv("NC_SMALL_MAX_GRID") ? atol(std::getenv("NC_SMALL_MAX_GRID")) : 2048;
+    static const int64_t wide_below = std::getenv("NC_SMALL_WIDE_BELOW") ? atol(std::getenv("NC_SMALL_WIDE_BELOW")) : 512;
+    const int64_t Tout = L.out_len(io.Tin);
+    const int64_t grid16 = (int64_t)B * ((Tout + 15) / 16) * ((L.Cout + 63) / 64);
+    if (grid16 <= max_grid) return 1;
+    const int64_t template_grid = (int64_t)((L.rows() + L.cfg.BM() - 1) / L.cfg.BM()) * (((int64_t)B * Tout + 255) / 256);
+    if (conv_small_max_tn(L.Cin, L.K, L.stride, L.dil) >= 2 && template_grid < wide_below) return 2;
+    return 0;
+}
+
+bool conv_gn_fusable(const ConvLayer& L, const ConvIO& io, int B) {
     static const bool off = std::getenv("NC_NO_GN_FUSE") && std::getenv("NC_NO_GN_FUSE")[0] == '1';
     // plain epilogues only; one launch covering the whole output (no per-phase transposed launches); the streaming thin-output /
     // stem / skinny kernels keep the stand-alone statistics pass (launch_conv skips them when gn_part is set, so the answer here only
@@ -510,6 +527,7 @@ bool conv_gn_fusable(const ConvLayer& L, const ConvIO& io) {
     if (off || io.res || io.alpha_out || io.alpha_in || io.epi || io.fuse_k1 || L.n_phase != 1 || (L.sub_stride && !L.sub_shift)) return false;
     if (L.w_thin.p) return thin_inm_layer(L) && io.in_L > 0;   // (the input-mode head kernel emits its sums; the plain head does not)
     if (L.w_stem.p || L.w_skinny.p) return false;
+    if (conv_small_choice(L, io, B)) return false;   // (bias-only epilogue: the caller runs the stand-alone statistics pass)
     return true;
 }
 
@@ -519,7 +537,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     if (in_mode && (io.alpha_in || io.fuse_k1)) fail(NC_ESTATE, "internal: the Encodec input mode does not combine with Snake / fused units");
     if (io.x2 && (!conv_in2_available(L) || (io.in_stats != nullptr) != (io.in_stats2 != nullptr)))
         fail(NC_ESTATE, "internal: no two-input kernel for this layer");
-    if (io.gn_part && !conv_gn_fusable(L, io)) fail(NC_ESTATE, "internal: this launch cannot emit GroupNorm block sums");
+    if (io.gn_part && !conv_gn_fusable(L, io, B)) fail(NC_ESTATE, "internal: this launch cannot emit GroupNorm block sums");
     if (L.w_skinny.p && !no_skinny && !in_mode && !io.alpha_in && !io.alpha_out && !io.res && io.epi == 0 && !io.fuse_k1 && io.x_len == io.Tin) {
         if (prof && prof->on)
             prof->begin(stream, L.kclass, L.flops(B, io.Tin), 4.0 * ((double)B * L.Cin * io.Tin + (double)B * L.Cout * io.Tin + (double)L.Cin * L.Cout));
@@ -571,16 +589,14 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     if (launch_conv1x1(L, io, B, stream, prof)) return;
     if (launch_conv3_stream(L, io, B, stream, prof)) return;
     const int64_t Tout = L.out_len(io.Tin);
-    {   // Short rows of a few-clip batch (one-clip SNAC / DAC: the deep down-convolutions over 47 .. 375 frames): the 16x16x4 kernel of
-        // nc_conv_small.hip -- 16-column tiles, a four times shorter dependent chain -- while the launch stays a grid of lone workgroups.
-        static const int64_t max_grid = std::getenv("NC_SMALL_MAX_GRID") ? atol(std::getenv("NC_SMALL_MAX_GRID")) : 2048;
-        const int64_t grid = (int64_t)B * ((Tout + 15) / 16) * ((L.Cout + 63) / 64);
-        if (L.w_small.p && !in_mode && !io.alpha_in && !io.alpha_out && !io.res && !io.fuse_k1 && io.epi == 0 && !io.gn_part && grid <= max_grid &&
-            (int64_t)(L.Cin) * io.x_cstride + io.x_len < ((int64_t)1 << 40)) {
+    if (const int small_tn = io.gn_part ? 0 : conv_small_choice(L, io, B)) {
+        // Short rows of a few-clip batch (one-clip SNAC / DAC: the deep down-convolutions over 47 .. 375 frames) and the k = 16 layers
+        // whose template grid leaves most of the chip to lone workgroups: the 16x16x4 kernel of nc_conv_small.hip
+        if ((int64_t)(L.Cin) * io.x_cstride + io.x_len < ((int64_t)1 << 40)) {
             ProfScope ps(prof, stream, L.kclass, L.flops(B, io.Tin),
                          4.0 * ((double)B * L.Cin * io.Tin + (double)B * L.Cout * Tout + (double)L.Cin * L.Cout * L.K));
-            if (launch_conv_small(io.x, io.x_bstride, io.x_cstride, io.x_len, L.w_small.as<float>(), L.has_bias ? L.bias.as<float>() : nullptr, io.y, io.y_bstride,
-                                  io.y_cstride, B, L.Cin, L.Cout, L.K, L.stride, L.pad, L.dil, (int)Tout, stream))
+            if (launch_conv_small(io.x, io.x_bstride, io.x_cstride, io.x_len, L.w_small.as<float>(), L.has_bias ? L.bias.as<float>() : nullptr, io.alpha_out,
+                                  io.y, io.y_bstride, io.y_cstride, B, L.Cin, L.Cout, L.K, L.stride, L.pad, L.dil, (int)Tout, small_tn, stream))
                 return;
         }
     }

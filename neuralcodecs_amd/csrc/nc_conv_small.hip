@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "nc_conv.h"
+#include "nc_math.h"
 
 namespace nc {
 
@@ -40,6 +41,7 @@ struct ConvSmallArgs {
     int x_len;
     const float* wp;     // packed image, see pack_small()
     const float* bias;   // nullable
+    const float* alpha_out;   // nullable: Snake of the consuming layer applied to the stored value (Snake1d.cs:40-63)
     float* y;
     int64_t y_bstride, y_cstride;
     int Cin, Cout, K, stride, pad, dil, Tout;
@@ -47,6 +49,16 @@ struct ConvSmallArgs {
     int W;                         // window samples per channel: 15*stride + (K-1)*dil + 1
     int groups;                    // Cin*K / 16: groups of 4 steps in the whole reduction
 };
+
+// value of the canonical chain -> stored value: + bias, then the consumer's Snake when the producer applies it
+__device__ __forceinline__ float small_epilogue(const ConvSmallArgs& a, int row, float v) {
+    v = v + (a.bias ? a.bias[row] : 0.0f);
+    if (a.alpha_out) {
+        const float al = a.alpha_out[row];
+        v = nc_snakef(v, al, nc_snake_inv(al));
+    }
+    return v;
+}
 
 __global__ __launch_bounds__(256) void conv_small_kernel(const ConvSmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) float xs[];   // [2][SMALL_CB][W]
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvSmallArgs a) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = (4 * rt + wave) * 16 + 4 * kq + r;
-            if (row < a.Cout) yb[(int64_t)row * a.y_cstride] = acc[r] + (a.bias ? a.bias[row] : 0.0f);
+            if (row < a.Cout) yb[(int64_t)row * a.y_cstride] = small_epilogue(a, row, acc[r]);
         }
     }
 }
@@ -155,8 +167,9 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvSmallArgs a) 
 // loads, and drains the whole ring in front of every block barrier (s_waitcnt vmcnt(1): one memory latency per 8 channels -- 48 of
 // them in the 384 -> 768 layer, 98 us).  Here the window loads of block n+1 are followed by exactly GPB ring loads before the barrier
 // that needs them, the wait is vmcnt(GPB), and the weight stream never stops.  Needs n_blocks % NB == 0 (the host checks).
-template <int GPB, int NB>
+template <int GPB, int NB, int TN = 1>
 __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmallArgs a) {
+    constexpr int BNC = 16 * TN;                                      // output columns per workgroup: TN column tiles share every A fragment
     constexpr int PF = GPB * NB;                                      // ring depth = groups per loop iteration
     extern __shared__ __attribute__((aligned(16))) float xs[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -167,7 +180,7 @@ __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmal
     const int b = bid / a.n_t_tiles;
     const int K = a.K, W = a.W, dil = a.dil;
     const int col = lane & 15, kq = lane >> 4;
-    const int g0 = tt * 16 * a.stride - a.pad;
+    const int g0 = tt * BNC * a.stride - a.pad;
     const float* xb = a.x + (int64_t)b * a.x_bstride;
     const small_f32x4* wsrc = reinterpret_cast<const small_f32x4*>(a.wp) + ((int64_t)(4 * rt + wave) * a.groups) * 64 + lane;
     const int groups = a.groups;
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmal
     for (int i = 0; i < PF; ++i) ring[i] = wsrc[(int64_t)min(i, groups - 1) * 64];
     const int n_blocks = a.Cin / SMALL_CB;
     const int n_slots = SMALL_CB * W;
-    constexpr int NS = 6;
+    constexpr int NS = TN == 1 ? 6 : TN == 2 ? 9 : 18;                              // slots per thread (host: CB * W <= NS * 256)
     float rx[NS];
     // loop-invariant part of the window reads: slot -> (channel of the block, position), predicate of the position
     int xo[NS];
@@ -204,8 +217,10 @@ __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmal
     issue(0);
     store(xs);
     __syncthreads();
-    small_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    const int off0 = col * a.stride + kq * dil;
+    small_f32x4 acc[TN];
+#pragma unroll
+    for (int c = 0; c < TN; ++c) acc[c] = small_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int off0 = col * a.stride + kq * dil, cts = 16 * a.stride;   // cts: window offset between adjacent column tiles
     for (int cb0 = 0; cb0 < n_blocks; cb0 += NB) {
         nc_static_for_small<NB>([&](auto bt) __attribute__((always_inline)) {
             constexpr int nb = decltype(bt)::value;
@@ -214,11 +229,12 @@ __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmal
             const int nxt = min(cbk + 1, n_blocks - 1);              // (the last block re-reads itself: branch-free, never stored)
             issue(nxt);
             int k = kq, off = off0;
-            float bv[2][4];
-            auto read_group = [&](float (&v)[4]) __attribute__((always_inline)) {
+            float bv[2][4][TN];
+            auto read_group = [&](float (&v)[4][TN]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    v[j] = xc[off];
+#pragma unroll
+                    for (int c = 0; c < TN; ++c) v[j][c] = xc[off + c * cts];
                     k += 4; off += 4 * dil;
                     if (k >= K) { k -= K; off += W - K * dil; }
                 }
@@ -230,19 +246,24 @@ __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmal
                 ring[ri] = wsrc[(int64_t)min((cbk + NB) * GPB + g, groups - 1) * 64];
                 if constexpr (g + 1 < GPB) read_group(bv[(g + 1) & 1]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], bv[g & 1][j], acc, 0, 0, 0);
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c = 0; c < TN; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], bv[g & 1][j][c], acc[c], 0, 0, 0);
             });
             store(xs + ((cbk + 1) & 1) * n_slots);                    // (after the last block: a dead store into the free buffer)
             __syncthreads();
         });
     }
-    const int t = tt * 16 + col;
-    if (t < a.Tout) {
-        float* yb = a.y + (int64_t)b * a.y_bstride + t;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = (4 * rt + wave) * 16 + 4 * kq + r;
-            if (row < a.Cout) yb[(int64_t)row * a.y_cstride] = acc[r] + (a.bias ? a.bias[row] : 0.0f);
+    for (int c = 0; c < TN; ++c) {
+        const int t = tt * BNC + c * 16 + col;
+        if (t < a.Tout) {
+            float* yb = a.y + (int64_t)b * a.y_bstride + t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (4 * rt + wave) * 16 + 4 * kq + r;
+                if (row < a.Cout) yb[(int64_t)row * a.y_cstride] = small_epilogue(a, row, acc[c][r]);
+            }
         }
     }
 }
@@ -267,15 +288,30 @@ bool conv_small_eligible(int Cin, int Cout, int K, int stride, int dil, bool tra
     return SMALL_CB * W <= 6 * 256 && (size_t)2 * SMALL_CB * W * 4 <= 64 * 1024;
 }
 
-bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int x_len, const float* wp, const float* bias, float* y, int64_t y_bstride,
-                       int64_t y_cstride, int B, int Cin, int Cout, int K, int stride, int pad, int dil, int Tout, hipStream_t s) {
+// widest column tile (in 16-column units) the instantiated kernels offer for this layer
+int conv_small_max_tn(int Cin, int K, int stride, int dil) {
+    const int W32 = 31 * stride + (K - 1) * dil + 1;
+    const bool k16 = K * SMALL_CB / 16 == 8 && Cin % SMALL_CB == 0 && (Cin / SMALL_CB) % 2 == 0;
+    return (k16 && SMALL_CB * W32 <= 9 * 256) ? 2 : 1;
+}
+
+bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int x_len, const float* wp, const float* bias, const float* alpha_out, float* y,
+                       int64_t y_bstride, int64_t y_cstride, int B, int Cin, int Cout, int K, int stride, int pad, int dil, int Tout, int want_tn, hipStream_t s) {
     ConvSmallArgs a{};
-    a.x = x; a.x_bstride = x_bstride; a.x_cstride = x_cstride; a.x_len = x_len; a.wp = wp; a.bias = bias;
+    a.x = x; a.x_bstride = x_bstride; a.x_cstride = x_cstride; a.x_len = x_len; a.wp = wp; a.bias = bias; a.alpha_out = alpha_out;
     a.y = y; a.y_bstride = y_bstride; a.y_cstride = y_cstride;
     a.Cin = Cin; a.Cout = Cout; a.K = K; a.stride = stride; a.pad = pad; a.dil = dil; a.Tout = Tout;
-    a.n_t_tiles = (Tout + 15) / 16; a.n_row_tiles = (Cout + 63) / 64;
-    a.W = 15 * stride + (K - 1) * dil + 1;
+    a.n_row_tiles = (Cout + 63) / 64;
     a.groups = Cin * K / 16;
+    // 32-column workgroups (two column tiles per A fragment: half the weight traffic) where the caller asks for them -- launches with
+    // thousands of 16-column tiles are bound by the weight stream out of L2; 16-column tiles for the latency-bound launches.  (A
+    // 64-column form is instantiated behind NC_SMALL_TN=4: 429 registers, one wave per SIMD, slower.)
+    static const int tn_env = std::getenv("NC_SMALL_TN") ? atoi(std::getenv("NC_SMALL_TN")) : 0;
+    const int W64 = 63 * stride + (K - 1) * dil + 1;
+    const bool tn2_fits = conv_small_max_tn(Cin, K, stride, dil) >= 2, tn4_fits = tn2_fits && SMALL_CB * W64 <= 18 * 256;
+    const int TN = (tn4_fits && tn_env == 4) ? 4 : (tn2_fits && (tn_env == 2 || (tn_env == 0 && want_tn >= 2))) ? 2 : 1;
+    a.n_t_tiles = (Tout + 16 * TN - 1) / (16 * TN);
+    a.W = (16 * TN - 1) * stride + (K - 1) * dil + 1;
     const size_t lds = (size_t)2 * SMALL_CB * a.W * sizeof(float);
     const int64_t grid = (int64_t)B * a.n_t_tiles * a.n_row_tiles;
     if (grid <= 0 || grid > 0x7fffffff) return false;
@@ -284,7 +320,13 @@ bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int
     const int gpb = SMALL_CB * K / 16, n_blocks = Cin / SMALL_CB;
     const bool fits31 = (int64_t)Cin * x_cstride + x_len < ((int64_t)1 << 31);
     void (*fn)(const ConvSmallArgs) = conv_small_kernel;
-    if (!rolled_only && fits31 && Cin % SMALL_CB == 0) {
+    if (TN == 4) {
+        if (!fits31) return false;
+        fn = conv_small_unrolled_kernel<8, 2, 4>;
+    } else if (TN == 2) {
+        if (!fits31) return false;
+        fn = conv_small_unrolled_kernel<8, 2, 2>;
+    } else if (!rolled_only && fits31 && Cin % SMALL_CB == 0) {
         if (gpb == 8 && n_blocks % 2 == 0) fn = conv_small_unrolled_kernel<8, 2>;
         else if (gpb == 4 && n_blocks % 4 == 0) fn = conv_small_unrolled_kernel<4, 4>;
         else if (gpb == 5 && n_blocks % 4 == 0) fn = conv_small_unrolled_kernel<5, 4>;

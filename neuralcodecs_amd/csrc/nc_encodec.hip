@@ -939,7 +939,7 @@ EncodecModel::GnJob EncodecModel::gn_begin(const ConvLayer& conv, ConvIO& io, in
     j.ncb = (int)(((L + sub - 1) / sub + 31) / 32);
     j.part = reinterpret_cast<double*>(alloc((size_t)N * j.nrb * j.ncb * 4));
     j.stats = alloc((size_t)N * 2);
-    if (conv_gn_fusable(conv, io)) {
+    if (conv_gn_fusable(conv, io, N)) {
         io.gn_part = j.part; io.gn_nrb = j.nrb; io.gn_ncb = j.ncb;
         j.fused = true;
         // finish inside the launch: the last workgroup of a sample to arrive writes (mean, rstd).  One self-resetting counter per

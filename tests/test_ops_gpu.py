@@ -328,3 +328,17 @@ def test_conv1d_short_rows_16x16x4_kernel_bit_exact(cin, cout, k, s, p, T, B):
     got = ops.conv1d(x, w, b, s, p, 1)
     assert got.shape == want.shape
     assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+
+
+@pytest.mark.parametrize("cin,cout,T,B", [(256, 512, 1200, 8), (512, 1024, 696, 4), (128, 256, 640, 40)])
+def test_conv1d_k16_wide_short_row_form_with_snake_out_bit_exact(cin, cout, T, B):
+    """k = 16 / stride 8 layers whose template grid would not fill the chip twice take the 32-column form of the 16x16x4 kernel
+    (two column tiles per A fragment); the consumer's Snake in the epilogue (DAC's last EncoderBlock, Encoder.cs:44)."""
+    rng = np.random.default_rng(cin + cout + T)
+    x = _rand(rng, B, cin, T)
+    w = _rand(rng, cout, cin, 16, scale=1.0 / np.sqrt(cin * 16)); b = _rand(rng, cout, scale=0.1)
+    ao = _alpha(rng, cout)
+    want = c_oracle.snake(c_oracle.conv1d(x, w, b, 8, 4, 1), ao)
+    got = ops.conv1d(x, w, b, 8, 4, 1, alpha_out=ao)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
