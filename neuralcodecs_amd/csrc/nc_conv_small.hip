@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvSmallArgs a) 
 // loads, and drains the whole ring in front of every block barrier (s_waitcnt vmcnt(1): one memory latency per 8 channels -- 48 of
 // them in the 384 -> 768 layer, 98 us).  Here the window loads of block n+1 are followed by exactly GPB ring loads before the barrier
 // that needs them, the wait is vmcnt(GPB), and the weight stream never stops.  Needs n_blocks % NB == 0 (the host checks).
-template <int GPB, int NB, int TN = 1>
+template <int GPB, int NB, int TN = 1, int CB = SMALL_CB, int NS = (TN == 1 ? 6 : TN == 2 ? 9 : 18)>
 __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmallArgs a) {
     constexpr int BNC = 16 * TN;                                      // output columns per workgroup: TN column tiles share every A fragment
     constexpr int PF = GPB * NB;                                      // ring depth = groups per loop iteration
@@ -187,9 +187,8 @@ __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmal
     small_f32x4 ring[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) ring[i] = wsrc[(int64_t)min(i, groups - 1) * 64];
-    const int n_blocks = a.Cin / SMALL_CB;
-    const int n_slots = SMALL_CB * W;
-    constexpr int NS = TN == 1 ? 6 : TN == 2 ? 9 : 18;                              // slots per thread (host: CB * W <= NS * 256)
+    const int n_blocks = a.Cin / CB;
+    const int n_slots = CB * W;
     float rx[NS];
     // loop-invariant part of the window reads: slot -> (channel of the block, position), predicate of the position
     int xo[NS];
@@ -203,7 +202,7 @@ __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmal
         xo[u] = ok ? c * (int)a.x_cstride + g : 0;                   // (host: Cin * x_cstride fits 31 bits)
     }
     auto issue = [&](int cbk) __attribute__((always_inline)) {
-        const float* xr = xb + (int64_t)cbk * SMALL_CB * a.x_cstride;
+        const float* xr = xb + (int64_t)cbk * CB * a.x_cstride;
 #pragma unroll
         for (int u = 0; u < NS; ++u) rx[u] = xr[xo[u]];               // branch-free: masked slots read a valid word and are zeroed at the store
     };
@@ -281,7 +280,11 @@ void pack_conv_small(const float* dense_w, int Cin, int Cout, int K, std::vector
                 }
 }
 
+// k = 7, stride 1 (the 512 <-> 128 convolutions around Encodec's quantizer, DAC's 1024 -> 1536 decoder input): 16 channels per block
+static bool small_k7(int Cin, int K, int stride, int dil) { return K == 7 && stride == 1 && dil == 1 && Cin % 32 == 0; }
+
 bool conv_small_eligible(int Cin, int Cout, int K, int stride, int dil, bool transposed) {
+    if (!transposed && Cout >= 64 && small_k7(Cin, K, stride, dil)) return true;
     if (transposed || K < 4 || stride < 2 || Cout < 64) return false;
     if ((Cin * K) % 16 != 0 || (SMALL_CB * K) % 16 != 0 || Cin % SMALL_CB != 0) return false;
     const int W = 15 * stride + (K - 1) * dil + 1;
@@ -290,6 +293,7 @@ bool conv_small_eligible(int Cin, int Cout, int K, int stride, int dil, bool tra
 
 // widest column tile (in 16-column units) the instantiated kernels offer for this layer
 int conv_small_max_tn(int Cin, int K, int stride, int dil) {
+    if (small_k7(Cin, K, stride, dil)) return 2;
     const int W32 = 31 * stride + (K - 1) * dil + 1;
     const bool k16 = K * SMALL_CB / 16 == 8 && Cin % SMALL_CB == 0 && (Cin / SMALL_CB) % 2 == 0;
     return (k16 && SMALL_CB * W32 <= 9 * 256) ? 2 : 1;
@@ -309,10 +313,11 @@ bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int
     static const int tn_env = std::getenv("NC_SMALL_TN") ? atoi(std::getenv("NC_SMALL_TN")) : 0;
     const int W64 = 63 * stride + (K - 1) * dil + 1;
     const bool tn2_fits = conv_small_max_tn(Cin, K, stride, dil) >= 2, tn4_fits = tn2_fits && SMALL_CB * W64 <= 18 * 256;
-    const int TN = (tn4_fits && tn_env == 4) ? 4 : (tn2_fits && (tn_env == 2 || (tn_env == 0 && want_tn >= 2))) ? 2 : 1;
+    const int TN = (tn4_fits && tn_env == 4 && !small_k7(Cin, K, stride, dil)) ? 4 : (tn2_fits && (tn_env == 2 || (tn_env == 0 && want_tn >= 2))) ? 2 : 1;
     a.n_t_tiles = (Tout + 16 * TN - 1) / (16 * TN);
     a.W = (16 * TN - 1) * stride + (K - 1) * dil + 1;
-    const size_t lds = (size_t)2 * SMALL_CB * a.W * sizeof(float);
+    const bool k7 = small_k7(Cin, K, stride, dil);
+    const size_t lds = (size_t)2 * (k7 ? 16 : SMALL_CB) * a.W * sizeof(float);
     const int64_t grid = (int64_t)B * a.n_t_tiles * a.n_row_tiles;
     if (grid <= 0 || grid > 0x7fffffff) return false;
     // the straight-line form where the block count is a multiple of its unroll; the rolled kernel otherwise
@@ -320,7 +325,10 @@ bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int
     const int gpb = SMALL_CB * K / 16, n_blocks = Cin / SMALL_CB;
     const bool fits31 = (int64_t)Cin * x_cstride + x_len < ((int64_t)1 << 31);
     void (*fn)(const ConvSmallArgs) = conv_small_kernel;
-    if (TN == 4) {
+    if (k7) {
+        if (!fits31) return false;
+        fn = TN == 2 ? conv_small_unrolled_kernel<7, 2, 2, 16, 3> : conv_small_unrolled_kernel<7, 2, 1, 16, 2>;
+    } else if (TN == 4) {
         if (!fits31) return false;
         fn = conv_small_unrolled_kernel<8, 2, 4>;
     } else if (TN == 2) {

@@ -342,3 +342,19 @@ def test_conv1d_k16_wide_short_row_form_with_snake_out_bit_exact(cin, cout, T, B
     got = ops.conv1d(x, w, b, 8, 4, 1, alpha_out=ao)
     assert got.shape == want.shape
     assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+
+
+@pytest.mark.parametrize("cin,cout,T,B,snake_out", [(512, 128, 150, 4, False), (128, 512, 150, 32, False), (1024, 1536, 87, 4, True), (64, 64, 47, 1, False)])
+def test_conv1d_k7_short_row_forms_bit_exact(cin, cout, T, B, snake_out):
+    """k = 7 / stride 1 plain-input layers (Encodec's 512 <-> 128 convolutions around the quantizer, DAC's decoder input with the first
+    DecoderBlock's Snake in the epilogue) on the 16x16x4 kernel: 16 channels per block, 16- and 32-column forms."""
+    rng = np.random.default_rng(cin + cout + T)
+    x = _rand(rng, B, cin, T)
+    w = _rand(rng, cout, cin, 7, scale=1.0 / np.sqrt(cin * 7)); b = _rand(rng, cout, scale=0.1)
+    ao = _alpha(rng, cout) if snake_out else None
+    want = c_oracle.conv1d(x, w, b, 1, 3, 1)
+    if snake_out:
+        want = c_oracle.snake(want, ao)
+    got = ops.conv1d(x, w, b, 1, 3, 1, alpha_out=ao)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
