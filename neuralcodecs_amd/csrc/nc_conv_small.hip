@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmal
             const int nxt = min(cbk + 1, n_blocks - 1);              // (the last block re-reads itself: branch-free, never stored)
             issue(nxt);
             int k = kq, off = off0;
+            if (k >= K) { k -= K; off += W - K * dil; }              // (k = 3: the fourth lane group starts in the next channel row)
             float bv[2][4][TN];
             auto read_group = [&](float (&v)[4][TN]) __attribute__((always_inline)) {
 #pragma unroll
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmal
                     for (int c = 0; c < TN; ++c) v[j][c] = xc[off + c * cts];
                     k += 4; off += 4 * dil;
                     if (k >= K) { k -= K; off += W - K * dil; }
+                    if (k >= K) { k -= K; off += W - K * dil; }      // (second wrap: k = 3 only)
                 }
             };
             read_group(bv[0]);
@@ -281,7 +283,8 @@ void pack_conv_small(const float* dense_w, int Cin, int Cout, int K, std::vector
 }
 
 // k = 7, stride 1 (the 512 <-> 128 convolutions around Encodec's quantizer, DAC's 1024 -> 1536 decoder input): 16 channels per block
-static bool small_k7(int Cin, int K, int stride, int dil) { return K == 7 && stride == 1 && dil == 1 && Cin % 32 == 0; }
+// ... and k = 3, stride 1 (DAC's 1024 -> 1024 encoder output convolution): the same 16-channel blocks, 3 groups each
+static bool small_k7(int Cin, int K, int stride, int dil) { return (K == 7 || K == 3) && stride == 1 && dil == 1 && Cin % 32 == 0; }
 
 bool conv_small_eligible(int Cin, int Cout, int K, int stride, int dil, bool transposed) {
     if (!transposed && Cout >= 64 && small_k7(Cin, K, stride, dil)) return true;
@@ -327,7 +330,8 @@ bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int
     void (*fn)(const ConvSmallArgs) = conv_small_kernel;
     if (k7) {
         if (!fits31) return false;
-        fn = TN == 2 ? conv_small_unrolled_kernel<7, 2, 2, 16, 3> : conv_small_unrolled_kernel<7, 2, 1, 16, 2>;
+        if (K == 7) fn = TN == 2 ? conv_small_unrolled_kernel<7, 2, 2, 16, 3> : conv_small_unrolled_kernel<7, 2, 1, 16, 2>;
+        else fn = TN == 2 ? conv_small_unrolled_kernel<3, 2, 2, 16, 3> : conv_small_unrolled_kernel<3, 2, 1, 16, 2>;
     } else if (TN == 4) {
         if (!fits31) return false;
         fn = conv_small_unrolled_kernel<8, 2, 4>;

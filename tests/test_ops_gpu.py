@@ -346,15 +346,26 @@ def test_conv1d_k16_wide_short_row_form_with_snake_out_bit_exact(cin, cout, T, B
 
 @pytest.mark.parametrize("cin,cout,T,B,snake_out", [(512, 128, 150, 4, False), (128, 512, 150, 32, False), (1024, 1536, 87, 4, True), (64, 64, 47, 1, False)])
 def test_conv1d_k7_short_row_forms_bit_exact(cin, cout, T, B, snake_out):
+    _short_row_stride1(7, cin, cout, T, B, snake_out)
+
+
+@pytest.mark.parametrize("cin,cout,T,B,snake_out", [(1024, 1024, 87, 4, False), (1024, 1024, 87, 32, True), (64, 128, 33, 2, False)])
+def test_conv1d_k3_short_row_forms_bit_exact(cin, cout, T, B, snake_out):
+    """k = 3 / stride 1 (DAC's encoder output convolution, Encoder.cs:45): the fourth lane group of a matrix-core step starts in the next
+    channel row, and a step can wrap twice."""
+    _short_row_stride1(3, cin, cout, T, B, snake_out)
+
+
+def _short_row_stride1(k, cin, cout, T, B, snake_out):
     """k = 7 / stride 1 plain-input layers (Encodec's 512 <-> 128 convolutions around the quantizer, DAC's decoder input with the first
     DecoderBlock's Snake in the epilogue) on the 16x16x4 kernel: 16 channels per block, 16- and 32-column forms."""
     rng = np.random.default_rng(cin + cout + T)
     x = _rand(rng, B, cin, T)
-    w = _rand(rng, cout, cin, 7, scale=1.0 / np.sqrt(cin * 7)); b = _rand(rng, cout, scale=0.1)
+    w = _rand(rng, cout, cin, k, scale=1.0 / np.sqrt(cin * k)); b = _rand(rng, cout, scale=0.1)
     ao = _alpha(rng, cout) if snake_out else None
-    want = c_oracle.conv1d(x, w, b, 1, 3, 1)
+    want = c_oracle.conv1d(x, w, b, 1, k // 2, 1)
     if snake_out:
         want = c_oracle.snake(want, ao)
-    got = ops.conv1d(x, w, b, 1, 3, 1, alpha_out=ao)
+    got = ops.conv1d(x, w, b, 1, k // 2, 1, alpha_out=ao)
     assert got.shape == want.shape
     assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
