@@ -508,7 +508,7 @@ bool conv_in2_available(const ConvLayer& L) {
 static int conv_small_choice(const ConvLayer& L, const ConvIO& io, int B) {
     if (!L.w_small.p || B <= 0) return 0;
     const int in_mode = (io.in_stats ? 1 : 0) | (io.in_elu ? 2 : 0) | (io.in_L > 0 ? 4 : 0) | (io.x2 ? 8 : 0);
-    if (in_mode || io.alpha_in || io.res || io.fuse_k1 || io.epi != 0) return 0;
+    if ((in_mode & ~4) || io.alpha_in || io.res || io.fuse_k1 || io.epi != 0) return 0;   // (the reflect-padded view alone is fine: an index map)
     static const int64_t max_grid = std::getenv("NC_SMALL_MAX_GRID") ? atol(std::getenv("NC_SMALL_MAX_GRID")) : 2048;
     static const int64_t wide_below = std::getenv("NC_SMALL_WIDE_BELOW") ? atol(std::getenv("NC_SMALL_WIDE_BELOW")) : 512;
     const int64_t Tout = L.out_len(io.Tin);
@@ -595,7 +595,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         if ((int64_t)(L.Cin) * io.x_cstride + io.x_len < ((int64_t)1 << 40)) {
             ProfScope ps(prof, stream, L.kclass, L.flops(B, io.Tin),
                          4.0 * ((double)B * L.Cin * io.Tin + (double)B * L.Cout * Tout + (double)L.Cin * L.Cout * L.K));
-            if (launch_conv_small(io.x, io.x_bstride, io.x_cstride, io.x_len, L.w_small.as<float>(), L.has_bias ? L.bias.as<float>() : nullptr, io.alpha_out,
+            if (launch_conv_small(io.x, io.x_bstride, io.x_cstride, io.x_len, (int)io.in_left, (int)io.in_Lz, (int)io.in_L, L.w_small.as<float>(), L.has_bias ? L.bias.as<float>() : nullptr, io.alpha_out,
                                   io.y, io.y_bstride, io.y_cstride, B, L.Cin, L.Cout, L.K, L.stride, L.pad, L.dil, (int)Tout, small_tn, stream))
                 return;
         }

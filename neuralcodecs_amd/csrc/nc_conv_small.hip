@@ -39,6 +39,8 @@ struct ConvSmallArgs {
     const float* x;
     int64_t x_bstride, x_cstride;
     int x_len;
+    int in_left, in_Lz, in_L;   // in_L > 0: x is the UN-padded row of in_L samples and positions run over SConv1d's reflect-padded row of x_len
+                                // samples (SConv1d.cs:258-274): position g reads sample |g - in_left| mirrored at in_Lz - 1, zero past in_L
     const float* wp;     // packed image, see pack_small()
     const float* bias;   // nullable
     const float* alpha_out;   // nullable: Snake of the consuming layer applied to the stored value (Snake1d.cs:40-63)
@@ -88,8 +90,16 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvSmallArgs a) 
         for (int u = 0; u < NS; ++u) {
             const int i = tid + 256 * u;
             const int c = i / W, j = i - c * W;
-            const int ci = cbk * SMALL_CB + c, g = g0 + j;
-            const bool ok = (i < n_slots) & (ci < a.Cin) & (g >= 0) & (g < a.x_len);
+            const int ci = cbk * SMALL_CB + c;
+            int g = g0 + j;
+            bool ok = (i < n_slots) & (ci < a.Cin) & (g >= 0) & (g < a.x_len);
+            if (a.in_L > 0) {
+                int q = g - a.in_left;
+                q = q < 0 ? -q : q;
+                if (q >= a.in_Lz) q = 2 * (a.in_Lz - 1) - q;
+                ok = ok & (q >= 0) & (q < a.in_L);
+                g = q;
+            }
             rx[u] = ok ? xb[(int64_t)ci * a.x_cstride + g] : 0.0f;
         }
     };
@@ -196,8 +206,16 @@ __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmal
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
         const int i = tid + 256 * u;
-        const int c = i / W, j = i - c * W, g = g0 + j;
-        const bool ok = (i < n_slots) & (g >= 0) & (g < a.x_len);
+        const int c = i / W, j = i - c * W;
+        int g = g0 + j;
+        bool ok = (i < n_slots) & (g >= 0) & (g < a.x_len);
+        if (a.in_L > 0) {   // reflect-padded view of an un-padded row
+            int q = g - a.in_left;
+            q = q < 0 ? -q : q;
+            if (q >= a.in_Lz) q = 2 * (a.in_Lz - 1) - q;
+            ok = ok & (q >= 0) & (q < a.in_L);
+            g = q;
+        }
         if (ok) okm |= 1u << u;
         xo[u] = ok ? c * (int)a.x_cstride + g : 0;                   // (host: Cin * x_cstride fits 31 bits)
     }
@@ -302,10 +320,11 @@ int conv_small_max_tn(int Cin, int K, int stride, int dil) {
     return (k16 && SMALL_CB * W32 <= 9 * 256) ? 2 : 1;
 }
 
-bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int x_len, const float* wp, const float* bias, const float* alpha_out, float* y,
+bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int x_len, int in_left, int in_Lz, int in_L, const float* wp, const float* bias, const float* alpha_out, float* y,
                        int64_t y_bstride, int64_t y_cstride, int B, int Cin, int Cout, int K, int stride, int pad, int dil, int Tout, int want_tn, hipStream_t s) {
     ConvSmallArgs a{};
     a.x = x; a.x_bstride = x_bstride; a.x_cstride = x_cstride; a.x_len = x_len; a.wp = wp; a.bias = bias; a.alpha_out = alpha_out;
+    a.in_left = in_left; a.in_Lz = in_Lz; a.in_L = in_L;
     a.y = y; a.y_bstride = y_bstride; a.y_cstride = y_cstride;
     a.Cin = Cin; a.Cout = Cout; a.K = K; a.stride = stride; a.pad = pad; a.dil = dil; a.Tout = Tout;
     a.n_row_tiles = (Cout + 63) / 64;
