@@ -508,7 +508,8 @@ bool conv_in2_available(const ConvLayer& L) {
 static int conv_small_choice(const ConvLayer& L, const ConvIO& io, int B) {
     if (!L.w_small.p || B <= 0) return 0;
     const int in_mode = (io.in_stats ? 1 : 0) | (io.in_elu ? 2 : 0) | (io.in_L > 0 ? 4 : 0) | (io.x2 ? 8 : 0);
-    if ((in_mode & ~4) || io.alpha_in || io.res || io.fuse_k1 || io.epi != 0) return 0;   // (the reflect-padded view alone is fine: an index map)
+    if ((in_mode & 8) || io.alpha_in || io.res || io.fuse_k1 || io.epi != 0) return 0;   // (the reflect-padded view alone is fine: an index map)
+    if ((in_mode & 3) && !conv_small_inm_available(L.Cin, L.K, L.stride, L.dil)) return 0;
     static const int64_t max_grid = std::getenv("NC_SMALL_MAX_GRID") ? atol(std::getenv("NC_SMALL_MAX_GRID")) : 2048;
     static const int64_t wide_below = std::getenv("NC_SMALL_WIDE_BELOW") ? atol(std::getenv("NC_SMALL_WIDE_BELOW")) : 512;
     const int64_t Tout = L.out_len(io.Tin);
@@ -587,7 +588,6 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         }
     }
     if (launch_conv1x1(L, io, B, stream, prof)) return;
-    if (launch_conv3_stream(L, io, B, stream, prof)) return;
     const int64_t Tout = L.out_len(io.Tin);
     if (const int small_tn = io.gn_part ? 0 : conv_small_choice(L, io, B)) {
         // Short rows of a few-clip batch (one-clip SNAC / DAC: the deep down-convolutions over 47 .. 375 frames) and the k = 16 layers
@@ -595,11 +595,13 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         if ((int64_t)(L.Cin) * io.x_cstride + io.x_len < ((int64_t)1 << 40)) {
             ProfScope ps(prof, stream, L.kclass, L.flops(B, io.Tin),
                          4.0 * ((double)B * L.Cin * io.Tin + (double)B * L.Cout * Tout + (double)L.Cin * L.Cout * L.K));
-            if (launch_conv_small(io.x, io.x_bstride, io.x_cstride, io.x_len, (int)io.in_left, (int)io.in_Lz, (int)io.in_L, L.w_small.as<float>(), L.has_bias ? L.bias.as<float>() : nullptr, io.alpha_out,
+            if (launch_conv_small(io.x, io.x_bstride, io.x_cstride, io.x_len, (int)io.in_left, (int)io.in_Lz, (int)io.in_L, io.in_stats, io.in_gamma, io.in_beta,
+                                  io.in_elu ? 1 : 0, L.w_small.as<float>(), L.has_bias ? L.bias.as<float>() : nullptr, io.alpha_out,
                                   io.y, io.y_bstride, io.y_cstride, B, L.Cin, L.Cout, L.K, L.stride, L.pad, L.dil, (int)Tout, small_tn, stream))
                 return;
         }
     }
+    if (launch_conv3_stream(L, io, B, stream, prof)) return;
     const int64_t n_cols_all = L.transposed ? io.Tin + L.Ktaps - 1 : Tout;
     TileChoice tsel{L.cfg, L.w.as<float>(), L.w_phase_stride};
     if (!io.fuse_k1) tsel = choose_tile(L, (int64_t)L.n_phase * B * ((n_cols_all + 255) / 256), false);

@@ -41,6 +41,10 @@ struct ConvSmallArgs {
     int x_len;
     int in_left, in_Lz, in_L;   // in_L > 0: x is the UN-padded row of in_L samples and positions run over SConv1d's reflect-padded row of x_len
                                 // samples (SConv1d.cs:258-274): position g reads sample |g - in_left| mirrored at in_Lz - 1, zero past in_L
+    // Encodec input mode (the unrolled INM instances): the row is a raw conv output with a pending GroupNorm(1,C) -- (mean, rstd) per sample,
+    // (gamma, beta) per channel, NormConv1d.cs:155 -- and / or a pending ELU, applied while the window is written to LDS (the template's
+    // formula: ((x - mu) * rstd) * gamma + beta, then ELU, then the zero extension of the ACTIVATED row)
+    const float* in_stats; const float* in_gamma; const float* in_beta; int in_elu;
     const float* wp;     // packed image, see pack_small()
     const float* bias;   // nullable
     const float* alpha_out;   // nullable: Snake of the consuming layer applied to the stored value (Snake1d.cs:40-63)
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvSmallArgs a) 
 // loads, and drains the whole ring in front of every block barrier (s_waitcnt vmcnt(1): one memory latency per 8 channels -- 48 of
 // them in the 384 -> 768 layer, 98 us).  Here the window loads of block n+1 are followed by exactly GPB ring loads before the barrier
 // that needs them, the wait is vmcnt(GPB), and the weight stream never stops.  Needs n_blocks % NB == 0 (the host checks).
-template <int GPB, int NB, int TN = 1, int CB = SMALL_CB, int NS = (TN == 1 ? 6 : TN == 2 ? 9 : 18)>
+template <int GPB, int NB, int TN = 1, int CB = SMALL_CB, int NS = (TN == 1 ? 6 : TN == 2 ? 9 : 18), bool INM = false>
 __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmallArgs a) {
     constexpr int BNC = 16 * TN;                                      // output columns per workgroup: TN column tiles share every A fragment
     constexpr int PF = GPB * NB;                                      // ring depth = groups per loop iteration
@@ -200,13 +204,24 @@ __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmal
     const int n_blocks = a.Cin / CB;
     const int n_slots = CB * W;
     float rx[NS];
+    // INM: (gamma, beta) of all input channels behind the two window buffers; the sample's (mean, rstd)
+    float2* const Gt = reinterpret_cast<float2*>(xs + 2 * n_slots);
+    float in_mu = 0.0f, in_rs = 1.0f;
+    if constexpr (INM) {
+        if (a.in_stats) {
+            in_mu = a.in_stats[2 * b]; in_rs = a.in_stats[2 * b + 1];
+            for (int i = tid; i < a.Cin; i += 256) Gt[i] = make_float2(a.in_gamma[i], a.in_beta[i]);
+        }
+        __syncthreads();
+    }
     // loop-invariant part of the window reads: slot -> (channel of the block, position), predicate of the position
-    int xo[NS];
+    int xo[NS], cu[INM ? NS : 1];
     unsigned okm = 0;
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
         const int i = tid + 256 * u;
         const int c = i / W, j = i - c * W;
+        if constexpr (INM) cu[u] = min(c, CB - 1);
         int g = g0 + j;
         bool ok = (i < n_slots) & (g >= 0) & (g < a.x_len);
         if (a.in_L > 0) {   // reflect-padded view of an un-padded row
@@ -224,15 +239,23 @@ __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmal
 #pragma unroll
         for (int u = 0; u < NS; ++u) rx[u] = xr[xo[u]];               // branch-free: masked slots read a valid word and are zeroed at the store
     };
-    auto store = [&](float* dst) __attribute__((always_inline)) {
+    auto store = [&](float* dst, int cbk) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
             const int i = tid + 256 * u;
-            if (i < n_slots) dst[i] = ((okm >> u) & 1u) ? rx[u] : 0.0f;
+            float v = rx[u];
+            if constexpr (INM) {
+                if (a.in_stats) {
+                    const float2 gb = Gt[cbk * CB + cu[u]];
+                    v = ((v - in_mu) * in_rs) * gb.x + gb.y;
+                }
+                if (a.in_elu) v = nc_eluf(v);
+            }
+            if (i < n_slots) dst[i] = ((okm >> u) & 1u) ? v : 0.0f;
         }
     };
     issue(0);
-    store(xs);
+    store(xs, 0);
     __syncthreads();
     small_f32x4 acc[TN];
 #pragma unroll
@@ -269,7 +292,7 @@ __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmal
 #pragma unroll
                     for (int c = 0; c < TN; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], bv[g & 1][j][c], acc[c], 0, 0, 0);
             });
-            store(xs + ((cbk + 1) & 1) * n_slots);                    // (after the last block: a dead store into the free buffer)
+            store(xs + ((cbk + 1) & 1) * n_slots, nxt);               // (after the last block: a dead store into the free buffer)
             __syncthreads();
         });
     }
@@ -320,11 +343,18 @@ int conv_small_max_tn(int Cin, int K, int stride, int dil) {
     return (k16 && SMALL_CB * W32 <= 9 * 256) ? 2 : 1;
 }
 
-bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int x_len, int in_left, int in_Lz, int in_L, const float* wp, const float* bias, const float* alpha_out, float* y,
+// true when the input-mode (pending GroupNorm / ELU) instances serve this layer
+bool conv_small_inm_available(int Cin, int K, int stride, int dil) { return K == 3 && small_k7(Cin, K, stride, dil) && Cin <= 1024; }
+
+bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int x_len, int in_left, int in_Lz, int in_L, const float* in_stats,
+                       const float* in_gamma, const float* in_beta, int in_elu, const float* wp, const float* bias, const float* alpha_out, float* y,
                        int64_t y_bstride, int64_t y_cstride, int B, int Cin, int Cout, int K, int stride, int pad, int dil, int Tout, int want_tn, hipStream_t s) {
     ConvSmallArgs a{};
     a.x = x; a.x_bstride = x_bstride; a.x_cstride = x_cstride; a.x_len = x_len; a.wp = wp; a.bias = bias; a.alpha_out = alpha_out;
     a.in_left = in_left; a.in_Lz = in_Lz; a.in_L = in_L;
+    a.in_stats = in_stats; a.in_gamma = in_gamma; a.in_beta = in_beta; a.in_elu = in_elu;
+    const bool inm = in_stats != nullptr || in_elu != 0;
+    if (inm && !conv_small_inm_available(Cin, K, stride, dil)) return false;
     a.y = y; a.y_bstride = y_bstride; a.y_cstride = y_cstride;
     a.Cin = Cin; a.Cout = Cout; a.K = K; a.stride = stride; a.pad = pad; a.dil = dil; a.Tout = Tout;
     a.n_row_tiles = (Cout + 63) / 64;
@@ -339,7 +369,7 @@ bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int
     a.n_t_tiles = (Tout + 16 * TN - 1) / (16 * TN);
     a.W = (16 * TN - 1) * stride + (K - 1) * dil + 1;
     const bool k7 = small_k7(Cin, K, stride, dil);
-    const size_t lds = (size_t)2 * (k7 ? 16 : SMALL_CB) * a.W * sizeof(float);
+    const size_t lds = (size_t)2 * (k7 ? 16 : SMALL_CB) * a.W * sizeof(float) + (inm ? (size_t)Cin * sizeof(float2) : 0);
     const int64_t grid = (int64_t)B * a.n_t_tiles * a.n_row_tiles;
     if (grid <= 0 || grid > 0x7fffffff) return false;
     // the straight-line form where the block count is a multiple of its unroll; the rolled kernel otherwise
@@ -350,6 +380,7 @@ bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int
     if (k7) {
         if (!fits31) return false;
         if (K == 7) fn = TN == 2 ? conv_small_unrolled_kernel<7, 2, 2, 16, 3> : conv_small_unrolled_kernel<7, 2, 1, 16, 2>;
+        else if (inm) fn = TN == 2 ? conv_small_unrolled_kernel<3, 2, 2, 16, 3, true> : conv_small_unrolled_kernel<3, 2, 1, 16, 2, true>;
         else fn = TN == 2 ? conv_small_unrolled_kernel<3, 2, 2, 16, 3> : conv_small_unrolled_kernel<3, 2, 1, 16, 2>;
     } else if (TN == 4) {
         if (!fits31) return false;
