@@ -195,9 +195,11 @@ bool launch_conv_thin_inm(const ThinInmArgs& a, int B, int Cout, hipStream_t s);
 bool conv_small_eligible(int Cin, int Cout, int K, int stride, int dil, bool transposed);
 void pack_conv_small(const float* dense_w, int Cin, int Cout, int K, std::vector<float>& out);
 int conv_small_max_tn(int Cin, int K, int stride, int dil);
+struct ConvSmallGn { double* part; int nrb, ncb; unsigned* count; float* stats; double n; };   // GroupNorm sums from the short-row kernel's epilogue
 bool conv_small_inm_available(int Cin, int K, int stride, int dil);
+bool conv_small_gn_available(int Cin, int K, int stride, int dil, bool inm);
 bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int x_len, int in_left, int in_Lz, int in_L, const float* in_stats,
-                       const float* in_gamma, const float* in_beta, int in_elu, const float* wp, const float* bias, const float* alpha_out, float* y,
+                       const float* in_gamma, const float* in_beta, int in_elu, const ConvSmallGn* gn, const float* wp, const float* bias, const float* alpha_out, float* y,
                        int64_t y_bstride, int64_t y_cstride, int B, int Cin, int Cout, int K, int stride, int pad, int dil, int Tout, int want_tn, hipStream_t s);
 
 TileCfg pick_tile(int Cout, int Ktaps);

@@ -528,7 +528,8 @@ bool conv_gn_fusable(const ConvLayer& L, const ConvIO& io, int B) {
     if (off || io.res || io.alpha_out || io.alpha_in || io.epi || io.fuse_k1 || L.n_phase != 1 || (L.sub_stride && !L.sub_shift)) return false;
     if (L.w_thin.p) return thin_inm_layer(L) && io.in_L > 0;   // (the input-mode head kernel emits its sums; the plain head does not)
     if (L.w_stem.p || L.w_skinny.p) return false;
-    if (conv_small_choice(L, io, B)) return false;   // (bias-only epilogue: the caller runs the stand-alone statistics pass)
+    if (conv_small_choice(L, io, B))   // (its 32-column instances reduce the blocks from an LDS copy of the tile; the others: stand-alone pass)
+        return conv_small_gn_available(L.Cin, L.K, L.stride, L.dil, io.in_stats != nullptr || io.in_elu);
     return true;
 }
 
@@ -589,14 +590,16 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     }
     if (launch_conv1x1(L, io, B, stream, prof)) return;
     const int64_t Tout = L.out_len(io.Tin);
-    if (const int small_tn = io.gn_part ? 0 : conv_small_choice(L, io, B)) {
+    const bool small_gn_ok = !io.gn_part || conv_small_gn_available(L.Cin, L.K, L.stride, L.dil, io.in_stats != nullptr || io.in_elu);
+    if (const int small_tn = small_gn_ok ? conv_small_choice(L, io, B) : 0) {
         // Short rows of a few-clip batch (one-clip SNAC / DAC: the deep down-convolutions over 47 .. 375 frames) and the k = 16 layers
         // whose template grid leaves most of the chip to lone workgroups: the 16x16x4 kernel of nc_conv_small.hip
         if ((int64_t)(L.Cin) * io.x_cstride + io.x_len < ((int64_t)1 << 40)) {
             ProfScope ps(prof, stream, L.kclass, L.flops(B, io.Tin),
                          4.0 * ((double)B * L.Cin * io.Tin + (double)B * L.Cout * Tout + (double)L.Cin * L.Cout * L.K));
+            const ConvSmallGn sgn{io.gn_part, io.gn_nrb, io.gn_ncb, io.gn_count, io.gn_stats, io.gn_n};
             if (launch_conv_small(io.x, io.x_bstride, io.x_cstride, io.x_len, (int)io.in_left, (int)io.in_Lz, (int)io.in_L, io.in_stats, io.in_gamma, io.in_beta,
-                                  io.in_elu ? 1 : 0, L.w_small.as<float>(), L.has_bias ? L.bias.as<float>() : nullptr, io.alpha_out,
+                                  io.in_elu ? 1 : 0, &sgn, L.w_small.as<float>(), L.has_bias ? L.bias.as<float>() : nullptr, io.alpha_out,
                                   io.y, io.y_bstride, io.y_cstride, B, L.Cin, L.Cout, L.K, L.stride, L.pad, L.dil, (int)Tout, small_tn, stream))
                 return;
         }

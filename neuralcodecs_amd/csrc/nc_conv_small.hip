@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "nc_conv.h"
+#include "nc_gn.h"
 #include "nc_math.h"
 
 namespace nc {
@@ -45,6 +46,9 @@ struct ConvSmallArgs {
     // (gamma, beta) per channel, NormConv1d.cs:155 -- and / or a pending ELU, applied while the window is written to LDS (the template's
     // formula: ((x - mu) * rstd) * gamma + beta, then ELU, then the zero extension of the ACTIVATED row)
     const float* in_stats; const float* in_gamma; const float* in_beta; int in_elu;
+    // GroupNorm block sums of the output (the GN instances, 32-column tiles): [B][gn_nrb][gn_ncb][2] partial sums in the canonical order
+    // of nc_gn.h, finished in the launch by the sample's last workgroup when gn_count is given
+    double* gn_part; int gn_nrb, gn_ncb; unsigned* gn_count; float* gn_stats; double gn_n;
     const float* wp;     // packed image, see pack_small()
     const float* bias;   // nullable
     const float* alpha_out;   // nullable: Snake of the consuming layer applied to the stored value (Snake1d.cs:40-63)
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvSmallArgs a) 
 // loads, and drains the whole ring in front of every block barrier (s_waitcnt vmcnt(1): one memory latency per 8 channels -- 48 of
 // them in the 384 -> 768 layer, 98 us).  Here the window loads of block n+1 are followed by exactly GPB ring loads before the barrier
 // that needs them, the wait is vmcnt(GPB), and the weight stream never stops.  Needs n_blocks % NB == 0 (the host checks).
-template <int GPB, int NB, int TN = 1, int CB = SMALL_CB, int NS = (TN == 1 ? 6 : TN == 2 ? 9 : 18), bool INM = false>
+template <int GPB, int NB, int TN = 1, int CB = SMALL_CB, int NS = (TN == 1 ? 6 : TN == 2 ? 9 : 18), bool INM = false, bool GN = false>
 __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmallArgs a) {
     constexpr int BNC = 16 * TN;                                      // output columns per workgroup: TN column tiles share every A fragment
     constexpr int PF = GPB * NB;                                      // ring depth = groups per loop iteration
@@ -296,6 +300,42 @@ __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmal
             __syncthreads();
         });
     }
+    if constexpr (GN) {
+        static_assert(!GN || TN == 2, "the GroupNorm epilogue reduces whole 32x32 blocks: 32-column tiles");
+        // The 64 x 32 tile meets in LDS (the window buffers are free after the last barrier), and waves 0 / 1 re-read its two 32 x 32
+        // blocks in the accumulator layout of v_mfma_f32_32x32x2_f32 -- lane = slot 32*h + c, register r = row (r&3) + 8*(r>>2) + 4*h --
+        // i.e. the canonical order of nc_gn.h: the same sums, bit for bit, as the template's register reduction.
+        float* const tile = xs;                                       // [64][33]
+#pragma unroll
+        for (int c = 0; c < TN; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lr = 16 * wave + 4 * kq + r, row = 64 * rt + lr;
+                tile[lr * 33 + c * 16 + col] = acc[c][r] + ((a.bias && row < a.Cout) ? a.bias[row] : 0.0f);
+            }
+        __syncthreads();
+        if (wave < 2) {
+            const int h = lane >> 5, cc = lane & 31;
+            const int t = tt * 32 + cc;
+            float vv[16];
+            unsigned okm16 = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+                vv[r] = tile[lr * 33 + cc];
+                if ((64 * rt + lr < a.Cout) & (t < a.Tout)) okm16 |= 1u << r;
+            }
+            double s1, s2;
+            nc_gn_slot_sums<false>(vv, okm16, s1, s2);
+            nc_gn_butterfly(s1, s2);
+            const int rbk = 2 * rt + wave, cbk = tt;
+            if (lane == 0 && rbk < a.gn_nrb && cbk < a.gn_ncb)
+                nc_gn_store_partial(a.gn_part + (((int64_t)b * a.gn_nrb + rbk) * a.gn_ncb + cbk) * 2, s1, s2);
+        }
+        if (a.gn_count != nullptr)
+            nc_gn_arrive_and_finish(a.gn_part + (int64_t)b * a.gn_nrb * a.gn_ncb * 2, a.gn_count + b, a.gn_stats + 2 * b, a.gn_nrb * a.gn_ncb,
+                                    (unsigned)(a.n_row_tiles * a.n_t_tiles), a.gn_n);
+    }
 #pragma unroll
     for (int c = 0; c < TN; ++c) {
         const int t = tt * BNC + c * 16 + col;
@@ -343,16 +383,29 @@ int conv_small_max_tn(int Cin, int K, int stride, int dil) {
     return (k16 && SMALL_CB * W32 <= 9 * 256) ? 2 : 1;
 }
 
+// true when a GroupNorm-sum epilogue instance serves this layer (32-column tiles; inm: the input carries a pending GroupNorm / ELU)
+bool conv_small_gn_available(int Cin, int K, int stride, int dil, bool inm) {
+    if (conv_small_max_tn(Cin, K, stride, dil) < 2) return false;
+    if (small_k7(Cin, K, stride, dil)) return K == 3 ? Cin <= 1024 : !inm;
+    return !inm;   // k = 16
+}
+
 // true when the input-mode (pending GroupNorm / ELU) instances serve this layer
 bool conv_small_inm_available(int Cin, int K, int stride, int dil) { return K == 3 && small_k7(Cin, K, stride, dil) && Cin <= 1024; }
 
 bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int x_len, int in_left, int in_Lz, int in_L, const float* in_stats,
-                       const float* in_gamma, const float* in_beta, int in_elu, const float* wp, const float* bias, const float* alpha_out, float* y,
+                       const float* in_gamma, const float* in_beta, int in_elu, const ConvSmallGn* gn, const float* wp, const float* bias, const float* alpha_out, float* y,
                        int64_t y_bstride, int64_t y_cstride, int B, int Cin, int Cout, int K, int stride, int pad, int dil, int Tout, int want_tn, hipStream_t s) {
     ConvSmallArgs a{};
     a.x = x; a.x_bstride = x_bstride; a.x_cstride = x_cstride; a.x_len = x_len; a.wp = wp; a.bias = bias; a.alpha_out = alpha_out;
     a.in_left = in_left; a.in_Lz = in_Lz; a.in_L = in_L;
     a.in_stats = in_stats; a.in_gamma = in_gamma; a.in_beta = in_beta; a.in_elu = in_elu;
+    if (gn && gn->part) {
+        if (alpha_out || conv_small_max_tn(Cin, K, stride, dil) < 2) return false;
+        a.gn_part = gn->part; a.gn_nrb = gn->nrb; a.gn_ncb = gn->ncb; a.gn_count = gn->count; a.gn_stats = gn->stats; a.gn_n = gn->n;
+        want_tn = 2;
+    }
+    const bool with_gn = a.gn_part != nullptr;
     const bool inm = in_stats != nullptr || in_elu != 0;
     if (inm && !conv_small_inm_available(Cin, K, stride, dil)) return false;
     a.y = y; a.y_bstride = y_bstride; a.y_cstride = y_cstride;
@@ -365,11 +418,12 @@ bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int
     static const int tn_env = std::getenv("NC_SMALL_TN") ? atoi(std::getenv("NC_SMALL_TN")) : 0;
     const int W64 = 63 * stride + (K - 1) * dil + 1;
     const bool tn2_fits = conv_small_max_tn(Cin, K, stride, dil) >= 2, tn4_fits = tn2_fits && SMALL_CB * W64 <= 18 * 256;
-    const int TN = (tn4_fits && tn_env == 4 && !small_k7(Cin, K, stride, dil)) ? 4 : (tn2_fits && (tn_env == 2 || (tn_env == 0 && want_tn >= 2))) ? 2 : 1;
+    const int TN = with_gn ? 2 : (tn4_fits && tn_env == 4 && !small_k7(Cin, K, stride, dil)) ? 4 : (tn2_fits && (tn_env == 2 || (tn_env == 0 && want_tn >= 2))) ? 2 : 1;
     a.n_t_tiles = (Tout + 16 * TN - 1) / (16 * TN);
     a.W = (16 * TN - 1) * stride + (K - 1) * dil + 1;
     const bool k7 = small_k7(Cin, K, stride, dil);
-    const size_t lds = (size_t)2 * (k7 ? 16 : SMALL_CB) * a.W * sizeof(float) + (inm ? (size_t)Cin * sizeof(float2) : 0);
+    size_t lds = (size_t)2 * (k7 ? 16 : SMALL_CB) * a.W * sizeof(float) + (inm ? (size_t)Cin * sizeof(float2) : 0);
+    if (with_gn) lds = std::max(lds, (size_t)64 * 33 * sizeof(float));
     const int64_t grid = (int64_t)B * a.n_t_tiles * a.n_row_tiles;
     if (grid <= 0 || grid > 0x7fffffff) return false;
     // the straight-line form where the block count is a multiple of its unroll; the rolled kernel otherwise
@@ -379,15 +433,19 @@ bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int
     void (*fn)(const ConvSmallArgs) = conv_small_kernel;
     if (k7) {
         if (!fits31) return false;
-        if (K == 7) fn = TN == 2 ? conv_small_unrolled_kernel<7, 2, 2, 16, 3> : conv_small_unrolled_kernel<7, 2, 1, 16, 2>;
+        if (with_gn) {
+            if (K == 7 && !inm) fn = conv_small_unrolled_kernel<7, 2, 2, 16, 3, false, true>;
+            else if (K == 3) fn = conv_small_unrolled_kernel<3, 2, 2, 16, 3, true, true>;   // (the INM instance also runs plain rows: flags at run time)
+            else return false;
+        } else if (K == 7) fn = TN == 2 ? conv_small_unrolled_kernel<7, 2, 2, 16, 3> : conv_small_unrolled_kernel<7, 2, 1, 16, 2>;
         else if (inm) fn = TN == 2 ? conv_small_unrolled_kernel<3, 2, 2, 16, 3, true> : conv_small_unrolled_kernel<3, 2, 1, 16, 2, true>;
         else fn = TN == 2 ? conv_small_unrolled_kernel<3, 2, 2, 16, 3> : conv_small_unrolled_kernel<3, 2, 1, 16, 2>;
     } else if (TN == 4) {
         if (!fits31) return false;
         fn = conv_small_unrolled_kernel<8, 2, 4>;
     } else if (TN == 2) {
-        if (!fits31) return false;
-        fn = conv_small_unrolled_kernel<8, 2, 2>;
+        if (!fits31 || (with_gn && inm)) return false;
+        fn = with_gn ? conv_small_unrolled_kernel<8, 2, 2, SMALL_CB, 9, false, true> : conv_small_unrolled_kernel<8, 2, 2>;
     } else if (!rolled_only && fits31 && Cin % SMALL_CB == 0) {
         if (gpb == 8 && n_blocks % 2 == 0) fn = conv_small_unrolled_kernel<8, 2>;
         else if (gpb == 4 && n_blocks % 4 == 0) fn = conv_small_unrolled_kernel<4, 4>;
