@@ -10,7 +10,11 @@
 //   * the input window of the 16 columns (15*stride + (K-1)*dil + 1 samples per channel) is staged through LDS, SMALL_CB channels per
 //     block, double-buffered, one barrier per block; zero padding by predicate;
 //   * per output: fmaf over kk = ci*K + k ascending from +0 (four kk per instruction), then + bias -- the canonical chain.
-// Plain input, bias-only epilogue (the callers' Snake arrives applied by the producer).
+// Forms: the rolled kernel (any eligible layer, 16-column tiles); the straight-line kernel `conv_small_unrolled_kernel<GPB, NB, TN, CB,
+// NS, INM, GN>` -- 16- or 32-column tiles (TN), k = 16 / 10 / 8 / 6 / 4 strided layers with 8 channels per block, k = 7 / k = 3
+// stride-1 layers with 16; INM: Encodec's pending GroupNorm + ELU applied while the window is written to LDS; GN: GroupNorm block
+// sums of the output in the canonical order, finished in the launch.  The input may be SConv1d's reflect-padded view of an un-padded
+// row (an index map); the epilogue adds the bias and, when asked, the consumer's Snake.
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
