@@ -506,28 +506,29 @@ __global__ __launch_bounds__(256) void euclid_vq_kernel(float* __restrict__ resi
 constexpr int EM_F = 32, EM_MAXD = 128;
 typedef float em_f32x16 __attribute__((ext_vector_type(16)));
 typedef float em_f32x4 __attribute__((ext_vector_type(4)));
-template <int DD>
-__global__ __launch_bounds__(256) void euclid_rvq_mfma_kernel(const float* __restrict__ residual, const float* const* __restrict__ cbT_ptrs,
+// NWV wavefronts share a stage's codebook scan (N / NWV codes each: 8 waves halve the scan of a workgroup that sits alone on its CU)
+template <int DD, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void euclid_rvq_mfma_kernel(const float* __restrict__ residual, const float* const* __restrict__ cbT_ptrs,
                                                               const float* const* __restrict__ cb_ptrs, const float* const* __restrict__ c2_ptrs,
                                                               int n_q, int N, int B, int64_t T, int64_t* __restrict__ codes,
                                                               int64_t codes_bstride) {
     constexpr int D = DD;
     __shared__ float es[EM_MAXD][EM_F];   // residual block [d][frame]: lane (frame, k half) of a B fragment reads es[2kp + half][frame]
     __shared__ float e2s[EM_F];
-    __shared__ float bd[4][EM_F];
-    __shared__ int bi[4][EM_F];
+    __shared__ float bd[NWV][EM_F];
+    __shared__ int bi[NWV][EM_F];
     __shared__ int win[EM_F];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int64_t f0 = (int64_t)blockIdx.x * EM_F, total = (int64_t)B * T;
-    for (int i = tid; i < EM_F * D; i += 256) {
+    for (int i = tid; i < EM_F * D; i += 64 * NWV) {
         const int d = i >> 5, f = i & 31;
         const int64_t fr = f0 + f;
         float v = 0.0f;
         if (fr < total) { const int64_t b = fr / T, t = fr - b * T; v = residual[(b * D + d) * T + t]; }
         es[d][f] = v;
     }
-    const int npw = N >> 2;                  // codes per wave (a multiple of 32)
+    const int npw = N / NWV;                 // codes per wave (a multiple of 128)
     for (int q = 0; q < n_q; ++q) {
         const float* __restrict__ cbT = cbT_ptrs[q];
         const float* __restrict__ cb = cb_ptrs[q];
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(256) void euclid_rvq_mfma_kernel(const float* __res
         if (tid < EM_F) {
             float d0 = bd[0][tid];
             int i0 = bi[0][tid];
-            for (int w = 1; w < 4; ++w)
+            for (int w = 1; w < NWV; ++w)
                 if (bd[w][tid] < d0 || (bd[w][tid] == d0 && bi[w][tid] < i0)) { d0 = bd[w][tid]; i0 = bi[w][tid]; }
             if (i0 == 0x7fffffff) i0 = 0;
             win[tid] = i0;
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(256) void euclid_rvq_mfma_kernel(const float* __res
             if (fr < total) { const int64_t b = fr / T, t = fr - b * T; codes[b * codes_bstride + (int64_t)q * T + t] = (int64_t)i0; }
         }
         __syncthreads();
-        for (int i = tid; i < EM_F * D; i += 256) {       // residual -= embed[idx]: 8 threads per frame walk its code vector
+        for (int i = tid; i < EM_F * D; i += 64 * NWV) {  // residual -= embed[idx]: 8 threads per frame walk its code vector
             const int f = i / D, d = i - f * D;
             es[d][f] = es[d][f] - ((__attribute__((address_space(1))) const float*)cb)[(int64_t)win[f] * D + d];
         }
@@ -1313,6 +1314,14 @@ void EncodecModel::encode_batch(const float* x, int N, int64_t L, int64_t Tz, in
     const int Nc = cfg.codebook_size;
     if (!no_mfma_vq && Nc % 512 == 0 && D == 128) {
         // all stages in one launch, cross terms on the matrix cores (the residual block stays in LDS between the stages)
+        // 8 wavefronts per workgroup where the grid leaves the workgroups alone on their CUs and a wave still gets whole 128-code passes
+        static const bool rvq4 = std::getenv("NC_RVQ_4WAVES") && std::getenv("NC_RVQ_4WAVES")[0] == '1';
+        const bool wide = !rvq4 && Nc % 1024 == 0 && (total + EM_F - 1) / EM_F <= 256;
+        if (wide)
+            hipLaunchKernelGGL((euclid_rvq_mfma_kernel<128, 8>), dim3((unsigned)((total + EM_F - 1) / EM_F)), dim3(512), 0, stream, residual,
+                               book_ptrsT.as<const float*>(), book_ptrs.as<const float*>(), book_ptrs2.as<const float*>(), n_q, Nc, N, Tz, codes,
+                               (int64_t)n_q * Tz);
+        else
         hipLaunchKernelGGL(euclid_rvq_mfma_kernel<128>, dim3((unsigned)((total + EM_F - 1) / EM_F)), dim3(256), 0, stream, residual,
                            book_ptrsT.as<const float*>(), book_ptrs.as<const float*>(), book_ptrs2.as<const float*>(), n_q, Nc, N, Tz, codes,
                            (int64_t)n_q * Tz);
