@@ -79,33 +79,44 @@ __global__ __launch_bounds__(256) void pad_act_kernel(ActView a, ActView b2, int
 // Stand-alone GroupNorm block sums in the canonical order of nc_gn.h, for the outputs whose producing kernel cannot emit them from
 // its epilogue (the streaming thin-output head, per-phase transposed launches): one wavefront per 32x32 block of the (rows = c*sub +
 // t % sub, columns = t / sub) view of x [B][C][T]; lane (h, c) adds its 16 rows of column c, then the butterfly.
+constexpr int GN_CBW = 4;   // column blocks per wavefront: their 64 row reads are all in flight before the first sum (memory-level parallelism)
 __global__ __launch_bounds__(256) void gn_block_kernel(const float* __restrict__ x, double* __restrict__ part, int64_t B, int C, int64_t T, int sub,
                                                        int nrb, int ncb) {
     const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
-    const int64_t total = B * nrb * ncb;
-    const int64_t bi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (bi >= total) return;
-    const int64_t b = bi / ((int64_t)nrb * ncb), rem = bi - b * nrb * ncb;
-    const int rb = (int)(rem / ncb), cb = (int)(rem - (int64_t)rb * ncb);
+    const int ncg = (ncb + GN_CBW - 1) / GN_CBW;                      // groups of column blocks per row block
+    const int64_t total = B * nrb * ncg;
+    const int64_t gi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gi >= total) return;
+    const int64_t b = gi / ((int64_t)nrb * ncg), rem = gi - b * nrb * ncg;
+    const int rb = (int)(rem / ncg), cg = (int)(rem - (int64_t)rb * ncg);
     const float* xb = x + b * C * T;
-    const int64_t q = (int64_t)cb * 32 + c;
-    float v[16];
-    unsigned okm = 0;
+    float v[GN_CBW][16];
+    unsigned okm[GN_CBW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int R = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int co = R / sub;
-        const int64_t t = q * sub + (R - co * sub);
-        const bool ok = co < C && t < T;
-        v[r] = ok ? xb[(int64_t)co * T + t] : 0.0f;
-        if (ok) okm |= 1u << r;
+    for (int u = 0; u < GN_CBW; ++u) {
+        const int64_t q = (int64_t)(cg * GN_CBW + u) * 32 + c;
+        okm[u] = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int R = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int co = sub == 1 ? R : R / sub;
+            const int64_t t = sub == 1 ? q : q * sub + (R - co * sub);
+            const bool ok = co < C && t < T;
+            v[u][r] = xb[(int64_t)min(co, C - 1) * T + min(t, T - 1)];   // branch-free: clamped address, value masked in the sum
+            if (ok) okm[u] |= 1u << r;
+        }
     }
-    double s1, s2;
-    nc_gn_slot_sums<false>(v, okm, s1, s2);
-    nc_gn_butterfly(s1, s2);
-    if (lane == 0) {
-        part[2 * bi] = s1;
-        part[2 * bi + 1] = s2;
+#pragma unroll
+    for (int u = 0; u < GN_CBW; ++u) {
+        const int cb = cg * GN_CBW + u;
+        double s1, s2;
+        nc_gn_slot_sums<false>(v[u], okm[u], s1, s2);
+        nc_gn_butterfly(s1, s2);
+        if (lane == 0 && cb < ncb) {
+            const int64_t bi = (b * nrb + rb) * ncb + cb;
+            part[2 * bi] = s1;
+            part[2 * bi + 1] = s2;
+        }
     }
 }
 // one wavefront per sample: the n block sums of the sample by 64 strided slots (slot i: idx = i, i+64, ... ascending) + butterfly
@@ -961,8 +972,8 @@ const float* EncodecModel::gn_end(const GnJob& j, const float* raw, int N, int C
     const int64_t n = (int64_t)j.nrb * j.ncb;
     ProfScope ps(&prof, stream, NC_KC_NORM, 3.0 * N * C * (double)L, j.fused ? 16.0 * N * (double)n : 4.0 * N * C * (double)L);
     if (!j.fused)
-        hipLaunchKernelGGL(gn_block_kernel, dim3((unsigned)(((int64_t)N * n + 3) / 4)), dim3(256), 0, stream, raw, j.part, (int64_t)N, C, L, j.sub, j.nrb,
-                           j.ncb);
+        hipLaunchKernelGGL(gn_block_kernel, dim3((unsigned)(((int64_t)N * j.nrb * ((j.ncb + GN_CBW - 1) / GN_CBW) + 3) / 4)), dim3(256), 0, stream, raw, j.part,
+                           (int64_t)N, C, L, j.sub, j.nrb, j.ncb);
     hipLaunchKernelGGL(gn_final_kernel, dim3((unsigned)N), dim3(64), 0, stream, j.part, j.stats, n, (double)C * (double)L);
     NC_HIP(hipGetLastError());
     return j.stats;
@@ -1314,9 +1325,10 @@ void EncodecModel::encode_batch(const float* x, int N, int64_t L, int64_t Tz, in
     const int Nc = cfg.codebook_size;
     if (!no_mfma_vq && Nc % 512 == 0 && D == 128) {
         // all stages in one launch, cross terms on the matrix cores (the residual block stays in LDS between the stages)
-        // 8 wavefronts per workgroup where the grid leaves the workgroups alone on their CUs and a wave still gets whole 128-code passes
-        static const bool rvq4 = std::getenv("NC_RVQ_4WAVES") && std::getenv("NC_RVQ_4WAVES")[0] == '1';
-        const bool wide = !rvq4 && Nc % 1024 == 0 && (total + EM_F - 1) / EM_F <= 256;
+        // (NC_RVQ_8WAVES=1: 8 wavefronts per workgroup, 128 codes each -- measured the same 236 us on C3's 150-workgroup grid as the
+        // 4-wave form: the stage is bound by its serial phases and the codebook stream, not by the matrix-core chain)
+        static const bool rvq8 = std::getenv("NC_RVQ_8WAVES") && std::getenv("NC_RVQ_8WAVES")[0] == '1';
+        const bool wide = rvq8 && Nc % 1024 == 0 && (total + EM_F - 1) / EM_F <= 256;
         if (wide)
             hipLaunchKernelGGL((euclid_rvq_mfma_kernel<128, 8>), dim3((unsigned)((total + EM_F - 1) / EM_F)), dim3(512), 0, stream, residual,
                                book_ptrsT.as<const float*>(), book_ptrs.as<const float*>(), book_ptrs2.as<const float*>(), n_q, Nc, N, Tz, codes,
