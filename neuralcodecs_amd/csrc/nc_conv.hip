@@ -513,6 +513,10 @@ static int conv_small_choice(const ConvLayer& L, const ConvIO& io, int B) {
     static const int64_t max_grid = std::getenv("NC_SMALL_MAX_GRID") ? atol(std::getenv("NC_SMALL_MAX_GRID")) : 2048;
     static const int64_t wide_below = std::getenv("NC_SMALL_WIDE_BELOW") ? atol(std::getenv("NC_SMALL_WIDE_BELOW")) : 512;
     const int64_t Tout = L.out_len(io.Tin);
+    if (L.K == 1) {   // wide pointwise GEMMs over few columns (the chunked LSTM input projections): 32-column form only
+        static const int64_t k1_cols = std::getenv("NC_SMALL_K1_COLS") ? atol(std::getenv("NC_SMALL_K1_COLS")) : 4096;
+        return (!io.gn_part && (int64_t)B * Tout <= k1_cols) ? 2 : 0;
+    }
     const int64_t grid16 = (int64_t)B * ((Tout + 15) / 16) * ((L.Cout + 63) / 64);
     if (grid16 <= max_grid) return 1;
     const int64_t template_grid = (int64_t)((L.rows() + L.cfg.BM() - 1) / L.cfg.BM()) * (((int64_t)B * Tout + 255) / 256);
@@ -588,7 +592,6 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
                 return;
         }
     }
-    if (launch_conv1x1(L, io, B, stream, prof)) return;
     const int64_t Tout = L.out_len(io.Tin);
     const bool small_gn_ok = !io.gn_part || conv_small_gn_available(L.Cin, L.K, L.stride, L.dil, io.in_stats != nullptr || io.in_elu);
     if (const int small_tn = small_gn_ok ? conv_small_choice(L, io, B) : 0) {
@@ -604,6 +607,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
                 return;
         }
     }
+    if (launch_conv1x1(L, io, B, stream, prof)) return;
     if (launch_conv3_stream(L, io, B, stream, prof)) return;
     const int64_t n_cols_all = L.transposed ? io.Tin + L.Ktaps - 1 : Tout;
     TileChoice tsel{L.cfg, L.w.as<float>(), L.w_phase_stride};

@@ -277,13 +277,15 @@ __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmal
             const int nxt = min(cbk + 1, n_blocks - 1);              // (the last block re-reads itself: branch-free, never stored)
             issue(nxt);
             int k = kq, off = off0;
-            if (k >= K) { k -= K; off += W - K * dil; }              // (k = 3: the fourth lane group starts in the next channel row)
+            if (K == 1) { k = 0; off = col * a.stride + kq * W; }    // (pointwise: lane group kq starts in channel row kq)
+            else if (k >= K) { k -= K; off += W - K * dil; }         // (k = 3: the fourth lane group starts in the next channel row)
             float bv[2][4][TN];
             auto read_group = [&](float (&v)[4][TN]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
 #pragma unroll
                     for (int c = 0; c < TN; ++c) v[j][c] = xc[off + c * cts];
+                    if (K == 1) { off += 4 * W; continue; }          // pointwise: every reduction index is its own channel row
                     k += 4; off += 4 * dil;
                     if (k >= K) { k -= K; off += W - K * dil; }
                     if (k >= K) { k -= K; off += W - K * dil; }      // (second wrap: k = 3 only)
@@ -369,9 +371,13 @@ void pack_conv_small(const float* dense_w, int Cin, int Cout, int K, std::vector
 
 // k = 7, stride 1 (the 512 <-> 128 convolutions around Encodec's quantizer, DAC's 1024 -> 1536 decoder input): 16 channels per block
 // ... and k = 3, stride 1 (DAC's 1024 -> 1024 encoder output convolution): the same 16-channel blocks, 3 groups each
+// ... and the wide pointwise GEMMs over few columns (the chunked LSTM input projections, 512 -> 2048 over 44 steps x 32 rows): 64
+// channels per block
+static bool small_k1(int Cin, int Cout, int K, int stride) { return K == 1 && stride == 1 && Cin % 256 == 0 && Cout >= 1024; }
 static bool small_k7(int Cin, int K, int stride, int dil) { return (K == 7 || K == 3) && stride == 1 && dil == 1 && Cin % 32 == 0; }
 
 bool conv_small_eligible(int Cin, int Cout, int K, int stride, int dil, bool transposed) {
+    if (!transposed && small_k1(Cin, Cout, K, stride)) return true;
     if (!transposed && Cout >= 64 && small_k7(Cin, K, stride, dil)) return true;
     if (transposed || K < 4 || stride < 2 || Cout < 64) return false;
     if ((Cin * K) % 16 != 0 || (SMALL_CB * K) % 16 != 0 || Cin % SMALL_CB != 0) return false;
@@ -381,6 +387,7 @@ bool conv_small_eligible(int Cin, int Cout, int K, int stride, int dil, bool tra
 
 // widest column tile (in 16-column units) the instantiated kernels offer for this layer
 int conv_small_max_tn(int Cin, int K, int stride, int dil) {
+    if (K == 1 && stride == 1 && Cin % 256 == 0) return 2;
     if (small_k7(Cin, K, stride, dil)) return 2;
     const int W32 = 31 * stride + (K - 1) * dil + 1;
     const bool k16 = K * SMALL_CB / 16 == 8 && Cin % SMALL_CB == 0 && (Cin / SMALL_CB) % 2 == 0;
@@ -425,8 +432,8 @@ bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int
     const int TN = with_gn ? 2 : (tn4_fits && tn_env == 4 && !small_k7(Cin, K, stride, dil)) ? 4 : (tn2_fits && (tn_env == 2 || (tn_env == 0 && want_tn >= 2))) ? 2 : 1;
     a.n_t_tiles = (Tout + 16 * TN - 1) / (16 * TN);
     a.W = (16 * TN - 1) * stride + (K - 1) * dil + 1;
-    const bool k7 = small_k7(Cin, K, stride, dil);
-    size_t lds = (size_t)2 * (k7 ? 16 : SMALL_CB) * a.W * sizeof(float) + (inm ? (size_t)Cin * sizeof(float2) : 0);
+    const bool k7 = small_k7(Cin, K, stride, dil), k1 = small_k1(Cin, Cout, K, stride);
+    size_t lds = (size_t)2 * (k1 ? 64 : k7 ? 16 : SMALL_CB) * a.W * sizeof(float) + (inm ? (size_t)Cin * sizeof(float2) : 0);
     if (with_gn) lds = std::max(lds, (size_t)64 * 33 * sizeof(float));
     const int64_t grid = (int64_t)B * a.n_t_tiles * a.n_row_tiles;
     if (grid <= 0 || grid > 0x7fffffff) return false;
@@ -435,7 +442,10 @@ bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int
     const int gpb = SMALL_CB * K / 16, n_blocks = Cin / SMALL_CB;
     const bool fits31 = (int64_t)Cin * x_cstride + x_len < ((int64_t)1 << 31);
     void (*fn)(const ConvSmallArgs) = conv_small_kernel;
-    if (k7) {
+    if (k1) {
+        if (!fits31 || TN != 2 || with_gn || inm) return false;
+        fn = conv_small_unrolled_kernel<4, 4, 2, 64, 8>;
+    } else if (k7) {
         if (!fits31) return false;
         if (with_gn) {
             if (K == 7 && !inm) fn = conv_small_unrolled_kernel<7, 2, 2, 16, 3, false, true>;

@@ -369,3 +369,16 @@ def _short_row_stride1(k, cin, cout, T, B, snake_out):
     got = ops.conv1d(x, w, b, 1, k // 2, 1, alpha_out=ao)
     assert got.shape == want.shape
     assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+
+
+@pytest.mark.parametrize("cin,cout,T,B", [(512, 2048, 1408, 1), (512, 2048, 576, 1), (256, 1024, 100, 3)])
+def test_conv1d_pointwise_short_row_form_bit_exact(cin, cout, T, B):
+    """Wide pointwise GEMMs over few columns (the chunked LSTM input projections, 512 -> 2048 over 44 steps x 32 rows) on the 16x16x4
+    kernel: 64 channels per block, every reduction index its own channel row."""
+    rng = np.random.default_rng(cin + cout + T)
+    x = _rand(rng, B, cin, T)
+    w = _rand(rng, cout, cin, 1, scale=1.0 / np.sqrt(cin)); b = _rand(rng, cout, scale=0.1)
+    want = c_oracle.conv1d(x, w, b, 1, 0, 1)
+    got = ops.conv1d(x, w, b, 1, 0, 1)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"

@@ -14,6 +14,6 @@ run NC_NO_GN_FINISH=1 NC_NO_THIN_INM=1 NC_DW_NO_VEC=1
 run NC_NO_FLAT_GN=1 NC_LSTM_NO_ELU=1 NC_NO_DIST_SMALL=1 NC_LSTM_UB=2 NC_NO_SUBPIXEL_ANY=1
 run NC_NO_CONV_SMALL=1
 run NC_SMALL_ROLLED=1 NC_SMALL_MAX_GRID=100000
-run NC_SMALL_TN=1 NC_SMALL_WIDE_BELOW=100000 NC_RVQ_8WAVES=1
+run NC_SMALL_TN=1 NC_SMALL_WIDE_BELOW=100000 NC_RVQ_8WAVES=1 NC_SMALL_K1_COLS=0
 run NC_LSTM_STEPWISE=1 NC_NO_TINY_TILES=1 NC_NO_SUBPIXEL=1
 run NC_NO_FUSE=1 NC_ENCODEC_NO_FUSE=1 NC_DAC_RVQ_STAGEWISE=1
