@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmal
             const int nxt = min(cbk + 1, n_blocks - 1);              // (the last block re-reads itself: branch-free, never stored)
             issue(nxt);
             int k = kq, off = off0;
-            if (K == 1) { k = 0; off = col * a.stride + kq * W; }    // (pointwise: lane group kq starts in channel row kq)
+            if constexpr (CB == 64) { k = 0; off = col * a.stride + kq * W; }   // (pointwise: lane group kq starts in channel row kq)
             else if (k >= K) { k -= K; off += W - K * dil; }         // (k = 3: the fourth lane group starts in the next channel row)
             float bv[2][4][TN];
             auto read_group = [&](float (&v)[4][TN]) __attribute__((always_inline)) {
@@ -285,10 +285,13 @@ __global__ __launch_bounds__(256) void conv_small_unrolled_kernel(const ConvSmal
                 for (int j = 0; j < 4; ++j) {
 #pragma unroll
                     for (int c = 0; c < TN; ++c) v[j][c] = xc[off + c * cts];
-                    if (K == 1) { off += 4 * W; continue; }          // pointwise: every reduction index is its own channel row
-                    k += 4; off += 4 * dil;
-                    if (k >= K) { k -= K; off += W - K * dil; }
-                    if (k >= K) { k -= K; off += W - K * dil; }      // (second wrap: k = 3 only)
+                    if constexpr (CB == 64) {                        // the pointwise instance: every reduction index is its own channel row
+                        off += 4 * W;
+                    } else {
+                        k += 4; off += 4 * dil;
+                        if (k >= K) { k -= K; off += W - K * dil; }
+                        if (k >= K) { k -= K; off += W - K * dil; }  // (second wrap: k = 3 only)
+                    }
                 }
             };
             read_group(bv[0]);
