@@ -190,6 +190,16 @@ NC_API nc_status nc_snac_decode_dev(nc_codec* h, const int64_t* codes, int32_t B
 /* total number of noise floats nc_snac_decode consumes for (B, frames) */
 NC_API nc_status nc_snac_noise_len(const nc_codec* h, int32_t B, int64_t frames, int64_t* n);
 
+/* replaces: SNAC.ProcessAudio(float[] audioData, int sampleRate)   Models/SNAC.cs:255-282 with ResampleAudio :284-308
+ * One upload, then resample (when sample_rate differs from the model's; binary64 position arithmetic as nc_audio_resample_linear_dev)
+ * -> forward (Preprocess pad, encode, quantize, decode, narrow to the resampled length: SNAC.cs:91-106) on the device, one download.
+ *   audio [n] float32 mono; NULL or n <= 0 -> NC_EINVAL (ArgumentException "Audio data cannot be empty", SNAC.cs:257-258)
+ *   noise / seed as nc_snac_decode (frames from nc_snac_query on the resampled length, B = 1)
+ *   out   [n_out], n_out from nc_snac_process_audio_len (= n when the rates agree, else nc_audio_resample_len) */
+NC_API nc_status nc_snac_process_audio_len(const nc_codec* h, int64_t n, int32_t sample_rate, int64_t* n_out);
+NC_API nc_status nc_snac_process_audio(nc_codec* h, const float* audio, int64_t n, int32_t sample_rate, const float* noise, uint64_t seed,
+                                       float* out);
+
 /* -------------------------------------------------------------------------------------- Encodec
  * replaces: new Encodec(EncodecConfig)             NeuralCodecs.Torch/Models/Encodec.cs:46-90
  * Only channels / dimension / norm / causal reach SEANet in the reference (Encodec.cs:57-68, deviation D11); the other SEANet
@@ -225,6 +235,11 @@ NC_API nc_status nc_encodec_set_bandwidth(nc_codec* h, float bandwidth_kbps);
  * every segment (frame_lens has room for `cap` entries), decoded length of Decode (before forward()'s trim to T). */
 NC_API nc_status nc_encodec_query(const nc_codec* h, int64_t T, int32_t* n_frames, int32_t* n_q, int64_t* frame_lens, int32_t cap,
                                   int64_t* decoded_len);
+/* The reference's Decode(List<EncodedFrame>) takes no clip length (Models/Encodec.cs:213-235: the frames alone fix the output,
+ * (n-1)*stride + decoded(last frame)).  This gives the smallest clip length T whose segment layout is `n_frames` segments with
+ * `tail_frames` code frames in the last one -- the T to hand to nc_encodec_decode for such a list.  NC_EINVAL when no clip length
+ * produces that layout. */
+NC_API nc_status nc_encodec_clip_length(const nc_codec* h, int32_t n_frames, int64_t tail_frames, int64_t* T);
 
 /* replaces: Encodec.Encode(Tensor x[B,C,T]) -> List<EncodedFrame>     Models/Encodec.cs:259-285, EncodeFrame :457-489
  *   codes  int64: the EncodedFrame.Codes tensors [B,n_q,T'_f] laid end to end in segment order

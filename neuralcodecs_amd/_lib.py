@@ -90,6 +90,8 @@ SYMBOLS = [
     ("nc_snac_query", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("nc_snac_noise_len", C.c_int, [_P, C.c_int32, C.c_int64, C.POINTER(C.c_int64)]),
+    ("nc_snac_process_audio_len", C.c_int, [_P, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),
+    ("nc_snac_process_audio", C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_uint64, _P]),
     ("nc_snac_encode", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
     ("nc_snac_encode_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
     ("nc_snac_query_tensor", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
@@ -103,6 +105,7 @@ SYMBOLS = [
     ("nc_encodec_set_bandwidth", C.c_int, [_P, C.c_float]),
     ("nc_encodec_query", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_int32,
                                    C.POINTER(C.c_int64)]),
+    ("nc_encodec_clip_length", C.c_int, [_P, C.c_int32, C.c_int64, C.POINTER(C.c_int64)]),
     ("nc_encodec_encode", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
     ("nc_encodec_encode_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
     ("nc_encodec_decode", C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),

@@ -390,6 +390,55 @@ nc_status nc_snac_decode(nc_codec* h, const int64_t* codes, int32_t B, int64_t f
     });
 }
 
+// SNAC.ProcessAudio (Models/SNAC.cs:255-282): resample (SNAC.cs:284-308) -> forward (:91-106) with the clip resident in HBM throughout.
+nc_status nc_snac_process_audio_len(const nc_codec* h, int64_t n, int32_t sample_rate, int64_t* n_out) {
+    return guard([&] {
+        SnacModel& m = as_snac(const_cast<nc_codec*>(h));
+        if (!n_out) fail(NC_EINVAL, "n_out must not be null");
+        if (n <= 0) fail(NC_EINVAL, "Audio data cannot be empty");
+        if (sample_rate <= 0) fail(NC_EINVAL, "sample rate must be positive");
+        *n_out = sample_rate == m.cfg.sample_rate ? n : nc_audio_resample_len(n, sample_rate, m.cfg.sample_rate);
+    });
+}
+
+nc_status nc_snac_process_audio(nc_codec* h, const float* audio, int64_t n, int32_t sample_rate, const float* noise, uint64_t seed,
+                                float* out) {
+    return guard([&] {
+        SnacModel& m = as_snac(h);
+        if (!audio || n <= 0) fail(NC_EINVAL, "Audio data cannot be empty");   // ArgumentException, SNAC.cs:257-258
+        if (!out) fail(NC_EINVAL, "out must not be null");
+        if (sample_rate <= 0) fail(NC_EINVAL, "sample rate must be positive");
+        m.use_device();
+        OwnStreamScope own(m);
+        const bool resample = sample_rate != m.cfg.sample_rate;
+        const int64_t T = resample ? nc_audio_resample_len(n, sample_rate, m.cfg.sample_rate) : n;
+        if (T <= 0) fail(NC_EINVAL, "resampled clip would be empty");
+        const int64_t Tz = m.padded_len(T) / m.hop;
+        const size_t n_codes = (size_t)m.codes_per_clip(Tz) * 8, n_dec = (size_t)m.decoded_len(Tz) * 4, n_z = (size_t)m.latent * Tz * 4;
+        const size_t n_noise = (size_t)m.noise_len(1, Tz) * 4;
+        m.h_in.reserve((size_t)T * 4); m.h_codes.reserve(n_codes); m.h_out.reserve(n_dec); m.h_aux0.reserve(std::max((size_t)n * 4, n_z));
+        m.h_aux1.reserve(n_z);
+        if (resample) {
+            h2d(m.h_aux0.p, audio, (size_t)n * 4, m.stream);
+            const nc_status st = nc_audio_resample_linear_dev(m.device, m.h_aux0.as<float>(), 1, n, sample_rate, m.cfg.sample_rate,
+                                                              m.h_in.as<float>(), m.stream);
+            if (st != NC_OK) fail(st, "%s", get_last_error());
+        } else {
+            h2d(m.h_in.p, audio, (size_t)n * 4, m.stream);
+        }
+        const float* nz = nullptr;
+        if (noise && n_noise) {
+            m.h_noise.reserve(n_noise);
+            h2d(m.h_noise.p, noise, n_noise, m.stream);
+            nz = m.h_noise.as<float>();
+        }
+        m.encode_dev(m.h_in.as<float>(), 1, T, m.h_codes.as<int64_t>(), m.h_aux0.as<float>(), m.h_aux1.as<float>(), true);
+        m.decode_dev(m.h_codes.as<int64_t>(), 1, Tz, nz, seed, m.h_out.as<float>());
+        d2h(out, m.h_out.p, (size_t)T * 4, m.stream);                          // SNAC.cs:103 narrow(-1, 0, length)
+        NC_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
 // ---- Encodec ---------------------------------------------------------------------------------------
 nc_status nc_encodec_create(const nc_encodec_config* cfg, int device_index, nc_codec** out) {
     return guard([&] {
@@ -422,6 +471,24 @@ nc_status nc_encodec_query(const nc_codec* h, int64_t T, int32_t* n_frames, int3
             if (m.cfg.segment_length <= 0) *decoded_len = m.decoded_for(segs[0].frames);
             else *decoded_len = (int64_t)m.cfg.segment_stride * ((int64_t)segs.size() - 1) + m.decoded_for(segs.back().frames);
         }
+    });
+}
+
+nc_status nc_encodec_clip_length(const nc_codec* h, int32_t n_frames, int64_t tail_frames, int64_t* T) {
+    return guard([&] {
+        EncodecModel& m = as_encodec(const_cast<nc_codec*>(h));
+        if (!T) fail(NC_EINVAL, "T must not be null");
+        if (n_frames <= 0 || tail_frames <= 0) fail(NC_EINVAL, "No frames provided to decode");   // Encodec.cs:215-218
+        if (m.cfg.segment_length <= 0) {
+            if (n_frames != 1) fail(NC_EINVAL, "Expected single frame when no segmentation is used");   // Encodec.cs:222-225
+            for (int64_t L = std::max<int64_t>(1, (tail_frames - 2) * m.hop); L <= (tail_frames + 1) * m.hop; ++L)
+                if (m.frames_for(L) == tail_frames) { *T = L; return; }
+            fail(NC_EINVAL, "no clip length yields %lld frames", (long long)tail_frames);
+        }
+        const int64_t base = (int64_t)(n_frames - 1) * m.cfg.segment_stride;
+        for (int64_t tail = 1; tail <= m.cfg.segment_stride; ++tail)   // a longer tail would start another segment (Encodec.cs:278-282)
+            if (m.frames_for(std::min<int64_t>(tail, m.cfg.segment_length)) == tail_frames) { *T = base + tail; return; }
+        fail(NC_EINVAL, "no clip length yields %d segments with %lld frames in the last", n_frames, (long long)tail_frames);
     });
 }
 

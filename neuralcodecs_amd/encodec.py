@@ -204,23 +204,11 @@ class Encodec(_lib.ProfileMixin):
         return out
 
     def _infer_length(self, frames) -> int:
-        hop = self.config.hop_length
-        if self.segment_length is None:
-            return int(frames[0].codes.shape[-1]) * hop
-        n = len(frames)
-        memo = self.__dict__.setdefault("_infer_memo", {})     # (frame count, tail frames) -> clip length: geometry only
-        mk = (n, int(frames[-1].codes.shape[-1]))
-        if mk in memo:
-            return memo[mk]
-        # smallest clip length that yields n segments with the observed tail frame count
-        base = (n - 1) * self.segment_stride
-        want = int(frames[-1].codes.shape[-1])
-        for tail in range(1, self.segment_length + 1):
-            q = self.query(base + tail)
-            if q[2][-1] == want and q[0] == n:
-                memo[mk] = base + tail
-                return base + tail
-        raise ValueError("cannot infer the clip length from the frames; pass length=")
+        """Clip length implied by the frames alone, as the reference's Decode(List<EncodedFrame>) sees them (Encodec.cs:213-235):
+        the smallest T with this many segments and this many code frames in the last (nc_encodec_clip_length)."""
+        T = C.c_int64()
+        _lib.check(_lib.lib().nc_encodec_clip_length(self._h, len(frames), int(frames[-1].codes.shape[-1]), C.byref(T)))
+        return T.value
 
     def forward(self, x):
         frames = self.encode(x)

@@ -239,7 +239,19 @@ class SNAC(_lib.ProfileMixin):
     def process_audio(self, audio_data, sample_rate: int, noise=None, seed: int = 0) -> np.ndarray:
         if audio_data is None or len(audio_data) == 0:
             raise ValueError("Audio data cannot be empty")
-        x = np.asarray(audio_data, dtype=np.float32)
-        if sample_rate != self.config.sampling_rate:
-            x = self.resample_linear(x, sample_rate, self.config.sampling_rate)
-        return self.forward(x.reshape(1, 1, -1), noise, seed)[0].reshape(-1)
+        x = np.ascontiguousarray(np.asarray(audio_data, dtype=np.float32).reshape(-1))
+        L = _lib.lib()
+        n_out = C.c_int64()
+        _lib.check(L.nc_snac_process_audio_len(self._h, x.size, int(sample_rate), C.byref(n_out)))
+        nz = None
+        if noise is not None:                                               # one [1,1,T_i] block per decoder stage, laid end to end
+            nz = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float32).reshape(-1) for a in noise]))
+            _, frames, _, _ = self.query(n_out.value)
+            if nz.size != sum(int(np.prod(s)) for s in self.noise_shapes(1, frames)):
+                raise ValueError("noise does not match the decoder stages of the resampled clip")
+        out = np.empty(n_out.value, dtype=np.float32)
+        # one upload -> resample -> forward -> one download, inside the engine (nc_snac_process_audio)
+        _lib.check(L.nc_snac_process_audio(self._h, x.ctypes.data_as(C.c_void_p), x.size, int(sample_rate),
+                                           nz.ctypes.data_as(C.c_void_p) if nz is not None else None, seed & 0xFFFFFFFFFFFFFFFF,
+                                           out.ctypes.data_as(C.c_void_p)))
+        return out

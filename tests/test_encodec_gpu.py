@@ -108,6 +108,16 @@ def test_encodec_errors_ragged_and_device_api():
     for T in (47, 48, 100, 3960, 3990, 4000, 4047, 9000):                         # ragged: short clips, exact stride / segment multiples
         pcm = synthetic_pcm(1, 2, T, cfg.sampling_rate, seed=T)
         _check_vs_oracle(m, ref, pcm)
+    # Decode(List<EncodedFrame>) takes no clip length in the reference (Encodec.cs:213-235): the frames alone fix the output.
+    # nc_encodec_clip_length gives the T of that layout; decoding with it equals decoding with the encoded clip's own length.
+    for T in (48, 100, 3960, 3990, 4047, 9000):
+        pcm = synthetic_pcm(1, 2, T, cfg.sampling_rate, seed=T + 1)
+        fr = m.encode(pcm)
+        Ti = m._infer_length(fr)
+        assert Ti <= T and m.query(Ti)[0] == len(fr) and m.query(Ti)[2] == [f.codes.shape[-1] for f in fr]
+        assert np.array_equal(m.decode(fr), m.decode(fr, T))
+    with pytest.raises(ValueError):
+        m._infer_length([EncodedFrame(np.zeros((1, 2, 10 ** 6), np.int64), None)])   # no clip yields that tail
     pcm = synthetic_pcm(3, 2, 5000, cfg.sampling_rate, seed=1)
     frames = m.encode(pcm)
     one = m.encode(pcm[2:3])

@@ -98,6 +98,29 @@ def test_snac_api_shapes_errors_and_noise_source():
     m.dispose()
 
 
+def test_snac_process_audio_one_call_vs_oracle_composition():
+    """SNAC.ProcessAudio (Models/SNAC.cs:255-308) behind ONE ABI call (nc_snac_process_audio: upload, resample, forward, download)
+    against the oracle composition ResampleAudio -> Preprocess -> encode -> decode -> narrow, bit for bit; same-rate input skips the
+    resampler; empty input is the reference's ArgumentException."""
+    from oracle import audio_ref
+    g, cfg, m, ref = _setup("snac_small")
+    x = synthetic_pcm(1, 1, 1777, cfg.sampling_rate, seed=31)[0, 0]
+    for src in (cfg.sampling_rate, cfg.sampling_rate * 2 // 3, 44100):
+        xr = x if src == cfg.sampling_rate else audio_ref.resample_linear(x, src, cfg.sampling_rate)
+        _, frames, _, _ = m.query(xr.size)
+        nz = snac_noise(cfg, 1, frames, seed=9)
+        out = m.process_audio(x, src, noise=nz)
+        _, _, rcodes = ref.encode(xr.reshape(1, 1, -1))
+        want = ref.decode(rcodes, nz).reshape(-1)[: xr.size]
+        assert out.shape == (xr.size,) and np.array_equal(out, want)
+        assert np.array_equal(out, m.forward(xr.reshape(1, 1, -1), nz)[0].reshape(-1))   # == the two-step path through the other entry points
+    with pytest.raises(ValueError):
+        m.process_audio(np.zeros(0, np.float32), cfg.sampling_rate)
+    with pytest.raises(ValueError):
+        m.process_audio(None, cfg.sampling_rate)
+    m.dispose()
+
+
 def test_snac_device_tensor_api_and_batch_invariance():
     import torch
     g, cfg, m, ref = _setup("snac_small_attn")

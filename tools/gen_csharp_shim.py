@@ -4,19 +4,23 @@
     python tools/gen_csharp_shim.py            # writes bindings/csharp/*.cs
     python tools/gen_csharp_shim.py --check    # exit 1 when the committed files differ from what the header generates
 
-Outputs (a maintainer of the reference drops them into NeuralCodecs.Torch/Native/ and Models/):
-  bindings/csharp/NcMi355x.cs       every enum, struct layout and NC_API export of the header as [DllImport] stubs + the status ->
-                                    exception map of SURVEY 8b.  Mechanical: one stub per export, parameter for parameter.
-  bindings/csharp/DAC.Native.cs     partial-class bodies of the managed members the reference exposes (INeuralCodec, DAC.Encode /
-  bindings/csharp/SNAC.Native.cs    Decode / FromCodes, SNAC.Encode / Decode, Encodec.Encode / Decode / SetTargetBandwidth) written
-  bindings/csharp/Encodec.Native.cs against those stubs.  Templates (below), checked mechanically: every NcMi355x.nc_* call they
-                                    make must exist in the header with the same number of arguments (tests/test_csharp_shim_cpu.py).
-dotnet is not available in the build image, so the files are generated and cross-checked, not compiled.
+Output (a maintainer of the reference drops bindings/csharp/ into NeuralCodecs.Torch/Native/):
+  bindings/csharp/NcMi355x.cs       GENERATED: every enum, struct layout and NC_API export of the header as [DllImport] stubs + the
+                                    status -> exception map of SURVEY 8b.  Mechanical: one stub per export, parameter for parameter.
+Checked, not generated (hand-written against those stubs and against the reference's own types):
+  bindings/csharp/DAC.Native.cs     DACNative / SNACNative / EncodecNative : INeuralCodec with every public member of the reference's
+  bindings/csharp/SNAC.Native.cs    DAC / SNAC / Encodec classes, signature for signature; NeuralCodecs.Create*NativeAsync factories.
+  bindings/csharp/Encodec.Native.cs Every NcMi355x.nc_* call they make must exist in the header with the same number of arguments
+  bindings/csharp/NeuralCodecs.Native.cs   (check_templates); tests/test_csharp_shim_cpu.py additionally parses the REFERENCE's .cs files
+                                    (Config/*Config.cs, Models/*.cs, NeuralCodecs.cs, Core/Exceptions) and holds the classes to them.
+dotnet is not available in the build image, so the files are cross-checked, not compiled.
 """
 import argparse
 import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HDR = os.path.join(ROOT, "include", "nc_mi355x.h")
@@ -162,6 +166,11 @@ def gen_native(enums, structs, funcs, defines):
     o.append("")
     o.append("    public static string LastError() => Marshal.PtrToStringUTF8(nc_last_error()) ?? string.Empty;")
     o.append("")
+    o.append("    // IModelConfig.Device (Core/Configuration/DeviceConfiguration.cs) -> device ordinal of the engine: the GPU index when the")
+    o.append("    // config names an accelerator, device 0 otherwise (the engine has no CPU path; the reference's default config says CPU)")
+    o.append("    public static int DeviceIndex(NeuralCodecs.Core.Configuration.DeviceConfiguration? d) =>")
+    o.append("        d is not null && d.Type == NeuralCodecs.Core.Configuration.DeviceType.CUDA ? d.Index : 0;")
+    o.append("")
     o.append("    // status -> the exception types the reference throws today (SURVEY 8b)")
     o.append("    public static void Check(NcStatus s)")
     o.append("    {")
@@ -175,371 +184,19 @@ def gen_native(enums, structs, funcs, defines):
     o.append("            NcStatus.NC_ESTATE => new InvalidOperationException(msg),              // Models/DAC.cs:385-388")
     o.append("            NcStatus.NC_ENOMEM => new OutOfMemoryException(msg),")
     o.append("            NcStatus.NC_EUNSUPPORTED => new NotSupportedException(msg),")
-    o.append("            _ => new NeuralCodecs.Core.Exceptions.CodecException(msg),             // NC_EDEVICE")
+    o.append("            _ => new NeuralCodecs.Core.Exceptions.NeuralCodecException(msg),       // NC_EDEVICE")
     o.append("        };")
     o.append("    }")
     o.append("}")
     return "\n".join(o) + "\n"
 
 
-# ---- partial-class bodies (templates; every NcMi355x.nc_* call is checked against the header) -----------------------------------------
-DAC_CS = r'''// <auto-generated> by tools/gen_csharp_shim.py -- template section; regenerate, do not edit. </auto-generated>
-// Bodies of the managed DAC members (NeuralCodecs.Torch/Models/DAC.cs) over libnc_mi355x.so: signatures, exceptions and INeuralCodec
-// stay as in the reference; no TorchSharp operator runs between a member's entry and its return.
-using System;
-using System.Collections.Generic;
-using NeuralCodecs.Core;
-using NeuralCodecs.Core.Configuration;
-using NeuralCodecs.Torch.Config.DAC;
-using NeuralCodecs.Torch.Native;
+# ---- hand-written model classes (bindings/csharp/*.Native.cs): checked here and in tests/test_csharp_shim_cpu.py -------------------------
+MODEL_FILES = ("DAC.Native.cs", "SNAC.Native.cs", "Encodec.Native.cs", "NeuralCodecs.Native.cs")
 
-namespace NeuralCodecs.Torch.Models;
 
-public sealed unsafe partial class DACNative : INeuralCodec
-{
-    private IntPtr _h;
-    private readonly DACConfig _config;
-    public IModelConfig Config => _config;                                  // INeuralCodec.cs:13
-
-    public DACNative(DACConfig config, int deviceIndex = 0)                 // Models/DAC.cs:51-93
-    {
-        _config = config ?? throw new ArgumentNullException(nameof(config));
-        var c = new NcDacConfig
-        {
-            sample_rate = config.SamplingRate, encoder_dim = config.EncoderDim, n_encoder_rates = config.EncoderRates.Length,
-            decoder_dim = config.DecoderDim, n_decoder_rates = config.DecoderRates.Length, latent_dim = config.LatentDim ?? 0,
-            n_codebooks = config.NumCodebooks, codebook_size = config.CodebookSize, codebook_dim = config.CodebookDim,
-        };
-        for (int i = 0; i < config.EncoderRates.Length; ++i) c.encoder_rates[i] = config.EncoderRates[i];
-        for (int i = 0; i < config.DecoderRates.Length; ++i) c.decoder_rates[i] = config.DecoderRates[i];
-        NcMi355x.Check(NcMi355x.nc_dac_create(in c, deviceIndex, out _h));
-    }
-
-    public void LoadWeights(string path)                                    // Models/DAC.cs:345-389 (NCWB blob: tools/convert_checkpoint.py)
-    {
-        if (string.IsNullOrEmpty(path)) throw new ArgumentException("path");
-        NcMi355x.Check(NcMi355x.nc_codec_load_weights(_h, path));
-    }
-
-    /// <summary>Encode(Tensor audio [B,1,T], nQuantizers, sampleRate) -> (z, codes, latents): Models/DAC.cs:163-181 on host arrays.</summary>
-    public (float[] z, long[] codes, float[] latents, long frames, int nQ) Encode(float[] audio, int B, long T, int? nQuantizers = null, int? sampleRate = null)
-    {
-        ArgumentNullException.ThrowIfNull(audio);
-        long padded, frames;
-        NcMi355x.Check(NcMi355x.nc_dac_query(_h, T, &padded, &frames));
-        int nq = (nQuantizers is int n && n > 0 && n <= _config.NumCodebooks) ? n : _config.NumCodebooks;
-        int latent = _config.LatentDim ?? _config.EncoderDim << _config.EncoderRates.Length;
-        var z = new float[(long)B * latent * frames];
-        var codes = new long[(long)B * nq * frames];
-        var lat = new float[(long)B * nq * _config.CodebookDim * frames];
-        fixed (float* p = audio, pz = z, pl = lat) fixed (long* pc = codes)
-            NcMi355x.Check(NcMi355x.nc_dac_encode(_h, p, B, T, sampleRate ?? 0, nQuantizers ?? 0, pc, pz, pl));
-        return (z, codes, lat, frames, nq);
-    }
-
-    public float[] Encode(float[] audioData)                               // Models/DAC.cs:205-224: returns the zQ latents (D12)
-    {
-        ArgumentNullException.ThrowIfNull(audioData);
-        return Encode(audioData, 1, audioData.Length).z;
-    }
-
-    public float[] Decode(float[] qAudio, int B, long frames)              // Models/DAC.cs:231-234 on host arrays
-    {
-        ArgumentNullException.ThrowIfNull(qAudio);
-        long padded, fr;
-        NcMi355x.Check(NcMi355x.nc_dac_query(_h, 1, &padded, &fr));
-        long hop = padded;                                                  // T = 1 pads to one hop
-        var pcm = new float[(long)B * frames * hop];
-        fixed (float* pz = qAudio, pp = pcm)
-            NcMi355x.Check(NcMi355x.nc_dac_decode(_h, pz, B, frames, pp));
-        return pcm;
-    }
-
-    public float[] Decode(float[] qAudio)                                  // Models/DAC.cs:241-253: reshape(1, latent, -1)
-    {
-        ArgumentNullException.ThrowIfNull(qAudio);
-        int latent = _config.LatentDim ?? _config.EncoderDim << _config.EncoderRates.Length;
-        return Decode(qAudio, 1, qAudio.Length / latent);
-    }
-
-    public float[] FromCodes(long[] codes, int B, int nQ, long frames)     // Models/DAC.cs:101-106
-    {
-        ArgumentNullException.ThrowIfNull(codes);
-        int latent = _config.LatentDim ?? _config.EncoderDim << _config.EncoderRates.Length;
-        var z = new float[(long)B * latent * frames];
-        fixed (long* pc = codes) fixed (float* pz = z)
-            NcMi355x.Check(NcMi355x.nc_dac_from_codes(_h, pc, B, nQ, frames, pz));
-        return z;
-    }
-
-    public float[] forward(float[] audioData) => Decode(Encode(audioData)); // Models/DAC.cs:310-322
-
-    /// <summary>Dia glue (Models/Dia.cs:973-981, Modules/Dia/AudioUtils.cs:189-199): codes [B,T',n_q] -> PCM.</summary>
-    public float[] DecodeCodeMatrix(long[] codesTq, int B, long frames, int nQ)
-    {
-        long padded, fr;
-        NcMi355x.Check(NcMi355x.nc_dac_query(_h, 1, &padded, &fr));
-        var pcm = new float[(long)B * frames * padded];
-        fixed (long* pc = codesTq) fixed (float* pp = pcm)
-            NcMi355x.Check(NcMi355x.nc_dac_decode_code_matrix(_h, pc, B, frames, nQ, pp));
-        return pcm;
-    }
-
-    public void Dispose()                                                   // Models/DAC.cs:329-338
-    {
-        if (_h != IntPtr.Zero) { NcMi355x.nc_codec_destroy(_h); _h = IntPtr.Zero; }
-        GC.SuppressFinalize(this);
-    }
-}
-'''
-
-SNAC_CS = r'''// <auto-generated> by tools/gen_csharp_shim.py -- template section; regenerate, do not edit. </auto-generated>
-// Bodies of the managed SNAC members (NeuralCodecs.Torch/Models/SNAC.cs) over libnc_mi355x.so.
-using System;
-using System.Collections.Generic;
-using NeuralCodecs.Core;
-using NeuralCodecs.Core.Configuration;
-using NeuralCodecs.Torch.Config.SNAC;
-using NeuralCodecs.Torch.Native;
-
-namespace NeuralCodecs.Torch.Models;
-
-public sealed unsafe partial class SNACNative : INeuralCodec
-{
-    private IntPtr _h;
-    private readonly SNACConfig _config;
-    public IModelConfig Config => _config;
-
-    public SNACNative(SNACConfig config, int deviceIndex = 0)               // Models/SNAC.cs:34-63
-    {
-        _config = config ?? throw new ArgumentNullException(nameof(config));
-        var c = new NcSnacConfig
-        {
-            sample_rate = config.SamplingRate, encoder_dim = config.EncoderDim, n_encoder_rates = config.EncoderRates.Length,
-            decoder_dim = config.DecoderDim, n_decoder_rates = config.DecoderRates.Length, latent_dim = config.LatentDim ?? 0,
-            attn_window_size = config.AttnWindowSize ?? 0, codebook_size = config.CodebookSize, codebook_dim = config.CodebookDim,
-            n_vq_strides = config.VQStrides.Length, noise = config.Noise ? 1 : 0, depthwise = config.Depthwise ? 1 : 0,
-        };
-        for (int i = 0; i < config.EncoderRates.Length; ++i) c.encoder_rates[i] = config.EncoderRates[i];
-        for (int i = 0; i < config.DecoderRates.Length; ++i) c.decoder_rates[i] = config.DecoderRates[i];
-        for (int i = 0; i < config.VQStrides.Length; ++i) c.vq_strides[i] = config.VQStrides[i];
-        NcMi355x.Check(NcMi355x.nc_snac_create(in c, deviceIndex, out _h));
-    }
-
-    public void LoadWeights(string path)                                    // Models/SNAC.cs:200-231
-    {
-        if (string.IsNullOrEmpty(path)) throw new ArgumentException("path");
-        NcMi355x.Check(NcMi355x.nc_codec_load_weights(_h, path));
-    }
-
-    /// <summary>SNAC.Encode(float[]) (Models/SNAC.cs:129-150): Preprocess pads; one long[] per level, coarse first.</summary>
-    public List<long[]> Encode(float[] audioData, int B = 1)
-    {
-        ArgumentNullException.ThrowIfNull(audioData);
-        long T = audioData.Length / B, padded, frames, decoded;
-        int nLevels;
-        long* widths = stackalloc long[8];
-        NcMi355x.Check(NcMi355x.nc_snac_query(_h, T, &padded, &frames, &nLevels, widths, &decoded));
-        long per = 0;
-        for (int i = 0; i < nLevels; ++i) per += widths[i];
-        var flat = new long[B * per];
-        fixed (float* p = audioData) fixed (long* pc = flat)
-            NcMi355x.Check(NcMi355x.nc_snac_encode(_h, p, B, T, pc, null, null));
-        var levels = new List<long[]>(nLevels);
-        long off = 0;
-        for (int i = 0; i < nLevels; ++i)                                   // the levels of a clip sit side by side: split per level
-        {
-            var lv = new long[B * widths[i]];
-            for (int b = 0; b < B; ++b) Array.Copy(flat, b * per + off, lv, b * widths[i], widths[i]);
-            levels.Add(lv);
-            off += widths[i];
-        }
-        return levels;
-    }
-
-    /// <summary>SNAC.Encode(Tensor) exactly as written (Models/SNAC.cs:113-122, deviation D7: no padding).</summary>
-    public List<long[]> EncodeTensor(float[] audioData, int B = 1)
-    {
-        ArgumentNullException.ThrowIfNull(audioData);
-        long T = audioData.Length / B, frames;
-        int nLevels;
-        long* widths = stackalloc long[8];
-        NcMi355x.Check(NcMi355x.nc_snac_query_tensor(_h, T, &frames, &nLevels, widths));
-        long per = 0;
-        for (int i = 0; i < nLevels; ++i) per += widths[i];
-        var flat = new long[B * per];
-        fixed (float* p = audioData) fixed (long* pc = flat)
-            NcMi355x.Check(NcMi355x.nc_snac_encode_tensor(_h, p, B, T, pc, null, null));
-        var levels = new List<long[]>(nLevels);
-        long off = 0;
-        for (int i = 0; i < nLevels; ++i)
-        {
-            var lv = new long[B * widths[i]];
-            for (int b = 0; b < B; ++b) Array.Copy(flat, b * per + off, lv, b * widths[i], widths[i]);
-            levels.Add(lv);
-            off += widths[i];
-        }
-        return levels;
-    }
-
-    /// <summary>SNAC.Decode(List codes) (Models/SNAC.cs:157-192); noise = null draws N(0,1) on the device (the reference's randn, D8).</summary>
-    public float[] Decode(List<long[]> codes, int B = 1, float[]? noise = null, ulong? seed = null)
-    {
-        if (codes is null || codes.Count == 0) throw new ArgumentException("codes");
-        long frames = codes[^1].Length / B;                                 // the finest level has one code per frame
-        long padded, fr, decoded;
-        int nLevels;
-        long* widths = stackalloc long[8];
-        NcMi355x.Check(NcMi355x.nc_snac_query(_h, frames * (long)HopLength, &padded, &fr, &nLevels, widths, &decoded));
-        if (codes.Count != nLevels) throw new ArgumentException($"Expected {nLevels} code levels, got {codes.Count}");   // SNAC/ResidualVectorQuantizer.cs:103
-        long per = 0;
-        for (int i = 0; i < nLevels; ++i) per += widths[i];
-        var flat = new long[B * per];
-        long off = 0;
-        for (int i = 0; i < nLevels; ++i)
-        {
-            for (int b = 0; b < B; ++b) Array.Copy(codes[i], b * widths[i], flat, b * per + off, widths[i]);
-            off += widths[i];
-        }
-        var pcm = new float[B * decoded];
-        fixed (long* pc = flat) fixed (float* pn = noise, pp = pcm)
-            NcMi355x.Check(NcMi355x.nc_snac_decode(_h, pc, B, frames, pn, seed ?? (ulong)Random.Shared.NextInt64(), pp));
-        return pcm;
-    }
-
-    private int HopLength { get { int h = 1; foreach (int r in _config.EncoderRates) h *= r; return h; } }
-
-    public void Dispose()
-    {
-        if (_h != IntPtr.Zero) { NcMi355x.nc_codec_destroy(_h); _h = IntPtr.Zero; }
-        GC.SuppressFinalize(this);
-    }
-}
-'''
-
-ENCODEC_CS = r'''// <auto-generated> by tools/gen_csharp_shim.py -- template section; regenerate, do not edit. </auto-generated>
-// Bodies of the managed Encodec members (NeuralCodecs.Torch/Models/Encodec.cs) over libnc_mi355x.so.
-using System;
-using System.Collections.Generic;
-using System.Linq;
-using NeuralCodecs.Core;
-using NeuralCodecs.Core.Configuration;
-using NeuralCodecs.Torch.Config.Encodec;
-using NeuralCodecs.Torch.Native;
-
-namespace NeuralCodecs.Torch.Models;
-
-/// <summary>EncodedFrame (Modules/Encodec/EncodedFrame.cs) on host arrays: Codes [B,n_q,T'_f] int64, Scale [B] or null.</summary>
-public sealed record EncodedFrameNative(long[] Codes, float[]? Scale, int NQ, long Frames);
-
-public sealed unsafe partial class EncodecNative : INeuralCodec
-{
-    private IntPtr _h;
-    private readonly EncodecConfig _config;
-    private float _bandwidth;
-    public IModelConfig Config => _config;
-
-    public EncodecNative(EncodecConfig config, int deviceIndex = 0)         // Models/Encodec.cs:46-90 (D11: SEANet hard defaults)
-    {
-        _config = config ?? throw new ArgumentNullException(nameof(config));
-        int[] ratios = { 8, 5, 4, 2 };
-        int hop = ratios.Aggregate(1, (a, b) => a * b);
-        int frameRate = (int)Math.Ceiling(config.SamplingRate / (double)hop);                        // Encodec.cs:83
-        float? seg = config.ChunkLengthSeconds;
-        int segLen = seg.HasValue ? (int)(seg.Value * config.SamplingRate) : 0;                       // Encodec.cs:190
-        int segStride = seg.HasValue ? Math.Max(1, (int)((1 - config.Overlap) * segLen)) : 0;         // Encodec.cs:196
-        _bandwidth = config.TargetBandwidths.Max();
-        var c = new NcEncodecConfig
-        {
-            sample_rate = config.SamplingRate, channels = config.AudioChannels, dimension = config.HiddenSize, n_filters = 32, n_ratios = 4,
-            lstm_layers = 2, compress = 2, kernel_size = 7, last_kernel_size = 7, residual_kernel_size = 3,
-            time_group_norm = config.NormType == "time_group_norm" ? 1 : 0, causal = config.UseCausalConv ? 1 : 0,
-            normalize = config.Normalize ? 1 : 0, segment_length = segLen, segment_stride = segStride, codebook_size = config.CodebookSize,
-            n_codebooks = (int)(1000 * config.TargetBandwidths.Max() / (frameRate * 10)),              // Encodec.cs:70-71
-            frame_rate = frameRate, bandwidth = _bandwidth,
-        };
-        for (int i = 0; i < 4; ++i) c.ratios[i] = ratios[i];
-        NcMi355x.Check(NcMi355x.nc_encodec_create(in c, deviceIndex, out _h));
-    }
-
-    public void LoadWeights(string path)                                    // Models/Encodec.cs:348-385
-    {
-        if (string.IsNullOrEmpty(path)) throw new ArgumentException("path");
-        NcMi355x.Check(NcMi355x.nc_codec_load_weights(_h, path));
-    }
-
-    public void SetTargetBandwidth(float bandwidth)                         // Models/Encodec.cs:409-419
-    {
-        if (!_config.TargetBandwidths.Contains(bandwidth))
-            throw new ArgumentException($"This model doesn't support the bandwidth {bandwidth}.");
-        NcMi355x.Check(NcMi355x.nc_encodec_set_bandwidth(_h, bandwidth));
-        _bandwidth = bandwidth;
-    }
-
-    /// <summary>Encodec.Encode(Tensor x [B,C,T]) (Models/Encodec.cs:259-285): one EncodedFrame per segment.</summary>
-    public List<EncodedFrameNative> Encode(float[] audio, int B, long T)
-    {
-        ArgumentNullException.ThrowIfNull(audio);                                                     // Encodec.cs:245
-        int nFrames, nQ;
-        long decoded;
-        long* lens = stackalloc long[4096];
-        NcMi355x.Check(NcMi355x.nc_encodec_query(_h, T, &nFrames, &nQ, lens, 4096, &decoded));
-        long total = 0;
-        for (int f = 0; f < nFrames; ++f) total += lens[f];
-        var codes = new long[B * nQ * total];
-        var scales = new float[nFrames * B];
-        fixed (float* p = audio, ps = scales) fixed (long* pc = codes)
-            NcMi355x.Check(NcMi355x.nc_encodec_encode(_h, p, B, T, pc, ps, null));
-        var frames = new List<EncodedFrameNative>(nFrames);
-        long off = 0;
-        for (int f = 0; f < nFrames; ++f)
-        {
-            long n = (long)B * nQ * lens[f];
-            var c = new long[n];
-            Array.Copy(codes, off, c, 0, n);
-            float[]? sc = _config.Normalize ? scales.AsSpan(f * B, B).ToArray() : null;
-            frames.Add(new EncodedFrameNative(c, sc, nQ, lens[f]));
-            off += n;
-        }
-        return frames;
-    }
-
-    public List<EncodedFrameNative> Encode(float[] audioData) => Encode(audioData, 1, audioData.Length / _config.AudioChannels);   // Encodec.cs:243-257
-
-    /// <summary>Encodec.Decode(List of EncodedFrame) (Models/Encodec.cs:213-235): decode + linear overlap-add; T = the encoded clip length.</summary>
-    public float[] Decode(List<EncodedFrameNative> frames, int B, long T)
-    {
-        if (frames is null || frames.Count == 0) throw new ArgumentException("No frames provided to decode");        // Encodec.cs:215-218
-        int nFrames, nQq;
-        long decoded;
-        long* lens = stackalloc long[4096];
-        NcMi355x.Check(NcMi355x.nc_encodec_query(_h, T, &nFrames, &nQq, lens, 4096, &decoded));
-        if (frames.Count != nFrames) throw new ArgumentException($"Expected {nFrames} frames for clips of {T} samples, got {frames.Count}");
-        int nQ = frames[0].NQ;
-        var codes = new long[frames.Sum(f => (long)f.Codes.Length)];
-        var scales = new float[nFrames * B];
-        long off = 0;
-        for (int f = 0; f < nFrames; ++f)
-        {
-            Array.Copy(frames[f].Codes, 0, codes, off, frames[f].Codes.Length);
-            off += frames[f].Codes.Length;
-            if (frames[f].Scale is float[] s) Array.Copy(s, 0, scales, f * B, B);
-        }
-        var pcm = new float[(long)B * _config.AudioChannels * decoded];
-        fixed (long* pc = codes) fixed (float* ps = scales, pp = pcm)
-            NcMi355x.Check(NcMi355x.nc_encodec_decode(_h, pc, _config.Normalize ? ps : null, B, T, nQ, pp));
-        return pcm;
-    }
-
-    public void Dispose()
-    {
-        if (_h != IntPtr.Zero) { NcMi355x.nc_codec_destroy(_h); _h = IntPtr.Zero; }
-        GC.SuppressFinalize(this);
-    }
-}
-'''
-
-TEMPLATES = {"DAC.Native.cs": DAC_CS, "SNAC.Native.cs": SNAC_CS, "Encodec.Native.cs": ENCODEC_CS}
+def model_sources():
+    return {f: open(os.path.join(OUT, f)).read() for f in MODEL_FILES}
 
 
 def split_args(s):
@@ -565,7 +222,7 @@ def check_templates(funcs):
     sig = {name: params for _, name, params in funcs}
     errors = []
     used = set()
-    for fname, text in TEMPLATES.items():
+    for fname, text in model_sources().items():
         for m in re.finditer(r"NcMi355x\.(nc_\w+)\s*\(", text):
             name = m.group(1)
             i, depth = m.end(), 1
@@ -582,14 +239,77 @@ def check_templates(funcs):
     return errors, used
 
 
+def integration_tables():
+    """Member -> C ABI call tables of INTEGRATION.md, derived from the model classes themselves: for every public member, the
+    nc_* exports its body reaches (through the class's own host-array cores), and the reference line it cites in its trailing comment."""
+    import csharp_parse as P
+    out = []
+    for fname, cls in (("DAC.Native.cs", "DACNative"), ("SNAC.Native.cs", "SNACNative"), ("Encodec.Native.cs", "EncodecNative")):
+        raw = open(os.path.join(OUT, fname)).read()
+        m = P.members(raw, cls)
+        names = [n for _, n, _, _ in m["methods"]]
+        direct = [set(re.findall(r"NcMi355x\.(nc_\w+)", b)) for b in m["bodies"]]
+        callees = [{n for n in set(names) if re.search(r"(?<![\w.])" + n + r"\s*\(", b)} for b in m["bodies"]]
+
+        def reach(i, seen):
+            calls = set(direct[i])
+            for j, n in enumerate(names):
+                if n in callees[i] and j not in seen and j != i:
+                    calls |= reach(j, seen | {i})
+            return calls
+
+        cites = {}                                              # "Name(params" -> the Models/...cs:line citation on the declaration line
+        for line in raw.splitlines():
+            decl = re.sub(r"^(\s*public\s+)\([^)]*\)\s+", r"\1T ", line)                 # a tuple return type holds parentheses
+            cm = re.match(r"\s*(?:public\s+[^(]*?)?(\w+)\(([^)]*)\).*//\s*(Models/[\w./]+:[\d\-,]+)", decl)
+            if cm and cm.group(1) in names:
+                cites.setdefault((cm.group(1), re.sub(r"\s+", "", cm.group(2))), cm.group(3))
+        ctor = re.search(r"public " + cls + r"\((.*?)\).*//\s*(Models/[\w./]+:[\d\-,]+)", raw)
+        cbody = raw[ctor.end():]
+        out.append(f"**`{cls}`** (`bindings/csharp/{fname}`)")
+        out.append("")
+        out.append("| Managed member (reference signature) | reference | C ABI calls |")
+        out.append("|---|---|---|")
+        out.append(f"| `new {cls}({ctor.group(1)})` | `{ctor.group(2)}` | " + ", ".join(f"`{c}`" for c in sorted(set(re.findall(r"NcMi355x\.(nc_\w+_create)", cbody)))) + " |")
+        for i, (ret, name, params, _) in enumerate(m["methods"]):
+            if name.endswith("Host"):
+                continue
+            key = re.sub(r"[\s?]+", "", ",".join(f"{t}{n}" for t, n, _ in params))
+            cite = next((v for (n2, p2), v in cites.items() if n2 == name and re.sub(r"=\w+|\?", "", p2) == key), "")
+            calls = sorted(reach(i, set()))
+            out.append(f"| `{ret} {name}({', '.join(t for t, _, _ in params)})` | {('`' + cite + '`') if cite else ''} | " + (", ".join(f"`{c}`" for c in calls) or "managed only") + " |")
+        out.append("")
+    return "\n".join(out)
+
+
+BEGIN_MARK, END_MARK = "<!-- BEGIN generated member tables (tools/gen_csharp_shim.py) -->", "<!-- END generated member tables -->"
+
+
+def integration_md_current():
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    if BEGIN_MARK not in md or END_MARK not in md:
+        return False
+    cur = md[md.index(BEGIN_MARK) + len(BEGIN_MARK):md.index(END_MARK)].strip()
+    return cur == integration_tables().strip()
+
+
+def write_integration_md():
+    path = os.path.join(ROOT, "INTEGRATION.md")
+    md = open(path).read()
+    block = BEGIN_MARK + "\n" + integration_tables().strip() + "\n" + END_MARK
+    if BEGIN_MARK in md and END_MARK in md:
+        md = md[:md.index(BEGIN_MARK)] + block + md[md.index(END_MARK) + len(END_MARK):]
+        open(path, "w").write(md)
+        return True
+    return False
+
+
 def generate():
     enums, structs, funcs, defines = parse_header()
     errs, _ = check_templates(funcs)
     if errs:
         raise SystemExit("gen_csharp_shim: " + "; ".join(errs))
-    files = {"NcMi355x.cs": gen_native(enums, structs, funcs, defines)}
-    files.update(TEMPLATES)
-    return files
+    return {"NcMi355x.cs": gen_native(enums, structs, funcs, defines)}
 
 
 if __name__ == "__main__":
@@ -606,6 +326,10 @@ if __name__ == "__main__":
         else:
             os.makedirs(OUT, exist_ok=True)
             open(p, "w").write(text)
+    if a.check and not integration_md_current():
+        bad.append("INTEGRATION.md member tables")
+    if not a.check:
+        write_integration_md()
     if a.check and bad:
         print("out of date:", ", ".join(bad))
         sys.exit(1)
