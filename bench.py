@@ -12,12 +12,15 @@ same loop on BASELINE config C5's per-GPU share (SNAC 44.1 kHz + LocalMHA, 8 x 5
 levels of a clip gathered in one collective).
 
 The JSON line carries
+  * `ms_per_step` / `value` from the wall clock around EXACTLY --steps steps (profiler off; barrier + synchronise both sides; max over
+    ranks), `ms_per_step_median` from HIP events recorded between the steps, `encode_only` / `decode_only` (SURVEY 8d);
   * `roofline` for the dominant kernel class (the dilated k=7 residual-unit convolutions, fp32 matrix-core implicit
-    GEMM: bound "mfma", peak = 157.3 TFLOP/s dense fp32 MFMA on MI355X) measured with HIP events on the launch stream;
-  * `cpu_baseline`: the C oracle (kind "port") timed on the host cores on a bounded sample of the same workload, the
+    GEMM: bound "mfma", peak = 157.3 TFLOP/s dense fp32 MFMA on MI355X) measured with HIP events on the launch stream in a
+    second pass of the same --steps steps (the per-launch event pairs stay out of the timed region);
+  * `cpu_baseline`: the C oracle (kind "port") timed on the host cores on the step's WHOLE batch once (~35 s), the
     GPU == oracle check on those clips (`gpu_equals_oracle`, outside the timed region) and `aten_proxy`: the same graph
-    as a sequence of ATen CPU operators (tools/aten_proxy.py, the closest stand-in for the reference's TorchSharp-CPU path);
-    both CPU legs: one warm-up + 3 timed passes, median (BASELINE.md 3);
+    as a sequence of ATen CPU operators (tools/aten_proxy.py, the closest stand-in for the reference's TorchSharp-CPU path):
+    one warm-up + 3 timed passes over 2 clips, median;
   * `extra_configs` (N=1 only): BASELINE configs C3 (Encodec 48 kHz stereo, 16 x 2 s), C5's per-GPU share and C1
     (SNAC 24 kHz, 1 x 1 s) on the same GPU: ms, x real-time, per-class HIP-event times, dominant kernel class with its
     roofline fraction, algorithmic vs PMC bytes, and a GPU == oracle check on one clip.
@@ -203,8 +206,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default: 32 for dac44k, 8 for snac44k)")
     ap.add_argument("--seconds", type=float, default=0.0, help="clip length (default: 1 s for dac44k, 5 s for snac44k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=4, help="clips in the bounded CPU-baseline sample (1 warm-up + --cpu-iters timed passes over them)")
-    ap.add_argument("--cpu-iters", type=int, default=3, help="timed passes of the CPU baselines (median reported)")
+    ap.add_argument("--cpu-clips", type=int, default=0, help="clips in the CPU-baseline sample (default: the whole batch of one step, BASELINE.md 3.1)")
+    ap.add_argument("--cpu-iters", type=int, default=1, help="timed passes of the C-oracle baseline over the sample (median reported; one pass of the C2 batch is ~35 s)")
+    ap.add_argument("--proxy-iters", type=int, default=3, help="timed passes of the ATen operator-sequence proxy (2 clips; median)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs block (C3 / C5 share / C1)")
     ap.add_argument("--no-check", action="store_true", help="skip the GPU == oracle comparisons (outside the timed region)")
     ap.add_argument("--check", action="store_true", help="(default now) kept for compatibility")
@@ -300,23 +304,55 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    model.profile_enable(True)
-    model.profile_reset()
+    # ---- the timed region: EXACTLY --steps steps, profiler off, barrier + device synchronise on both sides.  A HIP event is recorded on
+    # the launch stream between steps (asynchronous, no host wait) so that the per-step times -- and their median, SURVEY 8d -- are known.
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         codes, z, audio = step()
+        marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
-    prof = model.profile_read()
-    model.profile_enable(False)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # ---- second pass (untimed): the per-class table, HIP events around every launch on the launch stream (roofline.achieved)
+    model.profile_enable(True)
+    model.profile_reset()
+    for _ in range(args.steps):
+        step()
+    sync()
+    prof = model.profile_read()
+    model.profile_enable(False)
+
+    # ---- encode-only / decode-only (Examples/Program.cs:252-291 calls them separately), same inputs, rank-local
+    def half(fn):
+        fn(); torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        ev[0].record()
+        for i in range(args.steps):
+            fn()
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
+        med = ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2])
+        return {"ms_median": round(med, 3), "ms_mean": round(sum(ms) / len(ms), 3), "x_realtime_median": round(B * seconds / (med * 1e-3), 1)}
+    if snac_mode:
+        enc_only = half(lambda: model.encode(pcm))
+        dec_only = half(lambda: model.decode(codes, noise))
+    else:
+        enc_only = half(lambda: model.encode(pcm))
+        dec_only = half(lambda: model.decode(z))
+
     audio_seconds = world * B * seconds * args.steps
     value = audio_seconds / dt
     ms_per_step = dt / args.steps * 1e3
+    sms = sorted(step_ms)
+    med_ms = sms[len(sms) // 2] if len(sms) % 2 else 0.5 * (sms[len(sms) // 2 - 1] + sms[len(sms) // 2])   # this rank's per-step GPU times
 
     if rank == 0:
         classes = class_table(prof, args.steps)
@@ -364,20 +400,21 @@ def main():
             # the C restatement of the reference graph on this box's host cores, in this run: one warm-up pass, then
             # --cpu-iters timed passes over a bounded sample of the step's clips; median
             import statistics
-            n = max(1, min(args.cpu_clips if not snac_mode else 1, B))
+            n = max(1, min((args.cpu_clips or B) if not snac_mode else 1, B))
+            nw = min(2, n)                                       # warm-up: pages the weights in and spins the OpenMP team up
             if snac_mode:
                 ref = c_oracle.RefSNAC(cfg, blob)
 
-                def cpu_pass():
+                def cpu_pass(n=n):
                     _, _, rc = ref.encode(pcm_h[:n])
                     return rc, ref.decode(rc, [x[:n] for x in noise_h])
             else:
                 ref = c_oracle.RefDAC(cfg, blob)
 
-                def cpu_pass():
+                def cpu_pass(n=n):
                     rz, rc, _, _ = ref.encode(pcm_h[:n])
                     return rc, ref.decode(rz)
-            cpu_pass()
+            cpu_pass(nw)
             ctimes = []
             for _ in range(max(1, args.cpu_iters)):
                 tc = time.perf_counter()
@@ -387,7 +424,8 @@ def main():
             cpu = {"value": round(n * seconds / cdt, 4), "unit": "audio-seconds/sec", "cores": int(c_oracle.lib().ref_num_threads()),
                    "kind": "port", "cpu": cpu_model(), "host_cpus": os.cpu_count(), "iterations": len(ctimes), "median_s": round(cdt, 3),
                    "min_s": round(min(ctimes), 3), "max_s": round(max(ctimes), 3),
-                   "sample": f"{n} of the {B} clips of one step (encode+decode, C oracle with OpenMP): 1 warm-up + {len(ctimes)} timed passes, median"}
+                   "sample": f"{n} of the {B} clips of one step (encode+decode, C oracle, OpenMP over clips x output channels): "
+                             f"warm-up on {nw} clips + {len(ctimes)} timed pass(es) over the sample, median"}
             if not args.no_check:
                 if snac_mode:
                     same_codes = all(np.array_equal(c[:n].cpu().numpy(), r) for c, r in zip(codes, rcodes))
@@ -397,7 +435,7 @@ def main():
                                             "pcm_max_abs_diff": float(np.abs(audio[:n].cpu().numpy() - raudio).max())}
             if not snac_mode:
                 try:
-                    cpu["aten_proxy"] = aten_proxy(cfg, sd, pcm_h[:min(2, B)], seconds, args.cpu_iters)
+                    cpu["aten_proxy"] = aten_proxy(cfg, sd, pcm_h[:min(2, B)], seconds, args.proxy_iters)
                 except Exception as e:   # the proxy is informational: never lose the bench line to it
                     cpu["aten_proxy"] = {"error": repr(e)}
         if snac_mode:
@@ -411,7 +449,10 @@ def main():
         out = {
             "metric": metric,
             "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "ms_per_step_median": round(med_ms, 3), "value_at_median_step": round(world * B * seconds / (med_ms * 1e-3), 2),
+            "ms_per_step_min_max": [round(min(step_ms), 3), round(max(step_ms), 3)],
+            "encode_only": enc_only, "decode_only": dec_only,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "clips_per_gpu": B, "clip_seconds": seconds, "global_batch": world * B,
                        "collective": coll if use_dist else "none"},

@@ -129,16 +129,18 @@ public sealed unsafe class EncodecNative : INeuralCodec
         if (frames.Count == 0) throw new ArgumentException("No frames provided to decode");              // Encodec.cs:215-218
         if (SegmentLength == null && frames.Count != 1)
             throw new ArgumentException("Expected single frame when no segmentation is used");              // Encodec.cs:222-225
-        long T;
-        NcMi355x.Check(NcMi355x.nc_encodec_clip_length(_h, frames.Count, frames[^1].frames, &T));
+        long T, dec;
         int nFrames, nQq;
-        long dec;
-        var lens = new long[frames.Count];
-        fixed (long* pl = lens) NcMi355x.Check(NcMi355x.nc_encodec_query(_h, T, &nFrames, &nQq, pl, frames.Count, &dec));
+        var lens = frames.ConvertAll(f => f.frames).ToArray();
+        fixed (long* pl = lens)
+        {
+            NcMi355x.Check(NcMi355x.nc_encodec_clip_length(_h, frames.Count, pl, &T));   // NC_EINVAL: no clip is cut into frames of these lengths
+            NcMi355x.Check(NcMi355x.nc_encodec_query(_h, T, &nFrames, &nQq, null, 0, &dec));
+        }
         int nQ = frames[0].nQ;
         for (int f = 0; f < frames.Count; ++f)
-            if (frames[f].frames != lens[f] || frames[f].nQ != nQ || frames[f].codes.Length != (long)B * nQ * lens[f])
-                throw new ArgumentException($"Frame {f} does not match the segment layout: expected [{B}, {nQ}, {lens[f]}] codes");
+            if (frames[f].nQ != nQ || frames[f].codes.Length != (long)B * nQ * lens[f])
+                throw new ArgumentException($"Frame {f}: expected [{B}, {nQ}, {lens[f]}] codes");
         var codes = new long[frames.Sum(f => (long)f.codes.Length)];
         var scales = new float[frames.Count * B];
         long off = 0;

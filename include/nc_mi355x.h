@@ -236,10 +236,10 @@ NC_API nc_status nc_encodec_set_bandwidth(nc_codec* h, float bandwidth_kbps);
 NC_API nc_status nc_encodec_query(const nc_codec* h, int64_t T, int32_t* n_frames, int32_t* n_q, int64_t* frame_lens, int32_t cap,
                                   int64_t* decoded_len);
 /* The reference's Decode(List<EncodedFrame>) takes no clip length (Models/Encodec.cs:213-235: the frames alone fix the output,
- * (n-1)*stride + decoded(last frame)).  This gives the smallest clip length T whose segment layout is `n_frames` segments with
- * `tail_frames` code frames in the last one -- the T to hand to nc_encodec_decode for such a list.  NC_EINVAL when no clip length
- * produces that layout. */
-NC_API nc_status nc_encodec_clip_length(const nc_codec* h, int32_t n_frames, int64_t tail_frames, int64_t* T);
+ * (n-1)*stride + decoded(last frame)).  This gives the smallest clip length T whose segment layout is exactly `n_frames` segments
+ * with frame_lens[i] code frames in segment i (with overlapping segments the last TWO can be short) -- the T to hand to
+ * nc_encodec_decode for such a list.  NC_EINVAL when no clip length produces that layout. */
+NC_API nc_status nc_encodec_clip_length(const nc_codec* h, int32_t n_frames, const int64_t* frame_lens, int64_t* T);
 
 /* replaces: Encodec.Encode(Tensor x[B,C,T]) -> List<EncodedFrame>     Models/Encodec.cs:259-285, EncodeFrame :457-489
  *   codes  int64: the EncodedFrame.Codes tensors [B,n_q,T'_f] laid end to end in segment order

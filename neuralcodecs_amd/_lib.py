@@ -105,7 +105,7 @@ SYMBOLS = [
     ("nc_encodec_set_bandwidth", C.c_int, [_P, C.c_float]),
     ("nc_encodec_query", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_int32,
                                    C.POINTER(C.c_int64)]),
-    ("nc_encodec_clip_length", C.c_int, [_P, C.c_int32, C.c_int64, C.POINTER(C.c_int64)]),
+    ("nc_encodec_clip_length", C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("nc_encodec_encode", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
     ("nc_encodec_encode_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
     ("nc_encodec_decode", C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),

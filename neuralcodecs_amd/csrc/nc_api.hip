@@ -474,11 +474,13 @@ nc_status nc_encodec_query(const nc_codec* h, int64_t T, int32_t* n_frames, int3
     });
 }
 
-nc_status nc_encodec_clip_length(const nc_codec* h, int32_t n_frames, int64_t tail_frames, int64_t* T) {
+nc_status nc_encodec_clip_length(const nc_codec* h, int32_t n_frames, const int64_t* frame_lens, int64_t* T) {
     return guard([&] {
         EncodecModel& m = as_encodec(const_cast<nc_codec*>(h));
-        if (!T) fail(NC_EINVAL, "T must not be null");
-        if (n_frames <= 0 || tail_frames <= 0) fail(NC_EINVAL, "No frames provided to decode");   // Encodec.cs:215-218
+        if (!T || !frame_lens) fail(NC_EINVAL, "frame_lens and T must not be null");
+        if (n_frames <= 0) fail(NC_EINVAL, "No frames provided to decode");                               // Encodec.cs:215-218
+        const int64_t tail_frames = frame_lens[n_frames - 1];
+        if (tail_frames <= 0) fail(NC_EINVAL, "a frame without codes");
         if (m.cfg.segment_length <= 0) {
             if (n_frames != 1) fail(NC_EINVAL, "Expected single frame when no segmentation is used");   // Encodec.cs:222-225
             for (int64_t L = std::max<int64_t>(1, (tail_frames - 2) * m.hop); L <= (tail_frames + 1) * m.hop; ++L)
@@ -486,9 +488,14 @@ nc_status nc_encodec_clip_length(const nc_codec* h, int32_t n_frames, int64_t ta
             fail(NC_EINVAL, "no clip length yields %lld frames", (long long)tail_frames);
         }
         const int64_t base = (int64_t)(n_frames - 1) * m.cfg.segment_stride;
-        for (int64_t tail = 1; tail <= m.cfg.segment_stride; ++tail)   // a longer tail would start another segment (Encodec.cs:278-282)
-            if (m.frames_for(std::min<int64_t>(tail, m.cfg.segment_length)) == tail_frames) { *T = base + tail; return; }
-        fail(NC_EINVAL, "no clip length yields %d segments with %lld frames in the last", n_frames, (long long)tail_frames);
+        for (int64_t tail = 1; tail <= m.cfg.segment_stride; ++tail) {   // a longer tail would start another segment (Encodec.cs:278-282)
+            if (m.frames_for(std::min<int64_t>(tail, m.cfg.segment_length)) != tail_frames) continue;
+            const auto segs = m.segments(base + tail);                    // the segments before the last can be cut short by the clip end too
+            bool same = (int32_t)segs.size() == n_frames;
+            for (int32_t i = 0; same && i < n_frames; ++i) same = segs[(size_t)i].frames == frame_lens[i];
+            if (same) { *T = base + tail; return; }
+        }
+        fail(NC_EINVAL, "no clip length yields this layout of %d segments (%lld frames in the last)", n_frames, (long long)tail_frames);
     });
 }
 

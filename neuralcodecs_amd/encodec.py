@@ -205,9 +205,10 @@ class Encodec(_lib.ProfileMixin):
 
     def _infer_length(self, frames) -> int:
         """Clip length implied by the frames alone, as the reference's Decode(List<EncodedFrame>) sees them (Encodec.cs:213-235):
-        the smallest T with this many segments and this many code frames in the last (nc_encodec_clip_length)."""
+        the smallest T whose segment layout has exactly these frame counts (nc_encodec_clip_length)."""
         T = C.c_int64()
-        _lib.check(_lib.lib().nc_encodec_clip_length(self._h, len(frames), int(frames[-1].codes.shape[-1]), C.byref(T)))
+        lens = (C.c_int64 * len(frames))(*[int(f.codes.shape[-1]) for f in frames])
+        _lib.check(_lib.lib().nc_encodec_clip_length(self._h, len(frames), lens, C.byref(T)))
         return T.value
 
     def forward(self, x):

@@ -92,3 +92,28 @@ def test_parity_under_fallback_switches(row):
            os.path.join(ROOT, "tests", "test_snac_gpu.py")]
     r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
+
+
+# The driver's first multi-GPU run launches bench.py under torch.distributed.run with no chance to debug it; the SAME code path
+# (process group on RCCL, side-stream all-gather of the codes, barrier + max-over-ranks timing, every-slot verification, one JSON line)
+# runs with a single rank under NC_BENCH_FORCE_DIST=1 -- in a fresh child created before this process touches the GPU.
+@pytest.mark.parametrize("config,steps", [("dac44k", 2), ("snac44k", 1)])
+def test_bench_distributed_path_one_rank(config, steps):
+    import json
+    import socket
+    with socket.socket() as s:                                   # a free rendezvous port: several test processes may share a host
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    e = dict(os.environ, NC_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+             HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-extra",
+           "--config", config]
+    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # exactly ONE JSON line, after RCCL's banner
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == steps and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["collective"].startswith("RCCL all_gather")
+    assert out["config"]["gathered_equals_1gpu_every_slot_every_rank"] is True
+    assert out["encode_only"]["ms_median"] > 0 and out["decode_only"]["ms_median"] > 0 and out["ms_per_step_median"] > 0

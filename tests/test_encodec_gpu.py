@@ -117,7 +117,7 @@ def test_encodec_errors_ragged_and_device_api():
         assert Ti <= T and m.query(Ti)[0] == len(fr) and m.query(Ti)[2] == [f.codes.shape[-1] for f in fr]
         assert np.array_equal(m.decode(fr), m.decode(fr, T))
     with pytest.raises(ValueError):
-        m._infer_length([EncodedFrame(np.zeros((1, 2, 10 ** 6), np.int64), None)])   # no clip yields that tail
+        m._infer_length([EncodedFrame(np.zeros((1, 2, 10 ** 6), np.int64), None)])   # no clip yields that layout
     pcm = synthetic_pcm(3, 2, 5000, cfg.sampling_rate, seed=1)
     frames = m.encode(pcm)
     one = m.encode(pcm[2:3])
