@@ -14,6 +14,7 @@
 #include "nc_gn.h"
 #include "nc_math.h"
 #include "nc_model.h"
+#include "nc_lstm.h"
 
 namespace nc {
 
@@ -809,6 +810,16 @@ void EncodecModel::load_lstm(const Blob& b, const std::string& key, Lstm& l, int
             upload(y.whhp, pk.data(), pk.size());
         }
         upload(y.bhh, static_cast<const float*>(bhh.data), (size_t)4 * C);
+        upload(y.bih, static_cast<const float*>(bih.data), (size_t)4 * C);
+        if (lstm2_supported(C) && cfg.lstm_layers == 2) {   // images of the fused two-layer kernel: W_hh of both layers, W_ih of the upper one
+            std::vector<float> img((size_t)4 * C * C);
+            lstm2_pack_image(static_cast<const float*>(whh.data), C, img.data());
+            upload(y.w2hh, img.data(), img.size());
+            if (i == 1) {
+                lstm2_pack_image(static_cast<const float*>(wih.data), C, img.data());
+                upload(y.w2ih, img.data(), img.size());
+            }
+        }
     }
 }
 
@@ -1113,6 +1124,69 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
         io.y = gi; io.y_bstride = (int64_t)4 * C * T; io.y_cstride = T;
         launch_conv(y.ih, io, N, s, &prof);
     };
+    // Fused two-layer launch (nc_lstm.hip): every step of both layers in ONE persistent launch per pair of column tiles -- no drain in
+    // the exchange, no tensors between the layers, no chunked projection GEMMs.  C / 4 workgroups of 8 wavefronts per tile must be
+    // co-resident (128 CUs at C = 512).  NC_LSTM_PER_LAYER=1 switches back to the per-layer kernels below.
+    static const bool per_layer_env = std::getenv("NC_LSTM_PER_LAYER") && std::getenv("NC_LSTM_PER_LAYER")[0] == '1';
+    const int n_tiles2 = (N + 15) / 16;
+    const size_t ex_floats = lstm2_exchange_floats(C, T, std::min(n_tiles2, 2));
+    if (!stepwise && !per_layer_env && nl == 2 && lstm2_supported(C) && l.layers[1]->w2ih.p && cu_count >= C / 4 &&
+        lds_per_cu >= lstm2_lds_bytes(C, std::min(n_tiles2, 2)) && ex_floats * 4 < ((size_t)1 << 31) && (int64_t)4 * C * T * N < ((int64_t)1 << 31)) {
+        {   // NC_LSTM_FAKE_TIMEOUT=1 (tests): the first persistent launch of the process is reported as timed out
+            static bool fake = std::getenv("NC_LSTM_FAKE_TIMEOUT") && std::getenv("NC_LSTM_FAKE_TIMEOUT")[0] == '1';
+            if (fake) { fake = false; *reinterpret_cast<volatile unsigned*>(lstm_tmo_host) = 1; }
+        }
+        // layer 0's input projections of ALL steps as one pointwise GEMM over the [C][T][N] view of x: gi0 [4C][T][N]
+        float* xT = alloc((size_t)N * C * T);
+        float* gi0 = alloc((size_t)N * 4 * C * T);
+        float* out = alloc((size_t)N * C * T);
+        {
+            const int64_t n = (int64_t)N * C * T;
+            hipLaunchKernelGGL(nct_to_ctn_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, xT, N, C, T);
+            NC_HIP(hipGetLastError());
+            ConvIO io{};
+            io.x = xT; io.x_bstride = 0; io.x_cstride = T * N; io.x_len = (int32_t)(T * N); io.Tin = T * N;
+            io.y = gi0; io.y_bstride = 0; io.y_cstride = T * N;
+            launch_conv(l.layers[0]->ih, io, 1, stream, &prof);
+        }
+        for (int tl = 0; tl < n_tiles2; tl += 2) {
+            const int nt = std::min(2, n_tiles2 - tl);
+            const size_t exf = lstm2_exchange_floats(C, T, nt);
+            float* S = alloc(exf);
+            unsigned* flags = reinterpret_cast<unsigned*>(alloc((size_t)nt * 2 * (C / 4)));
+            NC_HIP(hipMemsetAsync(S, 0xFF, exf * 4, stream));                       // LSTM2_SENTINEL in every word
+            NC_HIP(hipMemsetAsync(flags, 0, (size_t)nt * 2 * (C / 4) * 4, stream));
+            Lstm2Args a{};
+            a.gi0 = gi0; a.whh0 = l.layers[0]->w2hh.as<float>(); a.wih1 = l.layers[1]->w2ih.as<float>(); a.whh1 = l.layers[1]->w2hh.as<float>();
+            a.bhh0 = l.layers[0]->bhh.as<float>(); a.bih1 = l.layers[1]->bih.as<float>(); a.bhh1 = l.layers[1]->bhh.as<float>();
+            a.skip = x; a.out = out; a.elu_out = elu_out ? 1 : 0; a.S = S; a.flags = flags; a.tmo = lstm_tmo_dev;
+            a.N = N; a.C = C; a.T = T; a.tile0 = tl; a.tiles = nt;
+            const double nn = (double)std::min(N - tl * 16, nt * 16) * (double)T;
+            if (prof.on) prof.begin(stream, NC_KC_LSTM, 2.0 * 3 * 4 * C * C * nn, 4.0 * 8 * C * nn);   // W_hh0, W_ih1, W_hh1 contractions
+            static const char* trace_path = std::getenv("NC_LSTM2_TRACE");   // diagnostic: stamps of 8 steps of the first full-size launch
+            static bool traced = false;
+            const size_t trace_words = (size_t)(C / 4) * nt * 8 * LSTM2_TRACE_STEPS * 4 + 4;   // + the clock probe
+            if (trace_path && !traced && T >= LSTM2_TRACE_T0 + LSTM2_TRACE_STEPS) {
+                a.trace = reinterpret_cast<unsigned long long*>(alloc(trace_words * 2));
+                NC_HIP(hipMemsetAsync(a.trace, 0, trace_words * 8, stream));
+            }
+            lstm2_launch(a, stream);
+            if (prof.on) prof.end(stream);
+            if (a.trace) {
+                traced = true;
+                std::vector<unsigned long long> hbuf(trace_words);
+                NC_HIP(hipStreamSynchronize(stream));
+                NC_HIP(hipMemcpy(hbuf.data(), a.trace, trace_words * 8, hipMemcpyDeviceToHost));
+                if (FILE* f = std::fopen(trace_path, "wb")) {
+                    const int hdr[4] = {C / 4, nt, 8, LSTM2_TRACE_STEPS};
+                    std::fwrite(hdr, sizeof(int), 4, f);
+                    std::fwrite(hbuf.data(), 8, trace_words, f);
+                    std::fclose(f);
+                }
+            }
+        }
+        return out;
+    }
     if (!stepwise && C % 64 == 0 && (KS == 128 || KS == 16)) {
         // Persistent layer kernel: a launch runs a range of steps for a group of column tiles (<= 64 co-resident workgroups, so the
         // two layers of a pipelined call plus a concurrent segment group still fit the chip's 256 CUs at one workgroup per CU).

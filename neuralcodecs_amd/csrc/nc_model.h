@@ -201,7 +201,7 @@ struct EncodecModel : Codec {
         DevBuf gamma, beta;
     };
     struct ResBlock { SConv c1, c2, sc; };
-    struct LstmLayer { ConvLayer ih; DevBuf whh, whhp, bhh; };
+    struct LstmLayer { ConvLayer ih; DevBuf whh, whhp, bhh, bih, w2hh, w2ih; };   // w2*: fragment images of the fused two-layer kernel (nc_lstm.h)
     struct Lstm { int C = 0; std::vector<std::unique_ptr<LstmLayer>> layers; };
     struct Plan { int64_t left = 0, right = 0, Lz = 0, Lp = 0, Lout = 0; };
     struct Seg { int64_t off = 0, len = 0, frames = 0; };
