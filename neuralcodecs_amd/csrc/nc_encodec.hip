@@ -1124,10 +1124,14 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
         io.y = gi; io.y_bstride = (int64_t)4 * C * T; io.y_cstride = T;
         launch_conv(y.ih, io, N, s, &prof);
     };
-    // Fused two-layer launch (nc_lstm.hip): every step of both layers in ONE persistent launch per pair of column tiles -- no drain in
-    // the exchange, no tensors between the layers, no chunked projection GEMMs.  C / 4 workgroups of 8 wavefronts per tile must be
-    // co-resident (128 CUs at C = 512).  NC_LSTM_PER_LAYER=1 switches back to the per-layer kernels below.
-    static const bool per_layer_env = std::getenv("NC_LSTM_PER_LAYER") && std::getenv("NC_LSTM_PER_LAYER")[0] == '1';
+    // Fused two-layer launch (nc_lstm.hip, NC_LSTM_FUSED=1): every step of both layers in ONE persistent launch per pair of column tiles
+    // -- no drain in the exchange (values validated against a sentinel), chain wavefronts that never store, no tensors between the
+    // layers, no chunked projection GEMMs.  Bit-exact, but MEASURED SLOWER than the per-layer kernels below on two tiles (C3 9.5-9.8
+    // against 9.05 ms; 16 clips at 24 kHz 5.4-5.9 against 5.67 ms): with C / 4 = 128 workgroups in every exchange a step is 9.8-12 us
+    // (in-kernel trace, tools/probe/lstm2_trace.py: publish -> flags seen 2.6-3.4 us, operand loads 1.4-2.2 us, and the workgroups
+    // drift 3.5-5 us apart inside a step) against 5.7-6.2 us for an exchange among 32.  Kept as a switch, not the default: DESIGN 8.
+    static const bool fused_env = std::getenv("NC_LSTM_FUSED") && std::getenv("NC_LSTM_FUSED")[0] == '1';
+    const bool per_layer_env = !fused_env;
     const int n_tiles2 = (N + 15) / 16;
     const size_t ex_floats = lstm2_exchange_floats(C, T, std::min(n_tiles2, 2));
     if (!stepwise && !per_layer_env && nl == 2 && lstm2_supported(C) && l.layers[1]->w2ih.p && cu_count >= C / 4 &&
