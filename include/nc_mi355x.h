@@ -51,6 +51,10 @@ NC_API const char* nc_last_error(void);
 NC_API const char* nc_version(void);
 /* number of HIP devices visible (0 when none); never fails */
 NC_API int nc_device_count(void);
+/* Every diagnostic environment switch the engine reads, one "NAME\tkind\twhat it does\n" line each; kind b = set to 1,
+ * p = set at all, i = integer, s = string.  None of them changes a result (every path is bit-exact against the oracle); they exist so
+ * that an A/B on one box is one environment variable.  The engine refuses to read a switch that is not in this table. */
+NC_API const char* nc_debug_switches(void);
 
 /* ------------------------------------------------------------------------------------------ DAC
  * replaces: new DAC(DACConfig)                    NeuralCodecs.Torch/Models/DAC.cs:51-93

@@ -66,6 +66,7 @@ SYMBOLS = [
     ("nc_last_error", C.c_char_p, []),
     ("nc_version", C.c_char_p, []),
     ("nc_device_count", C.c_int, []),
+    ("nc_debug_switches", C.c_char_p, []),
     ("nc_dac_create", C.c_int, [C.POINTER(NcDacConfig), C.c_int, C.POINTER(_P)]),
     ("nc_codec_destroy", C.c_int, [_P]),
     ("nc_codec_load_weights", C.c_int, [_P, C.c_char_p]),
@@ -150,15 +151,16 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise NcError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = os.environ.get("NC_MI355X_LIB") or LIB_PATH          # (diagnostic: A/B of library builds, tools/probe/ab_libs*.sh)
+    if not os.path.exists(path):
+        raise NcError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(make -C neuralcodecs_amd/csrc). There is no fallback implementation.")
     if "torch" not in sys.modules:
         try:
             import torch  # noqa: F401  (shares its HIP runtime with the engine)
         except Exception:
             pass
-    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL)
     for name, res, args in SYMBOLS:
         fn = getattr(L, name)
         fn.restype = res

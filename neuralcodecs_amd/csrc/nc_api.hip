@@ -56,6 +56,8 @@ extern "C" {
 const char* nc_last_error(void) { return get_last_error(); }
 const char* nc_version(void) { return "nc_mi355x 0.1 (gfx950)"; }
 
+const char* nc_debug_switches(void) { return env_switch_table(); }
+
 int nc_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -519,6 +521,7 @@ nc_status nc_encodec_encode(nc_codec* h, const float* pcm, int32_t B, int64_t T,
         const size_t n_in = (size_t)B * m.cfg.channels * T * 4, n_codes = (size_t)B * m.n_q * fr * 8, n_sc = segs.size() * (size_t)B * 4,
                      n_emb = (size_t)B * m.cfg.dimension * fr * 4;
         m.h_in.reserve(n_in); m.h_codes.reserve(n_codes); m.h_scales.reserve(n_sc); m.h_emb.reserve(n_emb);
+        m.absorb_stale_timeout();
         h2d(m.h_in.p, pcm, n_in, m.stream);
         for (int attempt = 0;; ++attempt) {
             m.encode_dev(m.h_in.as<float>(), B, T, m.h_codes.as<int64_t>(), m.h_scales.as<float>(), emb ? m.h_emb.as<float>() : nullptr);
@@ -549,6 +552,7 @@ nc_status nc_encodec_decode(nc_codec* h, const int64_t* codes, const float* scal
                                                        : (int64_t)m.cfg.segment_stride * ((int64_t)segs.size() - 1) + m.decoded_for(segs.back().frames);
         const size_t n_codes = (size_t)B * n_q * fr * 8, n_sc = segs.size() * (size_t)B * 4, n_out = (size_t)B * m.cfg.channels * Lout * 4;
         m.h_codes.reserve(n_codes); m.h_scales.reserve(n_sc); m.h_out.reserve(n_out);
+        m.absorb_stale_timeout();
         h2d(m.h_codes.p, codes, n_codes, m.stream);
         if (scales) h2d(m.h_scales.p, scales, n_sc, m.stream);
         for (int attempt = 0;; ++attempt) {

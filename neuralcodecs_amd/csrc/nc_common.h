@@ -39,6 +39,16 @@ struct Error : std::runtime_error {
 
 void set_last_error(const char* msg);
 
+// Diagnostic switches (environment): ONE table in nc_util.hip holds every name the engine reads, its kind and what it
+// switches.  The accessors fail on a name the table does not hold, so a switch cannot exist without its row; nc_debug_switches()
+// (C ABI) lists the table, which is what tools/probe/envmatrix.sh enumerates and tests/test_abi_cpu.py holds DESIGN.md to.
+// Call sites keep their `static const` caches: a switch is read once per process.
+bool env_flag(const char* name);                  // kind 'b': set to 1
+bool env_present(const char* name);               // kind 'p': set at all
+long env_int(const char* name, long dflt);        // kind 'i'
+const char* env_str(const char* name);            // kind 's': nullptr when unset
+const char* env_switch_table();                   // "NAME\tkind\twhat it does\n" per switch
+
 // Opt a kernel into > 64 KB of dynamic LDS on the CURRENT device.  The attribute is per (device, function): the cache is keyed on
 // both and guarded, so models on different GPUs (and host threads calling in concurrently) each get their opt-in.
 void ensure_dynamic_lds(const void* fn, size_t bytes);

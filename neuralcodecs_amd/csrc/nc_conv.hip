@@ -47,7 +47,7 @@ conv_kernel_fn conv_kernel_table_light_k7(int, int);
 conv_kernel_fn conv_kernel_table_wide_k7(int, int);
 conv_kernel_fn conv_kernel_table_spec_k7(int, int);
 conv_kernel_fn conv_kernel_table_dist_k7(int, int);
-static int experiment_mode(const char* name) { const char* v = std::getenv(name); return v ? atoi(v) : 0; }
+static int experiment_mode(const char* name) { return (int)env_int(name, 0); }
 #else
 static conv_kernel_fn conv_kernel_table_light_k7(int, int) { return nullptr; }
 static conv_kernel_fn conv_kernel_table_wide_k7(int, int) { return nullptr; }
@@ -152,8 +152,7 @@ TileCfg pick_tile(int Cout, int Ktaps) {
             c.TM = tm;
         }
     }
-    if (const char* e = std::getenv("NC_TM_FORCE")) {   // experiment: force the row-tile height where it divides Cout
-        const int tm = atoi(e);
+    if (const int tm = (int)env_int("NC_TM_FORCE", 0)) {   // experiment: force the row-tile height where it divides Cout
         if (tm >= 1 && tm <= 4 && Cout % (32 * tm) == 0) c.TM = tm;
     }
     c.TN = 2;
@@ -183,7 +182,7 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
         Ktaps = (K + stride - 1) / stride;
         // sub-pixel form (one launch, rows = (channel, phase)): power-of-two strides with two taps per phase, i.e. the k = 2s
         // up-convolutions of DAC / SNAC (DecoderBlock.cs:27-33); other strides keep the per-phase launches
-        static const bool no_sub = std::getenv("NC_NO_SUBPIXEL") && std::getenv("NC_NO_SUBPIXEL")[0] == '1';
+        static const bool no_sub = env_flag("NC_NO_SUBPIXEL");
         if (!no_sub && (stride == 2 || stride == 4 || stride == 8) && K == 2 * stride && (Cout * stride) % 32 == 0 && out_pad == 0) {
             sub_shift = stride == 2 ? 1 : stride == 4 ? 2 : 3;
             sub_stride = stride;
@@ -191,7 +190,7 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
         }
         // ... and the same form for the other strides (SNAC's stride-3 and Encodec's stride-5 up-convolutions, k = 2s): one launch with
         // full row tiles instead of s launches that each write every s-th sample (NC_NO_SUBPIXEL_ANY=1: per-phase launches)
-        static const bool no_sub_any = std::getenv("NC_NO_SUBPIXEL_ANY") && std::getenv("NC_NO_SUBPIXEL_ANY")[0] == '1';
+        static const bool no_sub_any = env_flag("NC_NO_SUBPIXEL_ANY");
         // (output_padding -- stride % 2 in SNAC's DecoderBlock -- only moves the right crop: the extra samples lie inside the (Tin + 1) * s
         // samples the rows cover as long as out_pad <= pad, and the store bounds come from out_len())
         if (!no_sub && !no_sub_any && !sub_stride && stride >= 3 && stride <= 16 && K == 2 * stride && (Cout * stride) % 32 == 0 && out_pad <= pad) {
@@ -238,7 +237,7 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
     };
     pack(cfg, w, w_phase_stride);
     alts.clear();
-    static const bool no_alts = std::getenv("NC_NO_TILE_ALTS") && std::getenv("NC_NO_TILE_ALTS")[0] == '1';
+    static const bool no_alts = env_flag("NC_NO_TILE_ALTS");
     if (!no_alts && rows() >= 128)
         for (int tm = 3; tm >= 1; --tm) {   // (single-row-block tiles: slower on every filled grid, chosen only for the tiny grids of choose_tile)
             if (tm == cfg.TM || rows() % (32 * tm) != 0) continue;
@@ -248,7 +247,7 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
             pack(alts.back()->cfg, alts.back()->w, alts.back()->w_phase_stride);
         }
     // whole-channel tile of the wide fused residual units (C = 192 / 256 -> TM = 6 / 8; launched only through ConvIO::fuse_k1)
-    static const bool no_wide_fuse = std::getenv("NC_NO_WIDE_FUSE") && std::getenv("NC_NO_WIDE_FUSE")[0] == '1';
+    static const bool no_wide_fuse = env_flag("NC_NO_WIDE_FUSE");
     const bool wide_c = Cin == Cout && (Cout == 256 || Cout == 192);
     if (!no_alts && !no_wide_fuse && !transposed && K == 7 && stride == 1 && wide_c) {
         alts.emplace_back(new Alt());
@@ -281,7 +280,7 @@ void ConvLayer::build(const float* dense_w, const float* bias_h, int Cin_, int C
         NC_HIP(hipMemcpy(w_stem.p, dense_w, sizeof(float) * (size_t)Cout * K, hipMemcpyHostToDevice));
     }
     {   // image for the short-row kernel (nc_conv_small.hip): the strided down-convolutions, taken when a launch has few columns
-        static const bool no_small = std::getenv("NC_NO_CONV_SMALL") && std::getenv("NC_NO_CONV_SMALL")[0] == '1';
+        static const bool no_small = env_flag("NC_NO_CONV_SMALL");
         if (!no_small && conv_small_eligible(Cin, Cout, K, stride, dil, transposed)) {
             std::vector<float> img;
             pack_conv_small(dense_w, Cin, Cout, K, img);
@@ -333,8 +332,8 @@ static TileChoice choose_tile(const ConvLayer& L, int64_t blocks_per_rowtile, bo
     {   // Tiny grids (one-clip / short-row launches: even with 32-row tiles every workgroup gets a CU of its own): a workgroup's life is
         // its serial reduction, TM matrix-core chains long per step, so the SMALLEST row tile finishes first -- SNAC 24 kHz at one clip:
         // the 384 -> 768 k=16 down-convolution ran 8 workgroups of 96 rows for 450 us (C1: 2.85 ms in all).
-        static const bool no_tiny = std::getenv("NC_NO_TINY_TILES") && std::getenv("NC_NO_TINY_TILES")[0] == '1';
-        static const int tiny_blocks = std::getenv("NC_TINY_BLOCKS") ? atoi(std::getenv("NC_TINY_BLOCKS")) : 256;
+        static const bool no_tiny = env_flag("NC_NO_TINY_TILES");
+        static const int tiny_blocks = (int)env_int("NC_TINY_BLOCKS", 256);
         if (!no_tiny) {
             // the smallest packed row tile whose grid still stays under `tiny_blocks` workgroups
             int tm = 0;
@@ -346,7 +345,7 @@ static TileChoice choose_tile(const ConvLayer& L, int64_t blocks_per_rowtile, bo
             if (tm) return best;
         }
     }
-    static const int tm_pick = std::getenv("NC_TM_PICK") ? atoi(std::getenv("NC_TM_PICK")) : 0;   // experiment: force a packed variant
+    static const int tm_pick = (int)env_int("NC_TM_PICK", 0);   // experiment: force a packed variant
     if (tm_pick) {
         for (const auto& a : L.alts)
             if (a->cfg.TM == tm_pick && tm_pick <= 4) return TileChoice{a->cfg, a->w.as<float>(), a->w_phase_stride};
@@ -371,7 +370,7 @@ static TileChoice choose_tile(const ConvLayer& L, int64_t blocks_per_rowtile, bo
 // Measured (PMC FETCH_SIZE, DAC C2): G = 1 -> 2 on the C = 384 k = 7 layers 1156 -> 709 MiB per launch, as this model predicts.
 // NC_CO_GROUP=<n> caps the group size (1 = one panel per XCD, the round-1 order).
 static int pick_co_group(int n_co_tiles, double x_bytes, double w_bytes, double n_col_tiles) {
-    static const int cap = std::getenv("NC_CO_GROUP") ? atoi(std::getenv("NC_CO_GROUP")) : 0;
+    static const int cap = (int)env_int("NC_CO_GROUP", 0);
     int best = 1;
     double bt = 0.0;
     for (int g = 1; g <= std::min(n_co_tiles, cap > 0 ? cap : 8); ++g) {
@@ -386,7 +385,7 @@ static int pick_co_group(int n_co_tiles, double x_bytes, double w_bytes, double 
 // pending GroupNorm + ELU applied once per element in registers, no LDS for the activations.
 conv_kernel_fn conv3_stream_kernel_table(int, bool);
 static bool launch_conv3_stream(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream, Profiler* prof) {
-    static const bool off = std::getenv("NC_NO_CONV3S") && std::getenv("NC_NO_CONV3S")[0] == '1';
+    static const bool off = env_flag("NC_NO_CONV3S");
     if (off || L.transposed || L.K != 3 || L.stride != 1 || L.dil != 1 || L.pad != 0 || L.cfg.CB != 16 || (L.Cin & 1) || L.Cin > 512) return false;
     if (io.alpha_in || io.alpha_out || io.res || io.epi || io.fuse_k1 || io.x2 || io.noise) return false;
     // the Encodec input mode with the non-causal pad of a k = 3, stride 1 SConv1d: one reflected sample on either side, no zero extension
@@ -425,7 +424,7 @@ static bool launch_conv3_stream(const ConvLayer& L, const ConvIO& io, int B, hip
 
 // Pointwise fast path (nc_conv1x1.hip): B fragments straight from global memory, 2-wide vector loads/stores.
 static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream, Profiler* prof) {
-    static const bool off = std::getenv("NC_NO_CONV1X1") && std::getenv("NC_NO_CONV1X1")[0] == '1';
+    static const bool off = env_flag("NC_NO_CONV1X1");
     const int64_t T = io.Tin;
     if (off || L.transposed || L.K != 1 || L.stride != 1 || L.pad != 0 || L.cfg.CB != 16 || io.fuse_k1 || (L.Cin & 1)) return false;
     if (io.alpha_in || (io.epi & ~EPI_NOISE) || T < 2 || (T & 1) || io.x_len != T) return false;
@@ -459,7 +458,7 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
     int64_t grid = (int64_t)a.n_co_tiles * B * a.n_t_tiles;
     size_t lds = 0;
     {   // streaming variant: narrow long rows, whole weight tile of a row tile resident in LDS (see conv1x1_stream_kernel)
-        static const bool no_stream = std::getenv("NC_NO_PW_STREAM") && std::getenv("NC_NO_PW_STREAM")[0] == '1';
+        static const bool no_stream = env_flag("NC_NO_PW_STREAM");
         const size_t need = sizeof(float) * ((size_t)L.Cin * BM + 3 * (size_t)BM);
         conv_kernel_fn sfn = (!no_stream && !in_mode && mode <= 4 && L.Cin % 32 == 0 && L.Cin <= 192 && L.Cout % BM == 0 && need <= 76 * 1024 &&
                               grid >= 2048)
@@ -485,12 +484,12 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
 
 // thin-output layers the input-mode streaming kernel serves: Conv1d(C -> 1|2, k = 7), stride 1, no dilation, explicit padding
 static bool thin_inm_layer(const ConvLayer& L) {
-    static const bool off = std::getenv("NC_NO_THIN_INM") && std::getenv("NC_NO_THIN_INM")[0] == '1';
+    static const bool off = env_flag("NC_NO_THIN_INM");
     return !off && L.w_thin.p && !L.transposed && L.K == 7 && L.stride == 1 && L.dil == 1 && L.pad == 0 && L.Cout <= 2;
 }
 
 bool conv_in2_available(const ConvLayer& L) {
-    static const bool off = std::getenv("NC_NO_IN2") && std::getenv("NC_NO_IN2")[0] == '1';
+    static const bool off = env_flag("NC_NO_IN2");
     if (off || L.w_stem.p || L.w_skinny.p) return false;
     if (L.w_thin.p) return thin_inm_layer(L);   // the PCM head in the input mode takes both operands (conv_thin_inm_kernel)
     // Only where ONE row tile covers all output rows: every row tile re-stages (normalises twice, adds, activates) the window it
@@ -510,11 +509,11 @@ static int conv_small_choice(const ConvLayer& L, const ConvIO& io, int B) {
     const int in_mode = (io.in_stats ? 1 : 0) | (io.in_elu ? 2 : 0) | (io.in_L > 0 ? 4 : 0) | (io.x2 ? 8 : 0);
     if ((in_mode & 8) || io.alpha_in || io.res || io.fuse_k1 || io.epi != 0) return 0;   // (the reflect-padded view alone is fine: an index map)
     if ((in_mode & 3) && !conv_small_inm_available(L.Cin, L.K, L.stride, L.dil)) return 0;
-    static const int64_t max_grid = std::getenv("NC_SMALL_MAX_GRID") ? atol(std::getenv("NC_SMALL_MAX_GRID")) : 2048;
-    static const int64_t wide_below = std::getenv("NC_SMALL_WIDE_BELOW") ? atol(std::getenv("NC_SMALL_WIDE_BELOW")) : 512;
+    static const int64_t max_grid = env_int("NC_SMALL_MAX_GRID", 2048);
+    static const int64_t wide_below = env_int("NC_SMALL_WIDE_BELOW", 512);
     const int64_t Tout = L.out_len(io.Tin);
     if (L.K == 1) {   // wide pointwise GEMMs over few columns (the chunked LSTM input projections): 32-column form only
-        static const int64_t k1_cols = std::getenv("NC_SMALL_K1_COLS") ? atol(std::getenv("NC_SMALL_K1_COLS")) : 4096;
+        static const int64_t k1_cols = env_int("NC_SMALL_K1_COLS", 4096);
         return (!io.gn_part && (int64_t)B * Tout <= k1_cols) ? 2 : 0;
     }
     const int64_t grid16 = (int64_t)B * ((Tout + 15) / 16) * ((L.Cout + 63) / 64);
@@ -525,7 +524,7 @@ static int conv_small_choice(const ConvLayer& L, const ConvIO& io, int B) {
 }
 
 bool conv_gn_fusable(const ConvLayer& L, const ConvIO& io, int B) {
-    static const bool off = std::getenv("NC_NO_GN_FUSE") && std::getenv("NC_NO_GN_FUSE")[0] == '1';
+    static const bool off = env_flag("NC_NO_GN_FUSE");
     // plain epilogues only; one launch covering the whole output (no per-phase transposed launches); the streaming thin-output /
     // stem / skinny kernels keep the stand-alone statistics pass (launch_conv skips them when gn_part is set, so the answer here only
     // has to say which layers are WORTH routing through the matrix-core template: all but those three)
@@ -538,7 +537,7 @@ bool conv_gn_fusable(const ConvLayer& L, const ConvIO& io, int B) {
 }
 
 void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream, Profiler* prof) {
-    static const bool no_skinny = std::getenv("NC_NO_SKINNY") && std::getenv("NC_NO_SKINNY")[0] == '1';
+    static const bool no_skinny = env_flag("NC_NO_SKINNY");
     const int in_mode = (io.in_stats ? 1 : 0) | (io.in_elu ? 2 : 0) | (io.in_L > 0 ? 4 : 0) | (io.x2 ? 8 : 0);
     if (in_mode && (io.alpha_in || io.fuse_k1)) fail(NC_ESTATE, "internal: the Encodec input mode does not combine with Snake / fused units");
     if (io.x2 && (!conv_in2_available(L) || (io.in_stats != nullptr) != (io.in_stats2 != nullptr)))
@@ -571,7 +570,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         if (launch_conv_thin_inm(t, B, L.Cout, stream)) return;
     }
     {   // thin-output layers (PCM heads): streaming kernel instead of a 32-row matrix tile with 1-2 live rows
-        static const bool no_thin = std::getenv("NC_NO_THIN") && std::getenv("NC_NO_THIN")[0] == '1';
+        static const bool no_thin = env_flag("NC_NO_THIN");
         if (L.w_thin.p && !no_thin && !in_mode && !io.alpha_in && !io.alpha_out && !io.res && !io.fuse_k1 && (io.epi & ~EPI_TANH) == 0) {
             const int64_t Tout = L.out_len(io.Tin);
             if (prof && prof->on)
@@ -583,7 +582,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         }
     }
     {   // thin-input layers (stems, Cin == 1): streaming store of Cout rows
-        static const bool no_stem = std::getenv("NC_NO_STEM") && std::getenv("NC_NO_STEM")[0] == '1';
+        static const bool no_stem = env_flag("NC_NO_STEM");
         if (L.w_stem.p && !no_stem && !in_mode && !io.alpha_in && !io.res && !io.fuse_k1 && io.epi == 0 && io.x_cstride >= 0) {
             const int64_t Tout = L.out_len(io.Tin);
             ProfScope ps(prof, stream, L.kclass, L.flops(B, io.Tin), 4.0 * ((double)B * io.Tin + (double)B * L.Cout * Tout));
@@ -616,7 +615,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         for (const auto& alt : L.alts)   // the fused residual unit needs the tile that spans all channels
             if (alt->cfg.BM() == L.Cout) tsel = TileChoice{alt->cfg, alt->w.as<float>(), alt->w_phase_stride};
     TileCfg c = tsel.cfg;
-    static const int tn_thresh = std::getenv("NC_TN_THRESH") ? atoi(std::getenv("NC_TN_THRESH")) : 192;
+    static const int tn_thresh = (int)env_int("NC_TN_THRESH", 192);
     c.TN = n_cols_all >= tn_thresh ? 2 : 1;  // 256-column tiles for long clips, 128 for the deep (short) layers
     {   // the per-lane staging registers bound the window: fall back to 128-column tiles when it does not fit
         const int sx0 = L.transposed ? 1 : L.stride, ad0 = L.transposed ? 1 : L.dil;
@@ -626,7 +625,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     // narrow variant (3 waves, 96 columns): rows of 65..96 columns would leave a quarter of a 128-column tile on padding
     bool narrow = false;
     {
-        static const bool no_narrow = std::getenv("NC_NO_NARROW") && std::getenv("NC_NO_NARROW")[0] == '1';
+        static const bool no_narrow = env_flag("NC_NO_NARROW");
         const int rem = (int)(n_cols_all % 128);
         const int sx0 = L.transposed ? 1 : L.stride, ad0 = L.transposed ? 1 : L.dil;
         const int xw96 = 95 * sx0 + (L.Ktaps - 1) * ad0 + 1;
@@ -645,12 +644,12 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     int flat_S = 0, flat_hc = 0;
     int64_t flat_pitch = 0;   // columns per clip on the flattened axis (>= n_cols_all)
     {
-        static const bool no_flat = std::getenv("NC_NO_FLAT") && std::getenv("NC_NO_FLAT")[0] == '1';
+        static const bool no_flat = env_flag("NC_NO_FLAT");
         const int sx0 = L.transposed ? 1 : L.stride, ad0 = L.transposed ? 1 : L.dil;
         const int hc = ((L.Ktaps - 1) * ad0) / sx0;
         // clip pitch on the flattened axis: the row length, or -- when the epilogue emits GroupNorm block sums -- the row length rounded up
         // to whole 32-column blocks (= 32 * gn_ncb), so that every 32x32 accumulator tile is one canonical block of one sample
-        static const bool no_flat_gn = std::getenv("NC_NO_FLAT_GN") && std::getenv("NC_NO_FLAT_GN")[0] == '1';
+        static const bool no_flat_gn = env_flag("NC_NO_FLAT_GN");
         const int64_t Tq = io.gn_part ? (int64_t)32 * io.gn_ncb : n_cols_all;
         auto segs = [&](int BN) { return (int)((BN - 2) / Tq) + 2; };
         auto fits = [&](int TN) {
@@ -687,7 +686,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         // 7.05 -> 6.83 ms).  Only where the whole weight set is a few MB: the deep DAC layers stream 16-75 MB of weights per launch and
         // a 128-column tile re-reads them twice as often -- there the same switch LOSES 8-23 % (C = 768 k=7 1.74 -> 1.88 ms, up-conv
         // 1536->768 1.31 -> 1.62 ms) although the round count says otherwise.
-        static const bool no_tn_rounds = std::getenv("NC_NO_TN_ROUNDS") && std::getenv("NC_NO_TN_ROUNDS")[0] == '1';
+        static const bool no_tn_rounds = env_flag("NC_NO_TN_ROUNDS");
         if (!no_tn_rounds && c.TN == 2 && !io.fuse_k1 && !narrow && c.TM <= 4) {
             static const int bpc_gen[5] = {0, 4, 3, 2, 2};
             const double slots = 256.0 * bpc_gen[c.TM];
@@ -721,7 +720,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         // round trips -- two reduction blocks per tile never fill the software pipeline -- so more resident workgroups overlap them:
         // 215 -> 145 us (32->16 k3, 48000 steps x 32 clips), 152 -> 118 us (64->32), 80 -> 51 us (2->32 k7).  Measured neutral or
         // slower for the strided k=4 / k=8 layers and the sub-pixel up-convolutions, which keep the standard blocks.
-        static const bool no_slim = std::getenv("NC_NO_SLIM") && std::getenv("NC_NO_SLIM")[0] == '1';
+        static const bool no_slim = env_flag("NC_NO_SLIM");
         if (!no_slim && !flat && !light && !narrow && !io.fuse_k1 && !io.x2 && !L.sub_stride && !L.transposed && c.TM <= 2 && n_cols_all >= 1024) {
             int cb2 = 0, nx2 = 0;
             if (c.K == 3 && c.CB == 16) { slim_fn = conv_kernel_table_slim_k3(c.TM, c.TN); cb2 = 8; nx2 = 10; }
@@ -757,8 +756,8 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     // 58 % pipe duty for a lone workgroup against 71 % for a co-resident pair -- so the runs are dealt into the matrix-core shadows.
     conv_kernel_fn dist_small_fn = nullptr;
     {
-        static const bool off = std::getenv("NC_NO_DIST_SMALL") && std::getenv("NC_NO_DIST_SMALL")[0] == '1';
-        static const int64_t max_grid = std::getenv("NC_DIST_MAX_GRID") ? atol(std::getenv("NC_DIST_MAX_GRID")) : 768;
+        static const bool off = env_flag("NC_NO_DIST_SMALL");
+        static const int64_t max_grid = env_int("NC_DIST_MAX_GRID", 768);
         const int64_t n_co = (L.rows() + c.BM() - 1) / c.BM();
         const int64_t n_tt = flat ? ((int64_t)B * flat_pitch + c.BN() - 1) / c.BN() : (int64_t)B * ((n_cols_all + c.BN() - 1) / c.BN());
         if (!off && !dist && !n_prod && !light && !narrow && !wide && !slim && !in_mode && !io.x2 && !io.fuse_k1 && io.epi == 0 && L.n_phase == 1 &&
@@ -876,7 +875,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         fn = lookup_kernel(c);
     }
     {   // experiment: NC_LDS_MIN=<bytes> raises the LDS request (fewer co-resident workgroups per CU)
-        static const size_t lds_min = std::getenv("NC_LDS_MIN") ? (size_t)atol(std::getenv("NC_LDS_MIN")) : 0;
+        static const size_t lds_min = (size_t)env_int("NC_LDS_MIN", 0);
         lds = std::max(lds, std::min<size_t>(lds_min, 160 * 1024));
     }
     if (lds > 160 * 1024) fail(NC_EUNSUPPORTED, "conv tile needs %zu B of LDS", lds);
@@ -897,7 +896,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     {   // NC_LAUNCH_LOG=<path>: one line per conv-template launch (class, threads, shape) in launch order.  The template serves several
         // kernel classes under one kernel name; tools/pmc_classes.py zips this log with the rocprofv3 counter rows of the same
         // kernel name (dispatch order) to attribute HBM traffic / matrix-core busy cycles to exactly the launches a class counts.
-        static FILE* lf = [] { const char* p = std::getenv("NC_LAUNCH_LOG"); return p && p[0] ? std::fopen(p, "w") : (FILE*)nullptr; }();
+        static FILE* lf = [] { const char* p = env_str("NC_LAUNCH_LOG"); return p ? std::fopen(p, "w") : (FILE*)nullptr; }();
         if (lf) {
             std::fprintf(lf, "conv_mfma %d %lld %d %d %d %lld %d\n", L.kclass, (long long)grid * 64 * (c.NW + n_prod), L.Cin, L.Cout, L.K,
                          (long long)io.Tin, io.fuse_k1 ? 1 : 0);

@@ -429,7 +429,7 @@ bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int
     // 32-column workgroups (two column tiles per A fragment: half the weight traffic) where the caller asks for them -- launches with
     // thousands of 16-column tiles are bound by the weight stream out of L2; 16-column tiles for the latency-bound launches.  (A
     // 64-column form is instantiated behind NC_SMALL_TN=4: 429 registers, one wave per SIMD, slower.)
-    static const int tn_env = std::getenv("NC_SMALL_TN") ? atoi(std::getenv("NC_SMALL_TN")) : 0;
+    static const int tn_env = (int)env_int("NC_SMALL_TN", 0);
     const int W64 = 63 * stride + (K - 1) * dil + 1;
     const bool tn2_fits = conv_small_max_tn(Cin, K, stride, dil) >= 2, tn4_fits = tn2_fits && SMALL_CB * W64 <= 18 * 256;
     const int TN = with_gn ? 2 : (tn4_fits && tn_env == 4 && !small_k7(Cin, K, stride, dil)) ? 4 : (tn2_fits && (tn_env == 2 || (tn_env == 0 && want_tn >= 2))) ? 2 : 1;
@@ -441,7 +441,7 @@ bool launch_conv_small(const float* x, int64_t x_bstride, int64_t x_cstride, int
     const int64_t grid = (int64_t)B * a.n_t_tiles * a.n_row_tiles;
     if (grid <= 0 || grid > 0x7fffffff) return false;
     // the straight-line form where the block count is a multiple of its unroll; the rolled kernel otherwise
-    static const bool rolled_only = std::getenv("NC_SMALL_ROLLED") && std::getenv("NC_SMALL_ROLLED")[0] == '1';
+    static const bool rolled_only = env_flag("NC_SMALL_ROLLED");
     const int gpb = SMALL_CB * K / 16, n_blocks = Cin / SMALL_CB;
     const bool fits31 = (int64_t)Cin * x_cstride + x_len < ((int64_t)1 << 31);
     void (*fn)(const ConvSmallArgs) = conv_small_kernel;

@@ -181,7 +181,7 @@ bool launch_conv_thin(const float* x, int64_t x_bstride, int64_t x_cstride, int 
     const int row = (THIN_TILE + halo + 3 + 3 + 4) & ~3;   // + up to 3 slots of alignment shift + one spare 16-byte word for the whole-word reads
     if (row > 1280) return false;
     // 16-byte window reads: k = 7, dilation 1 (the PCM heads), rows that start on 16-byte boundaries and hold whole 16-byte words
-    static const bool no_vec = std::getenv("NC_THIN_NO_VEC") != nullptr;
+    static const bool no_vec = env_present("NC_THIN_NO_VEC");
     const bool vec = !no_vec && K == 7 && dil == 1 && (x_len & 3) == 0 && x_len >= 4 && (x_bstride & 3) == 0 && (x_cstride & 3) == 0 &&
                      (reinterpret_cast<uintptr_t>(x) & 15) == 0 && row <= 4 * 512;
     const size_t lds = sizeof(float) * (size_t)THIN_CC * row;

@@ -92,7 +92,7 @@ DacModel::DacModel(const nc_dac_config& c) : cfg(c) {
         if (c.decoder_rates[i] <= 0) fail(NC_EINVAL, "decoder rate must be positive");
     if ((c.decoder_dim >> c.n_decoder_rates) <= 0) fail(NC_EINVAL, "decoder_dim too small for the number of decoder blocks");
     latent = c.latent_dim > 0 ? c.latent_dim : c.encoder_dim * (1 << c.n_encoder_rates);  // DAC.cs:64
-    if (const char* e = std::getenv("NC_NO_FUSE")) fuse_res_units = !(e[0] == '1');
+    if (env_flag("NC_NO_FUSE")) fuse_res_units = false;
     cfg.latent_dim = latent;
 }
 
@@ -226,7 +226,7 @@ float* DacModel::run_res_unit(ResUnit& ru, int dil, float* cur, int C, int64_t L
     // 1.79 ms against 1.88 ms in two launches).  At C = 192 the fused form only breaks even (2.00 against 2.02 ms per unit: the
     // 96-row x 256-column tiles of the two-launch form are the most efficient instances of the template, 124 TFLOP/s), so it keeps
     // the two launches unless NC_WIDE_FUSE_192=1.
-    static const bool wide_192 = std::getenv("NC_WIDE_FUSE_192") && std::getenv("NC_WIDE_FUSE_192")[0] == '1';
+    static const bool wide_192 = env_flag("NC_WIDE_FUSE_192");
     if (fuse_res_units && can_fuse_res_unit(ru.c7, ru.c1) && (C != 192 || wide_192)) {
         // one launch: y = x + W1.snake(conv7(snake(x)) + b7) + b1 ; h never reaches HBM
         io.res = cur; io.fuse_k1 = &ru.c1; io.alpha_out2 = alpha_next;

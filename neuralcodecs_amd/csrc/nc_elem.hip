@@ -158,7 +158,7 @@ void launch_dwconv(const DwConvLayer& L, const float* x, const float* alpha_in, 
                    hipStream_t s, Profiler* prof) {
     if (L.K > DW_MAXK) fail(NC_EUNSUPPORTED, "depthwise kernel size %d > %d", L.K, DW_MAXK);
     {
-        static const bool no_vec = std::getenv("NC_DW_NO_VEC") && std::getenv("NC_DW_NO_VEC")[0] == '1';
+        static const bool no_vec = env_flag("NC_DW_NO_VEC");
         const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
         if (!no_vec && L.K == 7 && L.pad == 3 * L.dil && (L.dil == 1 || L.dil == 3 || L.dil == 9) && (T & 3) == 0 && T >= 4 && al) {
             dim3 grid((unsigned)((T + DW_TT - 1) / DW_TT), (unsigned)L.C, (unsigned)B);
@@ -277,10 +277,71 @@ __global__ void layernorm_ct_kernel(const float* __restrict__ x, const float* __
             if (c0 + u < C) yp[(int64_t)(c0 + u) * T] = ((v[u] - muf) * r) * gamma[c0 + u] + beta[c0 + u];
     }
 }
+// Tile form (round 4): the kernel above has B*T threads that each walk C strided words three times -- 144 dependent memory round trips,
+// 224 us for a 28 MB tensor.  Here a workgroup stages a [C][TT] tile (TT consecutive steps of one clip) in LDS with every load in
+// flight at once, TT lanes walk their column out of LDS in the SAME sequential binary64 order (channels ascending: the canonical
+// sums; the dependent chain of 2 C double additions is what is left of the run time), and all threads normalise and store.
+template <int TT>
+__global__ __launch_bounds__(256) void layernorm_tile_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ y, int C, int64_t T) {
+    extern __shared__ __attribute__((aligned(16))) float ln_lds[];   // [C][TT] | mean[TT] | rstd[TT]
+    float* tile = ln_lds;
+    float* stat = ln_lds + (size_t)C * TT;
+    const int b = blockIdx.y;
+    const int64_t t0 = (int64_t)blockIdx.x * TT;
+    const int col = threadIdx.x % TT, r0 = threadIdx.x / TT;
+    constexpr int RP = 256 / TT;                                       // rows per pass
+    const int64_t tc = t0 + col < T ? t0 + col : T - 1;
+    const float* xp = x + (int64_t)b * C * T + tc;
+    constexpr int U = 16;
+    for (int c0 = r0; c0 < C; c0 += RP * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = xp[(int64_t)min(c0 + u * RP, C - 1) * T];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (c0 + u * RP < C) tile[(c0 + u * RP) * TT + col] = v[u];
+    }
+    __syncthreads();
+    if (threadIdx.x < TT) {
+        const float* cp = tile + threadIdx.x;
+        double s1 = 0.0;
+        for (int c = 0; c < C; ++c) s1 += (double)cp[c * TT];
+        const double mu = s1 / C;
+        double s2 = 0.0;
+        for (int c = 0; c < C; ++c) {
+            const double d = (double)cp[c * TT] - mu;
+            s2 += d * d;
+        }
+        stat[threadIdx.x] = (float)mu;
+        stat[TT + threadIdx.x] = (float)(1.0 / sqrt(s2 / C + 1e-5));
+    }
+    __syncthreads();
+    if (t0 + col >= T) return;
+    const float muf = stat[col], r = stat[TT + col];
+    float* yp = y + (int64_t)b * C * T + t0 + col;
+    for (int c = r0; c < C; c += RP) yp[(int64_t)c * T] = ((tile[c * TT + col] - muf) * r) * gamma[c] + beta[c];
+}
+
 void launch_layernorm_ct(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int64_t T, hipStream_t st,
                          Profiler* prof) {
     const int64_t n = (int64_t)B * T;
     ProfScope ps(prof, st, NC_KC_NORM, 8.0 * C * (double)n, 8.0 * C * (double)n);
+    static const int tile_env = (int)env_int("NC_LN_TILE", -1);   // 0 = the per-column kernel, 8 / 16 = tile width
+    const int tt = tile_env >= 0 ? tile_env : ((size_t)C * 16 * 4 <= 48 * 1024 ? 16 : 8);
+    if ((tt == 8 || tt == 16) && (size_t)C * tt * 4 + 2 * tt * 4 <= 96 * 1024) {
+        const size_t lds = (size_t)C * tt * 4 + 2 * tt * 4;
+        const dim3 grid((unsigned)((T + tt - 1) / tt), (unsigned)B);
+        if (tt == 16) {
+            ensure_dynamic_lds((const void*)layernorm_tile_kernel<16>, lds);
+            hipLaunchKernelGGL(layernorm_tile_kernel<16>, grid, dim3(256), lds, st, x, gamma, beta, y, C, T);
+        } else {
+            ensure_dynamic_lds((const void*)layernorm_tile_kernel<8>, lds);
+            hipLaunchKernelGGL(layernorm_tile_kernel<8>, grid, dim3(256), lds, st, x, gamma, beta, y, C, T);
+        }
+        NC_HIP(hipGetLastError());
+        return;
+    }
     hipLaunchKernelGGL(layernorm_ct_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, x, gamma, beta, y, B, C, T);
     NC_HIP(hipGetLastError());
 }
@@ -363,10 +424,106 @@ __global__ __launch_bounds__(64) void local_attn_kernel(const float* __restrict_
         for (int u = 0; u < 8; ++u) op[(int64_t)(d0 + u) * T] = a[u];
     }
 }
+// The same arithmetic on the matrix cores for the window the presets use (W = 32, head dim 64; round 4).  The kernel above keeps one
+// query per lane and reads K / V from LDS one word per fma: 4096 LDS round trips per lane, 256 VGPRs, one wave per SIMD -- 361 us per
+// launch on a 28 MB tensor.  Here one wavefront owns a (window, head, clip): q and k arrive from global memory ALREADY in the operand
+// layout of v_mfma_f32_32x32x2_f32 (lane l: position l & 31, feature 2s + (l >> 5) at step s -- two 128-byte row segments per load), the
+// rotation partner of feature d is the same lane's register of step s ^ 16, and
+//   scores   S[i][j] = chain_d(q'[i][d], k'[j][d])      32 instructions, d ascending = the canonical fma chain
+//   softmax  through LDS in the canonical order (row max, canonical exp, SEQUENTIAL sum over j, one division per element)
+//   output   O[i][d] = chain_j(p[i][j], v[j][d])         2 x 16 instructions, j ascending
+// are the identical operation sequences (bit-exact: tests/test_snac_gpu.py 44 kHz + LocalMHA vs the oracle).
+typedef float attn_f32x16 __attribute__((ext_vector_type(16)));
+typedef float attn_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void local_attn_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ cs,
+                                                             const float* __restrict__ sn, float* __restrict__ out, int C, int64_t T) {
+    constexpr int W = 32, D = 64, LD = 33;
+    __shared__ float Ss[W * LD];      // scores -> exponentials -> probabilities, [query][key]
+    __shared__ float Vs[D * LD];      // [feature][key]
+    const int wdx = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int l = threadIdx.x, i = l & 31, hi = l >> 5;
+    const float* base = qkv + (int64_t)b * 3 * C * T + (int64_t)wdx * W + i;
+    const float* qp = base + (int64_t)(h * D + hi) * T;
+    const float* kp = base + (int64_t)(C + h * D + hi) * T;
+    const float* vp = base + (int64_t)(2 * C + h * D + hi) * T;
+    float qv[32], kv[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        qv[s] = qp[(int64_t)(2 * s) * T];
+        kv[s] = kp[(int64_t)(2 * s) * T];
+    }
+#pragma unroll
+    for (int s = 0; s < 32; ++s) Vs[(2 * s + hi) * LD + i] = vp[(int64_t)(2 * s) * T];
+    attn_f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const int d = 2 * s + hi;                                  // s < 16 <=> d < 32; the partner feature d +- 32 is step s ^ 16
+        const float cc = cs[i * D + d], ss = sn[i * D + d];
+        const float qr = s < 16 ? -qv[s ^ 16] : qv[s ^ 16], kr = s < 16 ? -kv[s ^ 16] : kv[s ^ 16];
+        const float qq = (qv[s] * cc) + (qr * ss);                 // RotaryEmbedding.cs:46-68
+        const float kk = (kv[s] * cc) + (kr * ss);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qq, kk, acc, 0, 0, 0);
+    }
+    // accumulator: key j = i (column), queries (v & 3) + 8 * (v >> 2) + 4 * hi
+#pragma unroll
+    for (int v = 0; v < 16; ++v) Ss[((v & 3) + 8 * (v >> 2) + 4 * hi) * LD + i] = acc[v] * 0.125f;
+    // row i: lane (i, hi) owns keys 16 hi .. 16 hi + 15
+    float* row = Ss + i * LD + 16 * hi;
+    float e[16];
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        e[j] = row[j];
+        if (e[j] > mx) mx = e[j];
+    }
+    {
+        const float other = __shfl_xor(mx, 32);
+        if (other > mx) mx = other;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        e[j] = nc_expf(e[j] - mx);
+        row[j] = e[j];
+    }
+    float sum = 0.0f;                                              // the canonical SEQUENTIAL sum over the 32 keys (both halves compute it)
+    {
+        const float* r0 = Ss + i * LD;
+#pragma unroll
+        for (int j = 0; j < W; ++j) sum = sum + r0[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) row[j] = e[j] / sum;
+    attn_f32x16 o0, o1;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { o0[v] = 0.0f; o1[v] = 0.0f; }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float p = Ss[i * LD + 2 * s + hi];                   // A[query i][key 2s + hi]
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p, Vs[i * LD + 2 * s + hi], o0, 0, 0, 0);          // B[key][feature i]
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p, Vs[(32 + i) * LD + 2 * s + hi], o1, 0, 0, 0);   // features 32 + i
+    }
+    float* op = out + ((int64_t)b * C + h * D + i) * T + (int64_t)wdx * W + 4 * hi;   // feature i (column), queries 8 g + 4 hi + 0..3
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const attn_f32x4 a0 = {o0[4 * g], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]};
+        const attn_f32x4 a1 = {o1[4 * g], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]};
+        *reinterpret_cast<attn_f32x4*>(op + 8 * g) = a0;
+        *reinterpret_cast<attn_f32x4*>(op + (int64_t)32 * T + 8 * g) = a1;
+    }
+}
+
 void launch_local_attn(const float* qkv, const float* cs, const float* sn, float* out, int B, int C, int64_t T, int W,
                        hipStream_t st, Profiler* prof) {
     if (W > ATT_W || W <= 0 || T % W != 0 || C % 64 != 0) fail(NC_EUNSUPPORTED, "local attention: window %d / dim %d not supported", W, C);
     ProfScope ps(prof, st, NC_KC_ATTN, 4.0 * W * C * (double)T * B, 16.0 * C * (double)T * B);
+    static const bool no_mfma = env_flag("NC_ATTN_NO_MFMA");
+    if (W == 32 && !no_mfma && T % 4 == 0) {
+        hipLaunchKernelGGL(local_attn_mfma_kernel, dim3((unsigned)(T / W), (unsigned)(C / 64), (unsigned)B), dim3(64), 0, st, qkv, cs, sn, out, C, T);
+        NC_HIP(hipGetLastError());
+        return;
+    }
     hipLaunchKernelGGL(local_attn_kernel, dim3((unsigned)(T / W), (unsigned)(C / 64), (unsigned)B), dim3(64), 0, st, qkv, cs, sn, out,
                        C, T, W);
     NC_HIP(hipGetLastError());

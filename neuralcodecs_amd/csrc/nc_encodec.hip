@@ -918,10 +918,23 @@ EncodecModel::~EncodecModel() {
 // points, the engine's own -- succeeds.
 void EncodecModel::check_async_errors() {
     if (!lstm_timed_out()) return;
+    // the launches of the failed call that are still queued could raise the word again after it has been cleared: let them finish first
+    // (every side stream of a call joins the handle's stream before the call returns, so this covers them)
+    (void)hipStreamSynchronize(stream);
     *reinterpret_cast<volatile unsigned*>(lstm_tmo_host) = 0;
     lstm_force_stepwise = true;
     fail(NC_EDEVICE, "persistent LSTM kernel: a workgroup exchange timed out (its workgroups were not co-resident); the results of that call are "
                      "invalid -- this handle now runs the step-wise LSTM kernels, repeat the call");
+}
+
+// Host-pointer entry points: a timeout left behind by an EARLIER device-pointer call is not this call's failure.  Take note of it
+// (step-wise kernels from here on) and carry on; the caller of the earlier call learns of it through nc_codec_check_errors /
+// nc_codec_synchronize as documented -- or not at all if it never asked, which is its business.
+void EncodecModel::absorb_stale_timeout() {
+    if (!lstm_timed_out()) return;
+    (void)hipStreamSynchronize(stream);
+    *reinterpret_cast<volatile unsigned*>(lstm_tmo_host) = 0;
+    lstm_force_stepwise = true;
 }
 
 // ---- launch helpers --------------------------------------------------------------------------------
@@ -967,7 +980,7 @@ EncodecModel::GnJob EncodecModel::gn_begin(const ConvLayer& conv, ConvIO& io, in
         j.fused = true;
         // finish inside the launch: the last workgroup of a sample to arrive writes (mean, rstd).  One self-resetting counter per
         // sample; the segment groups of a call run concurrently, so each has its own set.
-        static const bool no_finish = std::getenv("NC_NO_GN_FINISH") && std::getenv("NC_NO_GN_FINISH")[0] == '1';
+        static const bool no_finish = env_flag("NC_NO_GN_FINISH");
         if (!no_finish && N <= GN_MAX_SAMPLES) {
             io.gn_count = gn_counters.as<unsigned>() + (size_t)cur_group * GN_MAX_SAMPLES;
             io.gn_stats = j.stats;
@@ -1014,7 +1027,7 @@ static void second_input(ConvIO& io, const EncodecModel::Act& b2) {
 
 EncodecModel::Act EncodecModel::sconv(SConv& L, const Act& a, const Act* b2, bool elu, int N) {
     const Plan pl = plan_sconv(a.L, L.K, L.stride, 1);
-    static const bool no_fuse = std::getenv("NC_ENCODEC_NO_FUSE") && std::getenv("NC_ENCODEC_NO_FUSE")[0] == '1';
+    static const bool no_fuse = env_flag("NC_ENCODEC_NO_FUSE");
     float* y = nullptr;
     ConvIO io{};
     const bool two_in = b2 && !no_fuse && conv_in2_available(L.conv) && b2->C == a.C && b2->L == a.L && b2->rs == a.rs &&
@@ -1042,7 +1055,7 @@ EncodecModel::Act EncodecModel::sconv(SConv& L, const Act& a, const Act* b2, boo
 
 // SConvTranspose1d.forward (SConvTranspose1d.cs:116-139): conv-transpose, GroupNorm over the UNTRIMMED output, then the trim
 EncodecModel::Act EncodecModel::sconvT(SConv& L, const Act& a, const Act* b2, bool elu, int N) {
-    static const bool no_fuse = std::getenv("NC_ENCODEC_NO_FUSE") && std::getenv("NC_ENCODEC_NO_FUSE")[0] == '1';
+    static const bool no_fuse = env_flag("NC_ENCODEC_NO_FUSE");
     const int64_t Lfull = (a.L - 1) * L.stride + L.K;
     ConvIO io{};
     const bool two_in = b2 && !no_fuse && conv_in2_available(L.conv) && b2->C == a.C && b2->L == a.L && b2->rs == a.rs &&
@@ -1102,7 +1115,7 @@ __global__ void nct_to_ctn_kernel(const float* __restrict__ x, float* __restrict
 
 // true when run_lstm should apply the consumer's ELU in its output store (NC_LSTM_NO_ELU=1: the consumer applies it while staging)
 static bool lstm_applies_elu(const EncodecModel::Lstm& l) {
-    static const bool off = std::getenv("NC_LSTM_NO_ELU") && std::getenv("NC_LSTM_NO_ELU")[0] == '1';
+    static const bool off = env_flag("NC_LSTM_NO_ELU");
     return !off && !l.layers.empty();
 }
 
@@ -1110,7 +1123,7 @@ static bool lstm_applies_elu(const EncodecModel::Lstm& l) {
 float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool elu_out) {
     const int C = l.C;
     if (l.layers.empty()) return const_cast<float*>(x);
-    static const bool stepwise_env = std::getenv("NC_LSTM_STEPWISE") && std::getenv("NC_LSTM_STEPWISE")[0] == '1';
+    static const bool stepwise_env = env_flag("NC_LSTM_STEPWISE");
     const int KS = C / 4;
     const int nl = (int)l.layers.size();
     // The persistent kernel needs every workgroup of a launch resident at once (one per CU at 140 KB of LDS): up to 64 per launch, two
@@ -1130,14 +1143,14 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
     // against 9.05 ms; 16 clips at 24 kHz 5.4-5.9 against 5.67 ms): with C / 4 = 128 workgroups in every exchange a step is 9.8-12 us
     // (in-kernel trace, tools/probe/lstm2_trace.py: publish -> flags seen 2.6-3.4 us, operand loads 1.4-2.2 us, and the workgroups
     // drift 3.5-5 us apart inside a step) against 5.7-6.2 us for an exchange among 32.  Kept as a switch, not the default: DESIGN 8.
-    static const bool fused_env = std::getenv("NC_LSTM_FUSED") && std::getenv("NC_LSTM_FUSED")[0] == '1';
+    static const bool fused_env = env_flag("NC_LSTM_FUSED");
     const bool per_layer_env = !fused_env;
     const int n_tiles2 = (N + 15) / 16;
     const size_t ex_floats = lstm2_exchange_floats(C, T, std::min(n_tiles2, 2));
     if (!stepwise && !per_layer_env && nl == 2 && lstm2_supported(C) && l.layers[1]->w2ih.p && cu_count >= C / 4 &&
         lds_per_cu >= lstm2_lds_bytes(C, std::min(n_tiles2, 2)) && ex_floats * 4 < ((size_t)1 << 31) && (int64_t)4 * C * T * N < ((int64_t)1 << 31)) {
         {   // NC_LSTM_FAKE_TIMEOUT=1 (tests): the first persistent launch of the process is reported as timed out
-            static bool fake = std::getenv("NC_LSTM_FAKE_TIMEOUT") && std::getenv("NC_LSTM_FAKE_TIMEOUT")[0] == '1';
+            static bool fake = env_flag("NC_LSTM_FAKE_TIMEOUT");
             if (fake) { fake = false; *reinterpret_cast<volatile unsigned*>(lstm_tmo_host) = 1; }
         }
         // layer 0's input projections of ALL steps as one pointwise GEMM over the [C][T][N] view of x: gi0 [4C][T][N]
@@ -1167,7 +1180,7 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
             a.N = N; a.C = C; a.T = T; a.tile0 = tl; a.tiles = nt;
             const double nn = (double)std::min(N - tl * 16, nt * 16) * (double)T;
             if (prof.on) prof.begin(stream, NC_KC_LSTM, 2.0 * 3 * 4 * C * C * nn, 4.0 * 8 * C * nn);   // W_hh0, W_ih1, W_hh1 contractions
-            static const char* trace_path = std::getenv("NC_LSTM2_TRACE");   // diagnostic: stamps of 8 steps of the first full-size launch
+            static const char* trace_path = env_str("NC_LSTM2_TRACE");   // diagnostic: stamps of 8 steps of the first full-size launch
             static bool traced = false;
             const size_t trace_words = (size_t)(C / 4) * nt * 8 * LSTM2_TRACE_STEPS * 4 + 4;   // + the clock probe
             if (trace_path && !traced && T >= LSTM2_TRACE_T0 + LSTM2_TRACE_STEPS) {
@@ -1201,20 +1214,21 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
         // are then one contiguous column range of a 2-D matrix, so the chunk's GEMM is a one-"clip" pointwise convolution over
         // chunk*N columns with full 128-column tiles (cut out of [N,C,T], a chunk would fill a fifth of every tile: measured, the
         // per-chunk GEMMs then cost as much as the full one and 6 chunks made C3 2.2 ms slower).
-        static const int want_chunks = [] { const char* e = std::getenv("NC_LSTM_CHUNKS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
+        static const int want_chunks = [] { const int v = (int)env_int("NC_LSTM_CHUNKS", 4); return v < 1 ? 1 : v; }();
         // chunk boundaries (even: chunk starts stay 8-byte aligned for the 1x1 path).  The layer above trails the layer below by its
         // LAST chunk (+ that chunk's input-projection GEMM), so the last chunk is short (T/8) and the others share the rest: with 4
         // chunks of 150 steps 44 / 44 / 44 / 18 instead of 38 / 38 / 38 / 36 -- the tail after layer 0 has finished shrinks from 36
         // steps to 18 without a single extra cross-stream event.
         std::vector<int64_t> cstart{0};
         if (nl >= 2 && want_chunks > 1 && T >= 32 && !on_side_group && (int64_t)4 * C * T * N < ((int64_t)1 << 31)) {
-            static const bool even_chunks = std::getenv("NC_LSTM_EVEN_CHUNKS") && std::getenv("NC_LSTM_EVEN_CHUNKS")[0] == '1';
+            static const bool even_chunks = env_flag("NC_LSTM_EVEN_CHUNKS");
             const int64_t last = even_chunks ? 0 : std::max<int64_t>(8, (T / 8) & ~(int64_t)1);
             const int nbig = even_chunks ? want_chunks : want_chunks - 1;
             int64_t big = ((((T - last) + nbig - 1) / nbig) + 1) & ~(int64_t)1;
             big = std::max<int64_t>(big, 8);
-            for (int64_t t0 = big; t0 < T - last; t0 += big) cstart.push_back(t0);
-            if (last > 0 && T - last > cstart.back()) cstart.push_back(T - last);
+            for (int64_t t0 = big; t0 < ((T - last) & ~(int64_t)1); t0 += big) cstart.push_back(t0);
+            const int64_t tail0 = (T - last) & ~(int64_t)1;   // an even start whatever the parity of T: the last chunk absorbs the odd step
+            if (last > 0 && tail0 > cstart.back()) cstart.push_back(tail0);
         }
         cstart.push_back(T);
         const int nch = (int)cstart.size() - 1;
@@ -1223,14 +1237,14 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
         // matrix-core part of a step is 2 chains per SIMD instead of 4: 1.8 -> 0.9 us of the ~5.7; Encodec 24 kHz at 16 clips
         // 6.24 -> 6.13 ms), 4 otherwise: with two tiles the 2 x 64-producer exchange costs more than the chains save (C3 9.59 -> 9.70 ms).
         // NC_LSTM_UB=4 / 2 force one form.
-        static const int ub_env = std::getenv("NC_LSTM_UB") ? atoi(std::getenv("NC_LSTM_UB")) : 0;
+        static const int ub_env = (int)env_int("NC_LSTM_UB", 0);
         const int n_tiles = (N + 15) / 16;
         const int UBW = (KS == 128 && (ub_env == 2 || (ub_env != 4 && n_tiles == 1))) ? 2 : 4;
         const int nprod = C / (4 * UBW), per_launch = std::max(1, (UBW == 2 ? 128 : 64) / nprod);
         const size_t lds = (size_t)4 * UBW * (KS / 4) * 64 * 4 + 3 * UBW * 64 * 16;
         unsigned* sync = lstm_tmo_dev;                                                 // timeout word (host-visible)
         {   // NC_LSTM_FAKE_TIMEOUT=1 (tests): the first persistent launch of the process is reported as timed out
-            static bool fake = std::getenv("NC_LSTM_FAKE_TIMEOUT") && std::getenv("NC_LSTM_FAKE_TIMEOUT")[0] == '1';
+            static bool fake = env_flag("NC_LSTM_FAKE_TIMEOUT");
             if (fake) { fake = false; *reinterpret_cast<volatile unsigned*>(lstm_tmo_host) = 1; }
         }
         std::vector<float*> gi(nl), out(nl), hx(nl), cs(nl);
@@ -1399,13 +1413,13 @@ void EncodecModel::encode_batch(const float* x, int N, int64_t L, int64_t Tz, in
     if (emb_out) NC_HIP(hipMemcpyAsync(emb_out, residual, (size_t)N * D * Tz * 4, hipMemcpyDeviceToDevice, stream));
     const int64_t total = (int64_t)N * Tz;
     if (prof.on) prof.begin(stream, NC_KC_RVQ, 2.0 * D * cfg.codebook_size * (double)total * n_q, 0.0);   // the distance GEMM
-    static const bool no_mfma_vq = std::getenv("NC_EUCLID_NO_MFMA") != nullptr;
+    static const bool no_mfma_vq = env_present("NC_EUCLID_NO_MFMA");
     const int Nc = cfg.codebook_size;
     if (!no_mfma_vq && Nc % 512 == 0 && D == 128) {
         // all stages in one launch, cross terms on the matrix cores (the residual block stays in LDS between the stages)
         // (NC_RVQ_8WAVES=1: 8 wavefronts per workgroup, 128 codes each -- measured the same 236 us on C3's 150-workgroup grid as the
         // 4-wave form: the stage is bound by its serial phases and the codebook stream, not by the matrix-core chain)
-        static const bool rvq8 = std::getenv("NC_RVQ_8WAVES") && std::getenv("NC_RVQ_8WAVES")[0] == '1';
+        static const bool rvq8 = env_flag("NC_RVQ_8WAVES");
         const bool wide = rvq8 && Nc % 1024 == 0 && (total + EM_F - 1) / EM_F <= 256;
         if (wide)
             hipLaunchKernelGGL((euclid_rvq_mfma_kernel<128, 8>), dim3((unsigned)((total + EM_F - 1) / EM_F)), dim3(512), 0, stream, residual,
@@ -1465,7 +1479,7 @@ void EncodecModel::encode_dev(const float* pcm, int B, int64_t T, int64_t* codes
     const std::vector<Seg> segs = segments(T);
     const int C = cfg.channels, D = cfg.dimension;
     int64_t code_off = 0, emb_off = 0;
-    static const bool no_overlap = std::getenv("NC_ENCODEC_NO_OVERLAP") && std::getenv("NC_ENCODEC_NO_OVERLAP")[0] == '1';
+    static const bool no_overlap = env_flag("NC_ENCODEC_NO_OVERLAP");
     hipStream_t const main_stream = stream;
     struct Restore { hipStream_t& s; hipStream_t v; ~Restore() { s = v; } } restore{stream, main_stream};   // also on an exception
     int n_groups = 0;
@@ -1523,7 +1537,7 @@ void EncodecModel::decode_dev(const int64_t* codes, const float* scales, int B, 
     std::vector<const float*> fp((size_t)nfr);
     std::vector<int64_t> flen((size_t)nfr);
     int64_t code_off = 0;
-    static const bool no_overlap = std::getenv("NC_ENCODEC_NO_OVERLAP") && std::getenv("NC_ENCODEC_NO_OVERLAP")[0] == '1';
+    static const bool no_overlap = env_flag("NC_ENCODEC_NO_OVERLAP");
     hipStream_t const main_stream = stream;
     struct Restore { hipStream_t& s; hipStream_t v; ~Restore() { s = v; } } restore{stream, main_stream};   // also on an exception
     int n_groups = 0;

@@ -42,7 +42,7 @@ Rccl& rccl() {
     static std::string err;
     std::call_once(once, [] {
         // NC_RCCL_LIB=<path> names the one library to open (deployments with a private RCCL; tests force the load failure with it)
-        const char* forced = std::getenv("NC_RCCL_LIB");
+        const char* forced = env_str("NC_RCCL_LIB");
         const char* defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         std::vector<const char*> names;
         if (forced && forced[0]) names.push_back(forced);

@@ -251,6 +251,7 @@ struct EncodecModel : Codec {
 
     explicit EncodecModel(const nc_encodec_config& c);
     void check_async_errors() override;
+    void absorb_stale_timeout();
     void load(const Blob& blob) override;
     void set_bandwidth(float bw);
     Plan plan_sconv(int64_t L, int k, int stride, int dil) const;

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void dac_rvq_fused_kernel(const RvqFusedArgs a
 
 bool launch_dac_rvq_fused(const RvqStage* stages_dev, int n_q, int L, int D, int N, const float* residual, int B, int64_t T, int64_t* codes,
                           float* zq, float* latents, hipStream_t s, Profiler* prof) {
-    static const bool off = std::getenv("NC_DAC_RVQ_STAGEWISE") != nullptr;
+    static const bool off = env_present("NC_DAC_RVQ_STAGEWISE");
     if (off || D != RD || L % 256 != 0 || L > 1024 || N % 64 != 0 || n_q <= 0) return false;
     const size_t lds = sizeof(float) * ((size_t)L * RF + (size_t)RD * N + N + (size_t)L * RD + 2 * RF * RD + 2 * RF);
     if (lds > 160 * 1024) return false;

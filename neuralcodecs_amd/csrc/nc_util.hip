@@ -13,6 +13,92 @@ static thread_local std::string g_last_error;
 void set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
 const char* get_last_error() { return g_last_error.c_str(); }
 
+// ---- diagnostic switches: the one table (see nc_common.h) --------------------------------------------------------------------------
+namespace {
+struct EnvRow { const char* name; char kind; const char* doc; };
+const EnvRow kEnv[] = {
+    {"NC_NO_FLAT", 'b', "one-clip column tiles instead of the flattened (clip, column) axis"},
+    {"NC_NO_FLAT_GN", 'b', "one-clip tiles wherever GroupNorm sums are emitted"},
+    {"NC_CO_GROUP", 'i', "cap of the row-tile groups (1 = one weight panel per XCD)"},
+    {"NC_NO_WIDE_FUSE", 'b', "no whole-channel fused residual units (C = 256)"},
+    {"NC_WIDE_FUSE_192", 'b', "whole-channel fused unit at C = 192 as well"},
+    {"NC_NO_FUSE", 'b', "every residual unit in two launches"},
+    {"NC_NO_TILE_ALTS", 'b', "primary row-tile height only"},
+    {"NC_TM_PICK", 'i', "force a packed row-tile variant"},
+    {"NC_TM_FORCE", 'i', "force the row-tile height where it divides Cout"},
+    {"NC_TN_THRESH", 'i', "column-tile width threshold"},
+    {"NC_NO_TN_ROUNDS", 'b', "no round-count rule for the column-tile width"},
+    {"NC_NO_NARROW", 'b', "no 3-wave narrow variants"},
+    {"NC_NO_SLIM", 'b', "no half-size reduction blocks for narrow long rows"},
+    {"NC_NO_SUBPIXEL", 'b', "per-phase launches for power-of-two strided transposed convolutions"},
+    {"NC_NO_SUBPIXEL_ANY", 'b', "per-phase launches for the other strides (3, 5)"},
+    {"NC_NO_CONV1X1", 'b', "pointwise layers through the windowed template"},
+    {"NC_NO_PW_STREAM", 'b', "no streaming pointwise variant"},
+    {"NC_NO_SKINNY", 'b', "no skinny projection kernel (Cout <= 16)"},
+    {"NC_NO_THIN", 'b', "PCM heads through the matrix-core template"},
+    {"NC_THIN_NO_VEC", 'p', "scalar window loads in the thin-output kernel"},
+    {"NC_NO_THIN_INM", 'b', "summed copy + plain head instead of the input-mode head"},
+    {"NC_NO_STEM", 'b', "stems through the matrix-core template"},
+    {"NC_NO_TINY_TILES", 'b', "no smallest-tile rule for tiny grids"},
+    {"NC_TINY_BLOCKS", 'i', "grid size below which the tiny-grid rule applies (256)"},
+    {"NC_NO_DIST_SMALL", 'b', "segmented staging on small grids"},
+    {"NC_DIST_MAX_GRID", 'i', "largest grid that takes distributed staging (768)"},
+    {"NC_LDS_MIN", 'i', "minimum dynamic LDS per workgroup (placement experiments)"},
+    {"NC_NO_CONV_SMALL", 'b', "no short-row 16x16x4 kernel"},
+    {"NC_SMALL_MAX_GRID", 'i', "largest short-row grid (2048)"},
+    {"NC_SMALL_WIDE_BELOW", 'i', "template grid below which the 32-column short-row form is taken (512)"},
+    {"NC_SMALL_K1_COLS", 'i', "columns up to which k = 1 layers take the short-row kernel (4096; 0 = off)"},
+    {"NC_SMALL_TN", 'i', "force the short-row column tiles (1 | 2 | 4)"},
+    {"NC_SMALL_ROLLED", 'b', "rolled short-row loop"},
+    {"NC_DAC_RVQ_STAGEWISE", 'p', "DAC quantizer stage by stage"},
+    {"NC_RVQ_8WAVES", 'b', "8-wavefront Euclidean RVQ workgroups"},
+    {"NC_EUCLID_NO_MFMA", 'p', "vector Euclidean codebook search"},
+    {"NC_ENCODEC_NO_FUSE", 'b', "padded / activated copies instead of the fused SConv1d input mode"},
+    {"NC_ENCODEC_NO_OVERLAP", 'b', "segment groups one after the other"},
+    {"NC_NO_GN_FUSE", 'b', "stand-alone GroupNorm sums"},
+    {"NC_NO_GN_FINISH", 'b', "separate GroupNorm final launch"},
+    {"NC_NO_IN2", 'b', "summed copies instead of the two-input staging mode"},
+    {"NC_NO_CONV3S", 'b', "windowed k = 3 instead of the streaming kernel"},
+    {"NC_LSTM_STEPWISE", 'b', "one LSTM launch per step"},
+    {"NC_LSTM_CHUNKS", 'i', "layer-pipeline chunks of the per-layer persistent LSTM (4; 1 = layers in sequence)"},
+    {"NC_LSTM_EVEN_CHUNKS", 'b', "equal LSTM chunks"},
+    {"NC_LSTM_UB", 'i', "hidden-unit blocks per LSTM workgroup (2 | 4)"},
+    {"NC_LSTM_NO_ELU", 'b', "the consumer applies the ELU behind an SLSTM"},
+    {"NC_LSTM_FUSED", 'b', "fused two-layer persistent LSTM (nc_lstm.hip)"},
+    {"NC_LSTM2_TRACE", 's', "file for the in-kernel stamps of the fused LSTM (tools/probe/lstm2_trace.py)"},
+    {"NC_LSTM_FAKE_TIMEOUT", 'b', "tests: report the first persistent LSTM launch as timed out"},
+    {"NC_DW_NO_VEC", 'b', "scalar depthwise kernel"},
+    {"NC_LN_TILE", 'i', "LayerNorm tile width (8 | 16; 0 = one thread per column)"},
+    {"NC_ATTN_NO_MFMA", 'b', "vector local-attention kernel"},
+    {"NC_RCCL_LIB", 's', "the one RCCL library to open"},
+    {"NC_LAUNCH_LOG", 's', "launch log for the per-class PMC attribution"},
+    {"NC_LIGHT", 'i', "EXPERIMENTS=1 builds: light k = 7 variant"},
+    {"NC_WIDE", 'i', "EXPERIMENTS=1 builds: 8-wave k = 7 variant"},
+    {"NC_SPEC", 'i', "EXPERIMENTS=1 builds: producer / consumer k = 7 variant"},
+    {"NC_DIST", 'i', "EXPERIMENTS=1 builds: distributed-staging k = 7 variant"},
+};
+const EnvRow& env_row(const char* name, char kind) {
+    for (const EnvRow& r : kEnv)
+        if (std::strcmp(r.name, name) == 0) {
+            if (r.kind != kind) fail(NC_ESTATE, "switch %s is registered as kind '%c', read as '%c'", name, r.kind, kind);
+            return r;
+        }
+    fail(NC_ESTATE, "switch %s is not in the table of nc_util.hip", name);
+}
+}  // namespace
+bool env_flag(const char* name) { const char* v = std::getenv(env_row(name, 'b').name); return v && v[0] == '1'; }
+bool env_present(const char* name) { return std::getenv(env_row(name, 'p').name) != nullptr; }
+long env_int(const char* name, long dflt) { const char* v = std::getenv(env_row(name, 'i').name); return v ? atol(v) : dflt; }
+const char* env_str(const char* name) { const char* v = std::getenv(env_row(name, 's').name); return v && v[0] ? v : nullptr; }
+const char* env_switch_table() {
+    static const std::string text = [] {
+        std::string t;
+        for (const EnvRow& r : kEnv) { t += r.name; t += '\t'; t += r.kind; t += '\t'; t += r.doc; t += '\n'; }
+        return t;
+    }();
+    return text.c_str();
+}
+
 void ensure_dynamic_lds(const void* fn, size_t bytes) {
     static std::mutex mu;
     static std::set<std::tuple<int, const void*, size_t>> done;

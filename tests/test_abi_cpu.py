@@ -145,3 +145,23 @@ def test_group_entry_points_fail_cleanly_without_rccl():
     env = dict(os.environ, NC_RCCL_LIB="/nonexistent/librccl-not-here.so")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout, r.stderr)
+
+
+def test_every_diagnostic_switch_is_in_the_one_table_and_documented():
+    """the switches were 51 scattered getenv calls.  They now live in ONE table (csrc/nc_util.hip) that the accessors
+    enforce; nc_debug_switches() lists it.  Hold the sources and DESIGN.md 10 to it."""
+    import glob
+    import re
+    rows = [ln.split("\t") for ln in _lib.lib().nc_debug_switches().decode().splitlines()]
+    names = {r[0] for r in rows}
+    assert len(rows) == len(names) >= 50 and all(len(r) == 3 and r[1] in "bpis" and r[2] for r in rows)
+    src_dir = os.path.join(ROOT, "neuralcodecs_amd", "csrc")
+    for path in glob.glob(os.path.join(src_dir, "*.hip")) + glob.glob(os.path.join(src_dir, "*.h")):
+        text = open(path).read()
+        if not path.endswith("nc_util.hip"):
+            assert "getenv" not in text, f"{os.path.basename(path)} reads the environment directly: use env_flag / env_int / env_str (nc_common.h)"
+        for name in re.findall(r'env_(?:flag|present|int|str)\("(\w+)"', text) + re.findall(r'experiment_mode\("(\w+)"\)', text):
+            assert name in names, f"{os.path.basename(path)}: {name} is not in the table"
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    missing = sorted(n for n in names if n not in design)
+    assert not missing, f"DESIGN.md 10 does not mention {missing}"
