@@ -11,6 +11,16 @@ struct DwConvLayer {
     bool has_bias = false;
     void build(const float* dense_w, const float* bias_h, int C, int K, int pad, int dil);
 };
+// SNAC residual unit (depthwise k = 7 + Snake + pointwise + skip) in one launch: nc_snac_unit.hip
+struct SnacFusedUnit {
+    int C = 0, dil = 1;
+    bool ready = false, has_b1 = false;
+    DevBuf w1, tab, b1;
+    static bool supported(int C, int K, int dil);
+    void build(int C, int dil, const float* w7, const float* b7, const float* a1, const float* a2, const float* w1_dense, const float* b1);
+    bool usable(const float* x, const float* y, int64_t T, int B) const;
+    void launch(const float* x, const float* alpha_next, float* y, int B, int64_t T, int cu_count, hipStream_t s, Profiler* prof) const;
+};
 void launch_dwconv(const DwConvLayer& L, const float* x, const float* alpha_in, const float* alpha_out, float* y, int B, int64_t T,
                    hipStream_t s, Profiler* prof);
 void launch_avg_pool(const float* x, float* y, int64_t rows, int64_t T, int s, hipStream_t st, Profiler* prof = nullptr);

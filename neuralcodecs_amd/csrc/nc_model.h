@@ -134,6 +134,7 @@ struct SnacModel : Codec {
         DwConvLayer dw;   // depthwise flavour
         ConvLayer c7;     // dense flavour (depthwise == 0)
         ConvLayer c1;
+        SnacFusedUnit fu; // depthwise flavour, narrow long rows: the whole unit in one launch
     };
     struct Mha {
         int C = 0;

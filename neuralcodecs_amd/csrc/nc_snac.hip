@@ -100,6 +100,13 @@ void SnacModel::load_res_unit(const Blob& b, const std::string& q, ResUnit& ru, 
     else load_dense(b, q + ".block.1", ru.c7, C, C, 7, 1, 3 * dil, dil, 0, false, NC_KC_CONV_K7);
     load_vec(b, q + ".block.2.alpha", C, ru.a2);
     load_dense(b, q + ".block.3", ru.c1, C, C, 1, 1, 0, 1, 0, false, NC_KC_CONV_K1);
+    if (cfg.depthwise && SnacFusedUnit::supported(C, 7, dil)) {   // the unit as one launch (nc_snac_unit.hip): same folded weights
+        std::vector<float> w7, w1;
+        const float* b7 = fold_conv(b, q + ".block.1", C, 1, 7, C, w7);
+        const float* b1 = fold_conv(b, q + ".block.3", C, C, 1, C, w1);
+        ru.fu.build(C, dil, w7.data(), b7, static_cast<const float*>(b.get(q + ".block.0.alpha").data),
+                    static_cast<const float*>(b.get(q + ".block.2.alpha").data), w1.data(), b1);
+    }
 }
 
 void SnacModel::load_mha(const Blob& b, const std::string& p, Mha& m, int C) {
@@ -241,6 +248,11 @@ float* SnacModel::run_res_unit(ResUnit& ru, float* cur, int C, int64_t L, int B,
     const int h_idx = (cur_idx + 1) % 3, o_idx = (cur_idx + 2) % 3;
     float* h = act[h_idx].as<float>();
     float* o = act[o_idx].as<float>();
+    if (cfg.depthwise && ru.fu.usable(cur, o, L, B)) {
+        ru.fu.launch(cur, alpha_next, o, B, L, cu_count, stream, &prof);
+        cur_idx = o_idx;
+        return o;
+    }
     if (cfg.depthwise) {
         launch_dwconv(ru.dw, cur, ru.a1.as<float>(), ru.a2.as<float>(), h, B, L, stream, &prof);
     } else {

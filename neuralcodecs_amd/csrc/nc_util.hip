@@ -67,6 +67,9 @@ const EnvRow kEnv[] = {
     {"NC_LSTM_FUSED", 'b', "fused two-layer persistent LSTM (nc_lstm.hip)"},
     {"NC_LSTM2_TRACE", 's', "file for the in-kernel stamps of the fused LSTM (tools/probe/lstm2_trace.py)"},
     {"NC_LSTM_FAKE_TIMEOUT", 'b', "tests: report the first persistent LSTM launch as timed out"},
+    {"NC_SNAC_NO_FUSE", 'b', "SNAC residual units in two launches (depthwise, pointwise)"},
+    {"NC_SNAC_FUSE_MIN_COLS", 'i', "columns (clips x steps) from which the one-launch SNAC residual unit is taken (65536)"},
+    {"NC_SNAC_UNIT_TRACE", 's', "file for the in-kernel stamps of the first one-launch SNAC residual unit at C = 96"},
     {"NC_DW_NO_VEC", 'b', "scalar depthwise kernel"},
     {"NC_LN_TILE", 'i', "LayerNorm tile width (8 | 16; 0 = one thread per column)"},
     {"NC_ATTN_NO_MFMA", 'b', "vector local-attention kernel"},

@@ -79,7 +79,8 @@ FALLBACK_ROWS = [
     {"NC_LSTM_STEPWISE": "1", "NC_NO_TINY_TILES": "1", "NC_NO_SUBPIXEL": "1"},         # step-wise LSTM, filled-grid tile rule, per-phase up-convs
     {"NC_NO_FUSE": "1", "NC_ENCODEC_NO_FUSE": "1", "NC_DAC_RVQ_STAGEWISE": "1"},       # two-launch residual units, padded copies, stage-wise RVQ
     {"NC_NO_FLAT_GN": "1", "NC_LSTM_NO_ELU": "1", "NC_NO_DIST_SMALL": "1", "NC_LSTM_UB": "2", "NC_NO_SUBPIXEL_ANY": "1"},   # one-clip GroupNorm tiles, ELU in the consumer, segmented staging, 8-wave LSTM
-    {"NC_LSTM_FUSED": "1"},                                                            # fused two-layer persistent LSTM (nc_lstm.hip)
+    {"NC_LSTM_FUSED": "1", "NC_SNAC_NO_FUSE": "1", "NC_ATTN_NO_MFMA": "1", "NC_LN_TILE": "0"},   # fused two-layer LSTM; SNAC units in two launches, vector attention, per-column LayerNorm
+    {"NC_SNAC_FUSE_MIN_COLS": "0", "NC_LN_TILE": "16"},                                # one-launch SNAC residual units on the small fixtures too
 ]
 
 
