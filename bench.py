@@ -205,6 +205,7 @@ def main():
     ap.add_argument("--config", default="dac44k", choices=("dac44k", "snac44k"), help="dac44k = BASELINE C2/C4 (headline); snac44k = C5 share per GPU")
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default: 32 for dac44k, 8 for snac44k)")
     ap.add_argument("--seconds", type=float, default=0.0, help="clip length (default: 1 s for dac44k, 5 s for snac44k)")
+    ap.add_argument("--pack-bits", type=int, default=0, help="N > 1: all-gather the codes bit-packed (10 for DAC's 1024-entry codebooks, 12 for SNAC)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=0, help="clips in the CPU-baseline sample (default: the whole batch of one step, BASELINE.md 3.1)")
     ap.add_argument("--cpu-iters", type=int, default=1, help="timed passes of the C-oracle baseline over the sample (median reported; one pass of the C2 batch is ~35 s)")
@@ -264,7 +265,7 @@ def main():
                 ev.record()
                 with torch.cuda.stream(side):
                     side.wait_event(ev)
-                    parallel.all_gather_levels(codes, world * B, out=gathered)
+                    parallel.all_gather_levels(codes, world * B, out=gathered, bits=args.pack_bits or None)
             audio = model.decode(codes, noise)
             if use_dist:
                 torch.cuda.current_stream().wait_stream(side)
@@ -290,7 +291,7 @@ def main():
                 ev.record()
                 with torch.cuda.stream(side):
                     side.wait_event(ev)
-                    parallel.all_gather_codes(codes, world * B, out=gathered)
+                    parallel.all_gather_codes(codes, world * B, out=gathered, bits=args.pack_bits or None)
             audio = model.decode(z)
             if use_dist:
                 torch.cuda.current_stream().wait_stream(side)
@@ -442,10 +443,12 @@ def main():
             metric = "audio-seconds/sec encode+decode (x real-time), SNAC-44.1kHz B=8 x 5 s per GPU"
             workload = "SNAC 44.1kHz + LocalMHA encode+decode, batch=%d x %.0f s clips per GPU (BASELINE configs[4] share)" % (B, seconds)
             coll = "RCCL all_gather of int64 codes [B,%d] (4 levels side by side) per rank" % sum(widths)
+            if args.pack_bits:
+                coll += ", %d-bit packed payload" % args.pack_bits
         else:
             metric = "audio-seconds/sec encode+decode (x real-time), DAC-44.1kHz B=32"
             workload = "DAC 44.1kHz 8kbps encode+decode, batch=%d x %.0f s clips per GPU (BASELINE configs[1])" % (B, seconds)
-            coll = "RCCL all_gather of int64 codes [B,9,87] per rank"
+            coll = "RCCL all_gather of int64 codes [B,9,87] per rank" + (", %d-bit packed payload" % args.pack_bits if args.pack_bits else "")
         out = {
             "metric": metric,
             "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -315,6 +315,11 @@ NC_API nc_status nc_group_create_rank(int32_t world, int32_t rank, const void* u
 NC_API nc_status nc_group_create_local(int32_t ndev, nc_codec* const* handles, nc_group** out);
 NC_API nc_status nc_group_destroy(nc_group* g);
 NC_API nc_status nc_group_info(const nc_group* g, int32_t* world, int32_t* rank /* -1 in local mode */);
+/* Payload of the code all-gather: bits = 0 (default) moves the int64 codes as they are; 1..24 moves them bit-packed in the wire layout of
+ * the reference's BitPacker (Modules/Encodec/BitPacker.cs: `bits` per value, LSB first, one packed row per clip; bits = 10 for 1024-entry
+ * codebooks, 12 for SNAC's 4096) -- 64 / bits times fewer bytes on xGMI; pack and unpack run on the device around the collective and
+ * the caller's tensors stay int64.  A code that does not fit `bits` is truncated to its low bits: pick bits >= log2(codebook size). */
+NC_API nc_status nc_group_set_code_bits(nc_group* g, int32_t bits);
 /* rank mode, device pointers, asynchronous: encode this rank's B_local clips (nc_dac_encode_dev / nc_snac_encode_dev semantics) with the
  * codes written straight into slot `rank` of codes_all [world*B_local, ...], then the in-place all-gather on the group's side stream.
  * B_local must be the same on every rank (a ragged batch: pad the short shards to the longest one and drop the padding rows).

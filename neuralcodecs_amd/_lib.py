@@ -128,6 +128,7 @@ SYMBOLS = [
     ("nc_group_create_local", C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P)]),
     ("nc_group_destroy", C.c_int, [_P]),
     ("nc_group_info", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("nc_group_set_code_bits", C.c_int, [_P, C.c_int32]),
     ("nc_group_dac_encode_allgather_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P]),
     ("nc_group_snac_encode_allgather_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
     ("nc_group_wait", C.c_int, [_P]),

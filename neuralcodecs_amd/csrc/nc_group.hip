@@ -114,6 +114,7 @@ struct PinBuf {
 
 struct nc_group {
     int world = 1, rank = -1;        // rank == -1: local mode (this process drives all `world` devices)
+    int code_bits = 0;               // > 0: the all-gather moves bit-packed codes (nc_group_set_code_bits)
     struct Member {
         nc_codec* h = nullptr;       // borrowed: the codec must outlive the group (nc_group_destroy before nc_codec_destroy)
         int device = 0;              // (kept here so that the destructor never reads through the borrowed handle)
@@ -121,6 +122,7 @@ struct nc_group {
         hipStream_t side = nullptr;
         hipEvent_t ev_enc = nullptr, ev_gather = nullptr;
         DevBuf pcm, codes_all, z;    // local mode staging
+        DevBuf packed_all;           // [world][slot bytes]: the packed payload of the collective (code_bits > 0)
         PinBuf pin_in, pin_out, pin_z;
     };
     std::vector<Member> m;
@@ -131,7 +133,7 @@ struct nc_group {
             if (x.side) (void)hipStreamDestroy(x.side);
             if (x.ev_enc) (void)hipEventDestroy(x.ev_enc);
             if (x.ev_gather) (void)hipEventDestroy(x.ev_gather);
-            x.pcm.release(); x.codes_all.release(); x.z.release();
+            x.pcm.release(); x.codes_all.release(); x.z.release(); x.packed_all.release();
             x.pin_in.release(); x.pin_out.release(); x.pin_z.release();
         }
     }
@@ -173,13 +175,37 @@ int64_t encode_into_slot(nc_group::Member& x, int kind, int slot, const float* p
     return per_rank;
 }
 
+// The all-gather of one member on its side stream.  code_bits == 0: the int64 slots in place.  code_bits > 0 (nc_group_set_code_bits): the
+// member packs its own slot into the wire layout of the reference's BitPacker (Modules/Encodec/BitPacker.cs: `bits` per value, LSB
+// first; one packed row per clip, csrc/nc_pack.hip), the collective moves the packed rows -- 64 / bits times fewer bytes -- and every
+// slot is unpacked back into the int64 tensor the caller sees.  rows = clips per slot, per_clip = values per clip.
+void gather_slots(nc_group* g, nc_group::Member& x, int slot, int64_t* codes_all, int rows, int64_t per_clip) {
+    const int64_t per_rank = (int64_t)rows * per_clip;
+    if (g->code_bits <= 0) {
+        NC_RCCL(rccl().AllGather(codes_all + (int64_t)slot * per_rank, codes_all, (size_t)per_rank, ncclInt64, x.comm, x.side));
+        return;
+    }
+    const int64_t row_bytes = nc_packed_bytes(per_clip, g->code_bits), slot_bytes = (int64_t)rows * row_bytes;
+    x.packed_all.reserve((size_t)slot_bytes * g->world);
+    uint8_t* pk = x.packed_all.as<uint8_t>();
+    nc_status st = nc_pack_codes_dev(x.device, codes_all + (int64_t)slot * per_rank, rows, 1, per_clip, g->code_bits, pk + (int64_t)slot * slot_bytes, x.side);
+    if (st != NC_OK) fail(st, "%s", get_last_error());
+    NC_RCCL(rccl().AllGather(pk + (int64_t)slot * slot_bytes, pk, (size_t)slot_bytes, ncclUint8, x.comm, x.side));
+}
+void unpack_slots(nc_group* g, nc_group::Member& x, int64_t* codes_all, int rows, int64_t per_clip) {
+    if (g->code_bits <= 0) return;
+    const nc_status st = nc_unpack_codes_dev(x.device, x.packed_all.as<uint8_t>(), rows * g->world, 1, per_clip, g->code_bits, codes_all, x.side);
+    if (st != NC_OK) fail(st, "%s", get_last_error());
+}
+
 void rank_encode_allgather(nc_group* g, int kind, const float* pcm, int B, int64_t T, int sample_rate, int n_q, int64_t* codes_all, float* z,
                            float* lat) {
     if (!g || g->rank < 0) fail(NC_EINVAL, "group was not created with nc_group_create_rank");
     if (!pcm || !codes_all || B <= 0 || T <= 0) fail(NC_EINVAL, "bad arguments");
     nc_group::Member& x = g->m[0];
     const int64_t per_rank = encode_into_slot(x, kind, g->rank, pcm, B, T, sample_rate, n_q, codes_all, z, lat);
-    NC_RCCL(rccl().AllGather(codes_all + (int64_t)g->rank * per_rank, codes_all, (size_t)per_rank, ncclInt64, x.comm, x.side));
+    gather_slots(g, x, g->rank, codes_all, B, per_rank / B);
+    unpack_slots(g, x, codes_all, B, per_rank / B);
     NC_HIP(hipEventRecord(x.ev_gather, x.side));
 }
 
@@ -248,13 +274,26 @@ void local_encode_allgather(nc_group* g, int kind, const float* pcm, int B_total
     }
     for (auto& e : errs)
         if (e) std::rethrow_exception(e);
+    if (g->code_bits > 0)   // (a device without clips still owns a slot: zero it so that its packed rows are defined)
+        for (int d = 0; d < W; ++d)
+            if (n_of(d) < B_max) {
+                nc_group::Member& x = g->m[(size_t)d];
+                (void)hipSetDevice(x.device);
+                NC_HIP(hipMemsetAsync(x.codes_all.as<int64_t>() + (int64_t)d * per_rank + (int64_t)n_of(d) * per_clip, 0,
+                                      (size_t)(B_max - n_of(d)) * per_clip * 8, x.side));
+            }
     NC_RCCL(rccl().GroupStart());
     for (int d = 0; d < W; ++d) {
         nc_group::Member& x = g->m[(size_t)d];
-        int64_t* all = x.codes_all.as<int64_t>();
-        NC_RCCL(rccl().AllGather(all + (int64_t)d * per_rank, all, (size_t)per_rank, ncclInt64, x.comm, x.side));
+        (void)hipSetDevice(x.device);
+        gather_slots(g, x, d, x.codes_all.as<int64_t>(), B_max, per_clip);
     }
     NC_RCCL(rccl().GroupEnd());
+    {   // only device 0's copy goes back to the host: it alone unpacks
+        nc_group::Member& x = g->m[0];
+        (void)hipSetDevice(x.device);
+        unpack_slots(g, x, x.codes_all.as<int64_t>(), B_max, per_clip);
+    }
     {   // every device now holds all codes; device 0's copy goes back to the host (pinned, then the valid rows of every slot)
         nc_group::Member& x = g->m[0];
         (void)hipSetDevice(x.device);
@@ -329,6 +368,14 @@ nc_status nc_group_create_local(int32_t ndev, nc_codec* const* handles, nc_group
 
 nc_status nc_group_destroy(nc_group* g) {
     return guard([&] { delete g; });
+}
+
+nc_status nc_group_set_code_bits(nc_group* g, int32_t bits) {
+    return guard([&] {
+        if (!g) fail(NC_EINVAL, "null group");
+        if (bits < 0 || bits > 24) fail(NC_EINVAL, "Bits must be between 1 and 24 (0 = unpacked int64 payload)");   // BitPacker.cs MaxBits
+        g->code_bits = bits;
+    });
 }
 
 nc_status nc_group_info(const nc_group* g, int32_t* world, int32_t* rank) {

@@ -23,14 +23,55 @@ def shard_sizes(n_clips: int, world: int) -> List[int]:
     return [shard_bounds(n_clips, world, r)[1] - shard_bounds(n_clips, world, r)[0] for r in range(world)]
 
 
-def all_gather_codes(codes, n_clips: int, group=None, out=None):
+def _pack_rows(codes, bits: int):
+    """[b, ...] int64 CUDA tensor -> [b, packed_bytes] uint8 (device kernel nc_pack_codes_dev: the BitPacker wire layout, `bits` per
+    value, one packed row per clip, values in the tensor's own element order)."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    if not codes.is_cuda:
+        raise ValueError("bit-packed all-gather payloads are packed by device kernels: the codes must live on the GPU")
+    b = int(codes.shape[0])
+    per = int(codes[0].numel()) if b else 0
+    L = _lib.lib()
+    nb = int(L.nc_packed_bytes(per, bits))
+    out = torch.empty((b, nb), dtype=torch.uint8, device=codes.device)
+    if b:
+        c = codes.contiguous().to(torch.int64)
+        _lib.check(L.nc_pack_codes_dev(codes.device.index or 0, c.data_ptr(), b, 1, per, bits, out.data_ptr(),
+                                       C.c_void_p(torch.cuda.current_stream(codes.device).cuda_stream)))
+    return out
+
+
+def _unpack_rows(packed, tail, bits: int, out=None):
+    import ctypes as C
+    import torch
+    from . import _lib
+    b = int(packed.shape[0])
+    per = 1
+    for d in tail:
+        per *= int(d)
+    if out is None:
+        out = torch.empty((b,) + tuple(tail), dtype=torch.int64, device=packed.device)
+    if b:
+        _lib.check(_lib.lib().nc_unpack_codes_dev(packed.device.index or 0, packed.contiguous().data_ptr(), b, 1, per, bits, out.data_ptr(),
+                                                  C.c_void_p(torch.cuda.current_stream(packed.device).cuda_stream)))
+    return out
+
+
+def all_gather_codes(codes, n_clips: int, group=None, out=None, bits: Optional[int] = None):
     """codes: this rank's [b_local, ...] integer tensor (torch).  Returns the [n_clips, ...] tensor of all ranks in clip order.
 
     Equal shards use one all_gather_into_tensor (a single RCCL collective); ragged shards are padded to the largest shard,
-    gathered, and the padding rows are dropped.
+    gathered, and the padding rows are dropped.  bits = 10 / 12 / ... moves the codes bit-packed (Modules/Encodec/BitPacker.cs
+    layout, packed and unpacked on the device: 64 / bits times fewer bytes over xGMI); the result is the same int64 tensor.
     """
     import torch
     import torch.distributed as dist
+    if bits:
+        tail = tuple(codes.shape[1:])
+        packed = all_gather_codes(_pack_rows(codes, int(bits)), n_clips, group=group)
+        return _unpack_rows(packed, tail, int(bits), out=out)
     world = dist.get_world_size(group)
     sizes = shard_sizes(n_clips, world)
     if codes.shape[0] != sizes[dist.get_rank(group)]:
@@ -57,11 +98,11 @@ def concat_levels(levels: Sequence, ) -> Tuple["object", List[int]]:
     return torch.cat([l.reshape(l.shape[0], -1) for l in levels], dim=-1), widths
 
 
-def all_gather_levels(levels: Sequence, n_clips: int, group=None, out=None):
+def all_gather_levels(levels: Sequence, n_clips: int, group=None, out=None, bits: Optional[int] = None):
     """SNAC.Encode's List<Tensor> (SNAC.cs:113-150) of this rank -> the [n_clips, sum(widths)] tensor of all ranks (levels of a clip
     side by side, the layout nc_snac_encode emits): one collective for all levels.  split_levels(result, widths) restores the list."""
     flat, _ = concat_levels(levels)
-    return all_gather_codes(flat.contiguous(), n_clips, group=group, out=out)
+    return all_gather_codes(flat.contiguous(), n_clips, group=group, out=out, bits=bits)
 
 
 def split_levels(flat, widths: Sequence[int]):
@@ -107,6 +148,11 @@ class Group:
         g = C.c_void_p()
         _lib.check(_lib.lib().nc_group_create_local(len(codecs), arr, C.byref(g)))
         return cls(g, len(codecs), -1, list(codecs))
+
+    def set_code_bits(self, bits: int) -> None:
+        """0 = int64 payload (default); 1..24 = the all-gather moves bit-packed codes (nc_group_set_code_bits)."""
+        from . import _lib
+        _lib.check(_lib.lib().nc_group_set_code_bits(self._g, int(bits)))
 
     def dispose(self):
         if self._g:

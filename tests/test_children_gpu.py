@@ -109,7 +109,7 @@ def test_bench_distributed_path_one_rank(config, steps):
     e = dict(os.environ, NC_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
              HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-extra",
-           "--config", config]
+           "--config", config] + (["--pack-bits", "12"] if config == "snac44k" else [])   # (the SNAC run also moves its codes bit-packed)
     r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

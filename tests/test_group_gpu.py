@@ -60,3 +60,62 @@ def test_snac_group_levels_in_one_collective():
         assert np.array_equal(a, b)
     loc.dispose()
     m.dispose()
+
+
+def test_bit_packed_all_gather_payload_equals_the_plain_one():
+    """nc_group_set_code_bits / parallel.all_gather_codes(bits=): the collective moves the codes in the BitPacker wire layout
+    (Modules/Encodec/BitPacker.cs; 10 bits for 1024-entry codebooks, 8 here for the fixtures' 64 / 256 entries) and every slot is
+    unpacked back on the device -- the int64 tensors the caller sees are those of the unpacked path, in rank and in local mode."""
+    import torch
+    import torch.distributed as dist
+    g = load_golden("dac_small")
+    cfg = dac_cfg_from_meta(g["meta"])
+    m = DAC(cfg)
+    m.load_blob(save_blob(dac_synthetic_state_dict(cfg, seed=g["meta"]["weight_seed"])))
+    pcm = synthetic_pcm(5, 1, 3000, cfg.sample_rate, seed=8)
+    _, codes, _, _, _ = m.encode(pcm)
+    grp = parallel.Group.rank(1, 0, parallel.Group.unique_id(), m)
+    for bits in (6, 7, 24, 0):                                # 64-entry codebooks: 6 bits is exact; 0 switches back to int64
+        grp.set_code_bits(bits)
+        _, call, _ = grp.dac_encode_allgather(torch.from_numpy(pcm).cuda())
+        grp.wait()
+        torch.cuda.synchronize()
+        assert np.array_equal(call.cpu().numpy(), codes), bits
+    with pytest.raises(ValueError):
+        grp.set_code_bits(25)                                 # BitPacker.cs MaxBits
+    grp.dispose()
+    loc = parallel.Group.local([m])
+    loc.set_code_bits(6)
+    assert np.array_equal(loc.dac_encode_allgather_host(pcm), codes)
+    loc.dispose()
+    # SNAC: the levels of a clip side by side, 256-entry codebooks
+    gs = load_golden("snac_small")
+    scfg = snac_cfg_from_meta(gs["meta"])
+    sm = SNAC(scfg)
+    sm.load_blob(save_blob(snac_synthetic_state_dict(scfg, seed=gs["meta"]["weight_seed"])))
+    spcm = synthetic_pcm(3, 1, 3001, scfg.sampling_rate, seed=6)
+    scodes = sm.encode(spcm)
+    sg = parallel.Group.rank(1, 0, parallel.Group.unique_id(), sm)
+    sg.set_code_bits(8)
+    flat, widths = sg.snac_encode_allgather(torch.from_numpy(spcm).cuda())
+    sg.wait()
+    torch.cuda.synchronize()
+    for a, b in zip(parallel.split_levels(flat.cpu().numpy(), widths), scodes):
+        assert np.array_equal(a, b)
+    sg.dispose()
+    sm.dispose()
+    # the torch.distributed form (bench.py --pack-bits), one rank on RCCL
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ct = torch.from_numpy(codes).cuda()
+        assert torch.equal(parallel.all_gather_codes(ct, ct.shape[0], bits=6), ct)
+        assert torch.equal(parallel.all_gather_codes(ct, ct.shape[0], bits=10), ct)
+        with pytest.raises(ValueError):
+            parallel.all_gather_codes(torch.from_numpy(codes), ct.shape[0], bits=6)     # packed payloads are device work
+    finally:
+        dist.destroy_process_group()
+    m.dispose()
