@@ -686,7 +686,7 @@ nc_status nc_op_conv1d_bench(int device_index, const nc_conv_desc* d, int32_t fu
             NC_HIP(hipMemset(gcnt.p, 0, (size_t)d->B * 4));
             if (!conv_gn_fusable(L, io)) fail(NC_EINVAL, "this layer cannot emit GroupNorm sums");
             io.gn_part = gpart.as<double>(); io.gn_nrb = nrb; io.gn_ncb = ncb;
-            io.gn_count = gcnt.as<unsigned>(); io.gn_stats = gstats.as<float>(); io.gn_n = (double)d->Cout * (double)Tout;
+            io.gn_count = gcnt.as<unsigned>(); io.gn_stats = gstats.as<float>(); io.gn_n = gn_count_arg((double)d->Cout * (double)Tout);
         }
         if (fuse & 16) {
             std::vector<float> st((size_t)d->B * 2), g((size_t)d->Cin * 2);

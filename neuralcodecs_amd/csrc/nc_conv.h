@@ -85,6 +85,13 @@ struct ConvArgs {
     double gn_n;
 };
 
+// ConvIO::gn_n as the kernels take it: the element count of a sample, NEGATED when NC_SYNC_ACQUIRE=1 asks the in-launch GroupNorm finish
+// (nc_gn.h) for an acquire fence in front of its reads.
+inline double gn_count_arg(double n) {
+    static const bool acquire = env_flag("NC_SYNC_ACQUIRE");
+    return acquire ? -n : n;
+}
+
 // Position of row (32*i + r) of a weight tile inside one kk row of BM = 32*TM floats.  The TM values of one matrix-core lane
 // (rows r, 32+r, ...) sit next to each other, so a lane fetches its A fragments with one wide LDS read (b64 / b128; TM = 3:
 // b64 + b32) whose address is lane base + immediate.

@@ -254,8 +254,9 @@ typedef __attribute__((address_space(3))) void* lstm_lptr;
 //     producer, relaxed), a workgroup barrier, and then read the h tile with relaxed AGENT-SCOPE (sc1) loads, which bypass the CU's L1
 //     and observe the producers' write-through stores directly -- the shipped build has NO acquire fence (the "sc1 stores and sc1
 //     loads both sides" form of MI355X_MICROARCH.md; ordering between the flag and the payload comes from the producer's vmcnt(0)
-//     drain before its flag store and the consumer's barrier before its loads).  -DNC_LSTM_FENCE builds the fence + plain-load
-//     variant (tools/probe/envmatrix.sh).  Layout [unit][16 clips] = the B-fragment order: every operand load is a 256-byte row.  Double-buffered by step parity: a
+//     drain before its flag store and the consumer's barrier before its loads).  NC_SYNC_ACQUIRE=1 adds the acquire fence behind the poll
+//     at run time (an operational fallback, exercised by tests/test_children_gpu.py); -DNC_LSTM_FENCE is the compile-time fence +
+//     plain-load variant (`make CXXFLAGS+=-DNC_LSTM_FENCE`; no envmatrix row builds it).  Layout [unit][16 clips] = the B-fragment order: every operand load is a 256-byte row.  Double-buffered by step parity: a
 //     workgroup can only publish h_{t+1} after every workgroup of the tile has published h_t, i.e. finished reading h_{t-1}.
 //   * Every spin is bounded: a timeout sets *tmo and all workgroups leave (the host reports NC_EDEVICE at the next synchronise).
 // Grid = (C/16, column tiles): at most 128 workgroups of 140 KB LDS per launch, all co-resident on the 256 CUs.
@@ -279,6 +280,9 @@ struct LstmSeqArgs {
     int64_t T;
     int64_t t0, t1;       // this launch runs steps [t0, t1) of the T-step sequence (state of step t0-1 in hx / cstate / flags)
     int tile0;            // first column tile of this launch
+    int acquire;          // NC_SYNC_ACQUIRE=1: agent-scope acquire fence behind the flag poll (the textbook hand-off; the default reads h with
+                          // agent-scope loads of drained write-through stores instead: validated by the parity sweeps and run in both forms by
+                          // tests/test_children_gpu.py)
 };
 typedef __attribute__((address_space(1))) unsigned lstm_gu32;
 // UB = unit blocks (of 4 hidden units) per workgroup: 4 (16 wavefronts, C/16 workgroups per column tile) or 2 (8 wavefronts, C/8
@@ -347,6 +351,8 @@ __global__ __launch_bounds__(256 * UB, 1) void lstm_seq_kernel(const LstmSeqArgs
                 }
 #ifdef NC_LSTM_FENCE
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+                if (a.acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
             }
             __syncthreads();
@@ -984,7 +990,7 @@ EncodecModel::GnJob EncodecModel::gn_begin(const ConvLayer& conv, ConvIO& io, in
         if (!no_finish && N <= GN_MAX_SAMPLES) {
             io.gn_count = gn_counters.as<unsigned>() + (size_t)cur_group * GN_MAX_SAMPLES;
             io.gn_stats = j.stats;
-            io.gn_n = (double)C * (double)L;
+            io.gn_n = gn_count_arg((double)C * (double)L);
             j.finished = true;
         }
     }
@@ -1288,6 +1294,8 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
                 a.cstate = cs[li] + (size_t)tl * C * 16;
                 a.flags = flags[li] + (size_t)tl * nprod; a.tmo = sync;
                 a.N = N; a.C = C; a.T = T; a.t0 = t0; a.t1 = t1; a.tile0 = tl;
+                static const bool sync_acquire = env_flag("NC_SYNC_ACQUIRE");
+                a.acquire = sync_acquire ? 1 : 0;
                 auto launch = [&](auto kern) {
                     ensure_dynamic_lds((const void*)kern, lds);
                     hipLaunchKernelGGL(kern, dim3((unsigned)nprod, (unsigned)nt), dim3(256 * UBW), lds, s, a);

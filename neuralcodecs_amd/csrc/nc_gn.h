@@ -113,6 +113,14 @@ __device__ __forceinline__ void nc_gn_arrive_blocks(const double* part0, unsigne
 }
 __device__ __forceinline__ void nc_gn_finish_sample(const double* part, unsigned* counter, float* stats, int n, double count) {
     const int lane = threadIdx.x & 63;
+    // count < 0 (host: NC_SYNC_ACQUIRE=1, gn_count_arg in nc_conv.h): an agent-scope acquire fence between the arrival that made this wave
+    // the last one and its reads of the block sums -- the textbook form of the hand-off.  The default relies on the reads being
+    // agent-scope (sc1) loads of write-through stores that were drained before the producers' arrivals (validated: parity sweeps, the
+    // fallback-switch suite runs both forms); the fence costs the last arriver ~1.7 us per sample and launch.
+    if (count < 0.0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        count = -count;
+    }
     double s1 = 0.0, s2 = 0.0;
     for (int k0 = 0; k0 < n; k0 += 64 * 4) {
         double a[4], c[4];

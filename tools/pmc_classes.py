@@ -21,9 +21,9 @@ import sys
 from collections import OrderedDict, defaultdict
 
 KC = ("conv_k7", "conv_k1", "conv_down", "conv_up", "conv_misc", "rvq", "elem", "dwconv", "norm", "attn", "lstm", "stem", "head")
-BY_NAME = [(r"conv1x1_kernel|conv1x1_stream_kernel|skinny_proj", "conv_k1"), (r"conv3_stream_kernel", "conv_misc"), (r"conv_small", "conv_down"),   # (the short-row kernel also serves two k=7 layers of the conv_misc class)
-           (r"dwconv_kernel|dwconv_vec_kernel", "dwconv"), (r"layernorm_ct|gn_block|gn_final|gn_", "norm"),
-           (r"local_attn", "attn"), (r"lstm_", "lstm"), (r"stem_", "stem"), (r"conv_thin(_inm)?_kernel", "head"),
+BY_NAME = [(r"conv1x1_kernel|conv1x1_stream_kernel|skinny_proj|snac_unit_kernel", "conv_k1"), (r"conv3_stream_kernel", "conv_misc"), (r"conv_small", "conv_down"),   # (the short-row kernel also serves two k=7 layers of the conv_misc class)
+           (r"dwconv_kernel|dwconv_vec_kernel", "dwconv"), (r"layernorm_ct|layernorm_tile|gn_block|gn_final|gn_", "norm"),
+           (r"local_attn", "attn"), (r"lstm_|lstm2_", "lstm"), (r"stem_", "stem"), (r"conv_thin(_inm)?_kernel", "head"),
            (r"vq_argmin|vq_gather|euclid_vq|euclid_rvq|dac_rvq|emb_sum", "rvq"),
            (r"avg_pool|rvq_update|pad_act|scale_kernel|overlap_add|rms_|randn", "elem")]
 
