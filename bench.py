@@ -158,7 +158,7 @@ def extra_configs(dev, steps, warmup, check):
         x = torch.from_numpy(xh).to(dev)
         frames = m.query(T)[1]
         nzh = snac_noise(cfg, B, frames, seed=3)
-        nz = [torch.from_numpy(n).to(dev) for n in nzh]
+        nz = m.flat_noise(nzh, dev)   # (the ABI's layout: views of one device buffer -- input preparation, outside the timed region)
 
         def snac_check(cfg=cfg, blob=blob, m=m, x=x, xh=xh, nz=nz, nzh=nzh):
             from oracle import c_oracle
@@ -254,7 +254,7 @@ def main():
         Tz = model.query(T)[1]
         widths = model.query(T)[2]
         noise_h = snac_noise(cfg, B, Tz, seed=3 + rank)
-        noise = [torch.from_numpy(n).to(dev) for n in noise_h]
+        noise = model.flat_noise(noise_h, dev)   # (the ABI's layout: views of one device buffer, prepared before the timed region)
         gathered = torch.empty((world * B, sum(widths)), dtype=torch.int64, device=dev) if use_dist else None
 
         def step():

@@ -128,8 +128,10 @@ class DAC(_lib.ProfileMixin):
             self._bind_torch_stream()
             _lib.check(_lib.lib().nc_dac_encode_dev(self._h, x.data_ptr(), B, T, sr, nq, codes.data_ptr(), z.data_ptr(),
                                                     lat.data_ptr()))
-            zero = torch.zeros((), device=x.device)
-            return z, codes, lat, zero, zero.clone()
+            zeros = self.__dict__.setdefault("_zero_losses", {})      # commitment / codebook loss: 0 in eval mode; allocated once per device
+            if x.device not in zeros:
+                zeros[x.device] = (torch.zeros((), device=x.device), torch.zeros((), device=x.device))
+            return (z, codes, lat) + zeros[x.device]
         x = np.ascontiguousarray(audio_data, dtype=np.float32)
         codes = np.empty((B, nq, Tz), np.int64)
         z = np.empty((B, self.latent_dim, Tz), np.float32)

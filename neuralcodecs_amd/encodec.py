@@ -187,8 +187,14 @@ class Encodec(_lib.ProfileMixin):
             raise ValueError(f"frames do not match the segment layout of a {T}-sample clip: expected {lens}")
         if _is_torch(frames[0].codes):
             import torch
-            codes = torch.cat([f.codes.reshape(-1).to(torch.int64) for f in frames]).contiguous()
-            scales = torch.cat([f.scale.reshape(-1).to(torch.float32) for f in frames]).contiguous() if self.config.normalize else None
+            codes = self._end_to_end([f.codes for f in frames], torch.int64)      # encode()'s own views: the ABI's flat buffers as they are
+            if codes is None:
+                codes = torch.cat([f.codes.reshape(-1).to(torch.int64) for f in frames]).contiguous()
+            scales = None
+            if self.config.normalize:
+                scales = self._end_to_end([f.scale for f in frames], torch.float32)
+                if scales is None:
+                    scales = torch.cat([f.scale.reshape(-1).to(torch.float32) for f in frames]).contiguous()
             out = torch.empty((B, self.config.channels, Ld), dtype=torch.float32, device=codes.device)
             self._bind_torch_stream()
             _lib.check(_lib.lib().nc_encodec_decode_dev(self._h, codes.data_ptr(), scales.data_ptr() if scales is not None else None,
@@ -202,6 +208,20 @@ class Encodec(_lib.ProfileMixin):
         _lib.check(_lib.lib().nc_encodec_decode(self._h, codes.ctypes.data, scales.ctypes.data if scales is not None else None, B, T, nq,
                                                 out.ctypes.data))
         return out
+
+    @staticmethod
+    def _end_to_end(parts, dtype):
+        """The flat tensor the parts are consecutive contiguous views of (what encode() hands out), or None.  No copy, no kernel."""
+        try:
+            p0 = parts[0]
+            base, off = p0.untyped_storage().data_ptr(), p0.storage_offset()
+            for p in parts:
+                if p.dtype != dtype or not p.is_contiguous() or p.untyped_storage().data_ptr() != base or p.storage_offset() != off:
+                    return None
+                off += p.numel()
+            return p0.as_strided((off - p0.storage_offset(),), (1,), p0.storage_offset())
+        except Exception:
+            return None
 
     def _infer_length(self, frames) -> int:
         """Clip length implied by the frames alone, as the reference's Decode(List<EncodedFrame>) sees them (Encodec.cs:213-235):

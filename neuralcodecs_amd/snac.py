@@ -172,6 +172,51 @@ class SNAC(_lib.ProfileMixin):
             raise ValueError(f"Expected {len(self.config.vq_strides)} codebooks but got {len(codes)}")   # SNAC RVQ.cs:103
         return codes
 
+    @staticmethod
+    def _as_one_buffer(parts, B: int):
+        """The [B, sum(widths)] int64 tensor the parts are column views of (what encode() hands out), or None.  No copy, no kernel."""
+        try:
+            p0 = parts[0]
+            total = sum(int(p.shape[-1]) for p in parts)
+            base, off = p0.untyped_storage().data_ptr(), p0.storage_offset()
+            for p in parts:
+                if (p.dtype != p0.dtype or p.dim() != 2 or p.shape[0] != B or p.untyped_storage().data_ptr() != base or p.storage_offset() != off
+                        or (B > 1 and p.stride(0) != total) or (p.shape[-1] > 1 and p.stride(1) != 1)):
+                    return None
+                off += int(p.shape[-1])
+            return p0.as_strided((B, total), (total, 1), p0.storage_offset())
+        except Exception:
+            return None
+
+    @staticmethod
+    def _noise_end_to_end(parts):
+        try:
+            import torch
+            p0 = parts[0]
+            base, off = p0.untyped_storage().data_ptr(), p0.storage_offset()
+            for p in parts:
+                if p.dtype != torch.float32 or not p.is_contiguous() or p.untyped_storage().data_ptr() != base or p.storage_offset() != off:
+                    return None
+                off += p.numel()
+            return p0.as_strided((off - p0.storage_offset(),), (1,), p0.storage_offset())
+        except Exception:
+            return None
+
+    def flat_noise(self, noise: Sequence, device=None):
+        """The NoiseBlock inputs in the layout the C ABI takes them (one block per decoder stage laid end to end, nc_snac_decode): returns
+        the list again, now as views of ONE device buffer, so that decode() passes the buffer without copying.  Input preparation:
+        do it once per noise draw, outside a timed region."""
+        import torch
+        flat = torch.cat([torch.as_tensor(n, dtype=torch.float32).reshape(-1) for n in noise]).contiguous()
+        if device is not None:
+            flat = flat.to(device)
+        out, o = [], 0
+        for n in noise:
+            k = int(np.prod(n.shape))
+            out.append(flat[o:o + k].view(tuple(n.shape)))
+            o += k
+        return out
+
     def decode(self, codes: Sequence, noise: Optional[Sequence] = None, seed: int = 0):
         codes = self._flat_codes(codes)
         B = codes[0].shape[0]
@@ -184,11 +229,15 @@ class SNAC(_lib.ProfileMixin):
             L = (L - 1) * s - 2 * (-(-s // 2)) + 2 * s + (s % 2)
         if _is_torch(codes[0]):
             import torch
-            flat = torch.cat([c.reshape(B, -1).to(torch.int64) for c in codes], dim=1).contiguous()
+            flat = self._as_one_buffer(codes, B) if codes[0].dtype == torch.int64 else None   # encode()'s own views: the ABI's flat buffer as it is
+            if flat is None:
+                flat = torch.cat([c.reshape(B, -1).to(torch.int64) for c in codes], dim=1).contiguous()
             out = torch.empty((B, 1, L), dtype=torch.float32, device=flat.device)
             nz = None
             if noise is not None and self.config.noise:
-                nz = torch.cat([n.reshape(-1).to(torch.float32) for n in noise]).contiguous()
+                nz = self._noise_end_to_end(noise)                        # views of one flat buffer (flat_noise()): passed as it is
+                if nz is None:
+                    nz = torch.cat([n.reshape(-1).to(torch.float32) for n in noise]).contiguous()
             self._bind_torch_stream()
             _lib.check(_lib.lib().nc_snac_decode_dev(self._h, flat.data_ptr(), B, frames, nz.data_ptr() if nz is not None else None,
                                                      seed, out.data_ptr()))

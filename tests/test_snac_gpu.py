@@ -134,6 +134,17 @@ def test_snac_device_tensor_api_and_batch_invariance():
     torch.cuda.synchronize()
     assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(dc, codes))
     assert np.array_equal(da.cpu().numpy(), m.decode(codes, nz))
+    # marshalling fast paths: encode()'s level views and flat_noise()'s views are handed to the ABI as the flat buffers underneath
+    # (no copy); lists assembled from other tensors take the concatenating path -- same result either way
+    assert m._as_one_buffer(dc, 3) is not None and m._as_one_buffer([c.clone() for c in dc], 3) is None
+    fn = m.flat_noise(nz, "cuda")
+    assert m._noise_end_to_end(fn) is not None and all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(fn, nz))
+    d1 = m.decode(dc, fn)
+    d2 = m.decode([c.clone() for c in dc], [n.clone() for n in fn])
+    fn[0].zero_()                                                      # in-place change of the noise must reach the next decode (nothing is cached)
+    d3 = m.decode(dc, fn)
+    torch.cuda.synchronize()
+    assert torch.equal(d1, da) and torch.equal(d2, da) and not torch.equal(d3, da)
     m.dispose()
 
 

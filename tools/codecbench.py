@@ -59,7 +59,7 @@ def main():
             T = int(secs * cfg.sampling_rate)
             x = torch.from_numpy(synthetic_pcm(B, 1, T, cfg.sampling_rate, seed=1)).to(dev)
             frames = m.query(T)[1]
-            nz = [torch.from_numpy(n).to(dev) for n in snac_noise(cfg, B, frames, seed=3)]
+            nz = m.flat_noise(snac_noise(cfg, B, frames, seed=3), dev)   # the ABI layout: views of one device buffer, prepared once
             dt = timed(lambda: m.decode(m.encode(x), nz), a.steps, a.warmup)
             out[name] = {"ms": round(dt * 1e3, 3), "x_realtime": round(B * secs / dt, 1), "B": B, "seconds": secs}
             if a.classes:
