@@ -817,11 +817,11 @@ void EncodecModel::load_lstm(const Blob& b, const std::string& key, Lstm& l, int
         }
         upload(y.bhh, static_cast<const float*>(bhh.data), (size_t)4 * C);
         upload(y.bih, static_cast<const float*>(bih.data), (size_t)4 * C);
-        if (lstm2_supported(C) && cfg.lstm_layers == 2) {   // images of the fused two-layer kernel: W_hh of both layers, W_ih of the upper one
+        if (lstm2_supported(C)) {   // fragment images of nc_lstm.hip: W_hh of every layer (per-layer split kernel), W_ih of the upper one (fused kernel)
             std::vector<float> img((size_t)4 * C * C);
             lstm2_pack_image(static_cast<const float*>(whh.data), C, img.data());
             upload(y.w2hh, img.data(), img.size());
-            if (i == 1) {
+            if (i == 1 && cfg.lstm_layers == 2) {
                 lstm2_pack_image(static_cast<const float*>(wih.data), C, img.data());
                 upload(y.w2ih, img.data(), img.size());
             }
@@ -1253,15 +1253,31 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
             static bool fake = env_flag("NC_LSTM_FAKE_TIMEOUT");
             if (fake) { fake = false; *reinterpret_cast<volatile unsigned*>(lstm_tmo_host) = 1; }
         }
+        // Role-split kernel (nc_lstm.hip lstm1_kernel, round 4, NC_LSTM_SPLIT=1): the same launches and chunk schedule, but load-only chain
+        // waves, store-only gate waves and exchange regions that are never reused and validated by value -- no drain.  Bit-exact and
+        // MEASURED SLOWER than lstm_seq_kernel (C3 10.1-10.2 against 9.07-9.15 ms on the same box, 16 clips at 24 kHz 6.75-6.9 against 5.6),
+        // with the flags polled by a gate wave and by a (load-only) chain wave alike: without the drain the hint flags run ahead of
+        // the payload, so operand loads are retried, and the LDS post / wait hops between chain, gate and polling waves cost more than
+        // the two workgroup barriers they replace.  Not the default; DESIGN 8 round 4.
+        static const bool want_split = env_flag("NC_LSTM_SPLIT");
+        const bool split = want_split && lstm2_supported(C) && l.layers[0]->w2hh.p && lds_per_cu >= lstm1_lds_bytes(C) &&
+                           (size_t)T * n_tiles * C * 16 * 4 < ((size_t)1 << 31);
         std::vector<float*> gi(nl), out(nl), hx(nl), cs(nl);
         std::vector<unsigned*> flags(nl);
         for (int li = 0; li < nl; ++li) {
             gi[li] = alloc((size_t)N * 4 * C * T);
             out[li] = alloc((size_t)N * C * T);
-            hx[li] = alloc((size_t)2 * n_tiles * C * 16);
             cs[li] = alloc((size_t)n_tiles * C * 16);
-            flags[li] = reinterpret_cast<unsigned*>(alloc((size_t)n_tiles * nprod));   // per call + layer: groups may run concurrently
-            NC_HIP(hipMemsetAsync(flags[li], 0, (size_t)n_tiles * nprod * 4, stream));
+            if (split) {
+                hx[li] = alloc((size_t)T * n_tiles * C * 16);                          // one exchange region per step
+                NC_HIP(hipMemsetAsync(hx[li], 0xFF, (size_t)T * n_tiles * C * 16 * 4, stream));   // LSTM2_SENTINEL in every word
+                flags[li] = reinterpret_cast<unsigned*>(alloc((size_t)n_tiles * (C / 4)));
+                NC_HIP(hipMemsetAsync(flags[li], 0, (size_t)n_tiles * (C / 4) * 4, stream));
+            } else {
+                hx[li] = alloc((size_t)2 * n_tiles * C * 16);
+                flags[li] = reinterpret_cast<unsigned*>(alloc((size_t)n_tiles * nprod));   // per call + layer: groups may run concurrently
+                NC_HIP(hipMemsetAsync(flags[li], 0, (size_t)n_tiles * nprod * 4, stream));
+            }
         }
         hipStream_t sA = stream, sB = stream;
         size_t ev_i = 0;
@@ -1282,7 +1298,19 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
             const bool last = li + 1 == nl;
             const double n = (double)N * (double)(t1 - t0);
             if (prof.on) prof.begin(s, NC_KC_LSTM, 2.0 * 4 * C * C * n, 4.0 * 6 * C * n);
-            for (int tl = 0; tl < n_tiles; tl += per_launch) {
+            for (int tl = 0; split && tl < n_tiles; tl += 4) {                         // (C / 16 workgroups per tile: up to four tiles per launch)
+                const int nt = std::min(4, n_tiles - tl);
+                LstmSplitArgs a{};
+                a.gi = gi[li]; a.w = y.w2hh.as<float>(); a.bhh = y.bhh.as<float>(); a.skip = last ? x : nullptr; a.out = out[li]; a.elu_out = (last && elu_out) ? 1 : 0;
+                if (piped) { a.gi_b = 1; a.gi_c = T * N; a.gi_t = N; }
+                else { a.gi_b = (int64_t)4 * C * T; a.gi_c = T; a.gi_t = 1; }
+                if (between(li)) { a.out_b = 1; a.out_c = T * N; a.out_t = N; }
+                else { a.out_b = (int64_t)C * T; a.out_c = T; a.out_t = 1; }
+                a.S = hx[li]; a.flags = flags[li]; a.tmo = sync; a.cstate = cs[li];
+                a.N = N; a.C = C; a.T = T; a.t0 = t0; a.t1 = t1; a.tile0 = tl; a.tiles_total = n_tiles;
+                lstm1_launch(a, nt, s);
+            }
+            for (int tl = 0; !split && tl < n_tiles; tl += per_launch) {
                 const int nt = std::min(per_launch, n_tiles - tl);
                 LstmSeqArgs a{};
                 a.gi = gi[li]; a.whhp = y.whhp.as<float>(); a.bhh = y.bhh.as<float>(); a.skip = last ? x : nullptr; a.out = out[li]; a.elu_out = (last && elu_out) ? 1 : 0;

@@ -33,6 +33,26 @@ struct Lstm2Args {
 constexpr int LSTM2_TRACE_T0 = 64, LSTM2_TRACE_STEPS = 8;
 constexpr unsigned LSTM2_SENTINEL = 0xFFFFFFFFu;   // a NaN pattern no gate output can take (|h| < 1); the byte memset value 0xFF
 
+// Per-layer launch with the same protocol (one layer, `tiles` column tiles starting at tile0, steps [t0, t1) of T): see nc_lstm.hip
+struct LstmSplitArgs {
+    const float* gi;       // input projections incl. b_ih, element strides (gi_b, gi_c, gi_t) over (clip, channel row, step)
+    const float* w;        // W_hh fragment images (lstm2_pack_image)
+    const float* bhh;      // [4C]
+    const float* skip;     // nullable [N,C,T]
+    float* out;            // strides (out_b, out_c, out_t)
+    int elu_out;
+    float* S;              // exchange regions [T][tiles_total][C*16], filled with LSTM2_SENTINEL words once per call
+    unsigned* flags;       // [tiles_total][C/4], zeroed once per call
+    unsigned* tmo;
+    float* cstate;         // [tiles_total][C][16] cell state carried between chunk launches
+    int64_t gi_b, gi_c, gi_t, out_b, out_c, out_t;
+    int N, C;
+    int64_t T, t0, t1;
+    int tile0, tiles_total;
+};
+size_t lstm1_lds_bytes(int C);
+void lstm1_launch(const LstmSplitArgs& a, int tiles, hipStream_t stream);
+
 size_t lstm2_lds_bytes(int C, int tiles);
 size_t lstm2_exchange_floats(int C, int64_t T, int tiles);
 bool lstm2_supported(int C);

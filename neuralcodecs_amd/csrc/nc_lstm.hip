@@ -57,10 +57,12 @@ struct Ctx {
     int lane, u, tiles, gl;       // gl: tile index within the launch
     int region_bytes;             // C * 16 * 4
     unsigned long long* tr;       // this wave's trace rows (nullable)
+    unsigned* tmo;                // timeout word
+    int64_t T;
 };
 
 __device__ __forceinline__ int region_off(const Ctx& c, int layer, int64_t t) {
-    return (int)(((int64_t)layer * c.a->T + t) * c.tiles + c.gl) * c.region_bytes;
+    return (int)(((int64_t)layer * c.T + t) * c.tiles + c.gl) * c.region_bytes;
 }
 
 __device__ __forceinline__ void stamp(const Ctx& c, int64_t t, int slot) {
@@ -70,7 +72,7 @@ __device__ __forceinline__ void stamp(const Ctx& c, int64_t t, int slot) {
 
 __device__ __forceinline__ void give_up(const Ctx& c) {
     if (c.lane == 0) {
-        __hip_atomic_store((l2_gu32*)c.a->tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((l2_gu32*)c.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *c.dead = 1u;
     }
 }
@@ -98,13 +100,12 @@ __device__ __forceinline__ bool lds_wait_ge(const Ctx& c, volatile unsigned* f, 
 // its own publish) and hands the answer to the chain waves through LDS: with every chain wave polling for itself, 1536 polling waves
 // kept the few lines that hold the flags so busy that a poll took 2-3 us and the workgroups drifted 4 us apart (trace, round 4).
 __device__ __forceinline__ bool poll_flags(const Ctx& c, const unsigned* f, int n, unsigned want) {
-    __builtin_amdgcn_s_sleep(6);                                      // nobody can be complete before the others have stored as well
     for (unsigned spins = 0; spins < L2_SPINS; ++spins) {
         unsigned v = c.lane < n ? __hip_atomic_load((l2_gu32*)(f + c.lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
         if (c.lane + 64 < n) v = min(v, __hip_atomic_load((l2_gu32*)(f + c.lane + 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         if (__all(v >= want)) return true;
         if ((spins & 255u) == 255u &&
-            (*c.dead || __hip_atomic_load((l2_gu32*)c.a->tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) return false;
+            (*c.dead || __hip_atomic_load((l2_gu32*)c.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) return false;
         __builtin_amdgcn_s_sleep(4);
     }
     give_up(c);
@@ -124,7 +125,7 @@ __device__ __forceinline__ bool load_valid(const Ctx& c, int off, u32x4v (&hb)[N
             ok = ok && hb[g].x != LSTM2_SENTINEL && hb[g].y != LSTM2_SENTINEL && hb[g].z != LSTM2_SENTINEL && hb[g].w != LSTM2_SENTINEL;
         if (__all(ok)) return true;
         if ((spins & 63u) == 63u &&
-            (*c.dead || __hip_atomic_load((l2_gu32*)c.a->tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) return false;
+            (*c.dead || __hip_atomic_load((l2_gu32*)c.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) return false;
         __builtin_amdgcn_s_sleep(2);
     }
     give_up(c);
@@ -150,7 +151,10 @@ __device__ __forceinline__ void chain_role(const Ctx& c, const f32x4v* W, float*
         f32x4v acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
         if (t > 0) {                                                  // h_{-1} = 0: every quarter chain of step 0 is +0
             stamp(c, t, 0);
-            if (!lds_wait_ge(c, ready, (unsigned)t)) return;
+            if (w == 0) {                                             // the polling wave of a tile and layer is a chain wave (load-only)
+                if (!poll_flags(c, c.a->flags + ((int64_t)c.gl * 2 + layer) * (NG * 4), NG * 4, (unsigned)t)) return;
+                lds_post(ready, (unsigned)t);
+            } else if (!lds_wait_ge(c, ready, (unsigned)t)) return;
             stamp(c, t, 1);
             u32x4v hb[NGH];
             if (!load_valid<NGH>(c, region_off(c, layer, t - 1) + (w * NGH * 64 + c.lane) * 16, hb)) return;
@@ -171,6 +175,10 @@ __device__ __forceinline__ void chain_role(const Ctx& c, const f32x4v* W, float*
         P[64] = acc1;
         lds_post(posted, (unsigned)(t + 1));
         stamp(c, t, 3);
+    }
+    if (layer == 0 && w == 0) {                                        // the projection chain of layer 1 still waits for the last h0
+        if (!poll_flags(c, c.a->flags + ((int64_t)c.gl * 2 + layer) * (NG * 4), NG * 4, (unsigned)T)) return;
+        lds_post(ready, (unsigned)T);
     }
 }
 
@@ -285,10 +293,6 @@ __device__ __forceinline__ void gate_role(const Ctx& c, float* part, float* ih, 
         }
         if (layer == 1 && b < N) orow[t] = a.elu_out ? nc_eluf(yo) : yo;
         stamp(c, t, 3);
-        if (layer == 0 || t + 1 < T) {                                  // every workgroup's h of this step is (about to be) there: tell the chains
-            if (!poll_flags(c, flag - c.u, NG * 4, (unsigned)(t + 1))) return;
-            lds_post(c.sync + (layer == 0 ? SY_READY0 : SY_READY1), (unsigned)(t + 1));
-        }
     }
 }
 
@@ -314,6 +318,8 @@ __global__ __launch_bounds__(1024, 1) void lstm2_kernel(const Lstm2Args a) {
     __syncthreads();                                                     // the only workgroup barrier of the launch
     Ctx c;
     c.a = &a;
+    c.tmo = a.tmo;
+    c.T = a.T;
     c.tiles = a.tiles;
     c.region_bytes = a.C * 16 * 4;
     c.rs = __builtin_amdgcn_make_buffer_rsrc(a.S, 0, (int)((int64_t)2 * a.T * a.tiles * a.C * 16 * 4), 0x00020000);
@@ -342,6 +348,143 @@ __global__ __launch_bounds__(1024, 1) void lstm2_kernel(const Lstm2Args a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Per-layer form (round 4, second attempt): ONE layer, ONE 16-row column tile per workgroup, the exchange among the C / 16 = 32
+// workgroups of a tile as in lstm_seq_kernel (nc_encodec.hip) -- the fused kernel above showed that an exchange among 128 costs more than
+// the drain it removes saves -- but with the fused kernel's protocol: load-only chain wavefronts, store-only gate wavefronts, never-reused
+// exchange regions validated by value (no drain), one polling wave per workgroup, no workgroup barrier in the loop.  Workgroup m owns the
+// 16 hidden units of exchange group m: 8 chain waves (4 unit blocks x 2 halves of the reduction, two quarter chains side by side each)
+// and 4 gate waves; the chain waves hand the gate wave q0 + q1 and q2 + q3 (the canonical (q0 + q1) + (q2 + q3) finishes there).
+// Same LstmSeq-style arguments as the kernel it replaces: chunked launches resume from carried state, operand layouts by strides.
+struct Lstm1Args {
+    const float* gi; const float* w; const float* bhh; const float* skip; float* out; int elu_out;
+    float* S;              // exchange regions [T][tiles of the CALL][C * 16], sentinel-filled once per call
+    unsigned* flags;       // [tiles of the call][C / 4]
+    unsigned* tmo; float* cstate;
+    int64_t gi_b, gi_c, gi_t, out_b, out_c, out_t;
+    int N, C; int64_t T, t0, t1; int tile0, tiles_total;
+};
+constexpr int L1_PART = 2 * 4 * 2 * 256;   // [parity][unit block][half][64 x 4]
+constexpr int L1_HTR = 4 * 64;
+enum { S1_P = 0 /* 8 words: [unit block][half] */, S1_READY = 8, S1_DEAD = 9 };
+
+template <int NG>
+__global__ __launch_bounds__(768, 1) void lstm1_kernel(const Lstm1Args a) {
+    extern __shared__ __attribute__((aligned(16))) float l1_lds[];   // W [4 unit blocks][NG][64][4] | part | htr | sync
+    constexpr int IMG = NG * 64 * 4, NGH = NG / 2, NGQ = NG / 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = blockIdx.x, tile = a.tile0 + blockIdx.y;
+    float* const Wf = l1_lds;
+    for (int ch = wave; ch < 4 * NG; ch += 12) {
+        const float* src = a.w + ((int64_t)(4 * m) * NG + ch) * 256 + lane * 4;      // images of unit blocks 4m .. 4m + 3 are contiguous
+        __builtin_amdgcn_global_load_lds((l2_gptr)src, (l2_lptr)(Wf + ch * 256), 16, 0, 0);
+    }
+    float* const part = l1_lds + 4 * IMG;
+    float* const htr = part + L1_PART;
+    volatile unsigned* const sync = reinterpret_cast<volatile unsigned*>(htr + L1_HTR);
+    if (wave == 0 && lane < 16) sync[lane] = 0u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    Ctx c;
+    c.a = nullptr;
+    c.tiles = a.tiles_total;
+    c.region_bytes = a.C * 16 * 4;
+    c.rs = __builtin_amdgcn_make_buffer_rsrc(a.S, 0, (int)((int64_t)a.T * a.tiles_total * a.C * 16 * 4), 0x00020000);
+    c.sync = sync;
+    c.dead = sync + S1_DEAD;
+    c.lane = lane;
+    c.u = m;
+    c.gl = tile;
+    c.tr = nullptr;
+    c.tmo = a.tmo;
+    c.T = a.T;
+    const int64_t T = a.T;
+    unsigned* const flags = a.flags + (int64_t)tile * (NG * 4);
+    if (wave < 8) {
+        // ---- chain wave: unit block kap, half w of the reduction
+        const int kap = wave >> 1, w = wave & 1;
+        const f32x4v* Wl = reinterpret_cast<const f32x4v*>(Wf + kap * IMG) + (w * NGH) * 64 + lane;
+        __builtin_amdgcn_s_setprio(2);
+        for (int64_t t = a.t0; t < a.t1; ++t) {
+            f32x4v acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (t > 0) {
+                // the polling wave of the workgroup is a CHAIN wave: it never stores, so its polls do not queue behind store
+                // acknowledgements (a gate wave polling after its own publish waits ~1 us for them: the drain again, measured)
+                if (wave == 0) {
+                    if (!poll_flags(c, flags, NG * 4, (unsigned)t)) return;
+                    lds_post(sync + S1_READY, (unsigned)t);
+                } else if (!lds_wait_ge(c, sync + S1_READY, (unsigned)t)) return;
+                u32x4v hb[NGH];
+                if (!load_valid<NGH>(c, region_off(c, 0, t - 1) + (w * NGH * 64 + lane) * 16, hb)) return;
+#pragma unroll
+                for (int g = 0; g < NGQ; ++g) {
+                    const f32x4v a0 = Wl[g * 64], a1 = Wl[(NGQ + g) * 64];
+                    const f32x4v b0 = __builtin_bit_cast(f32x4v, hb[g]), b1 = __builtin_bit_cast(f32x4v, hb[NGQ + g]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b1[e], acc1, 0, 0, 0);
+                    }
+                }
+            }
+            f32x4v s2;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) s2[v] = acc0[v] + acc1[v];          // q_{2w} + q_{2w+1}
+            *(reinterpret_cast<f32x4v*>(part + (((int)(t & 1) * 4 + kap) * 2 + w) * 256) + lane) = s2;
+            lds_post(sync + S1_P + kap * 2 + w, (unsigned)(t + 1));
+        }
+        return;
+    }
+    // ---- gate wave of unit block kap: lane (i = lane >> 4, n = lane & 15) -> unit 16 m + 4 i + kap, clip n of the tile
+    const int kap = wave - 8, io = lane >> 4, n = lane & 15;
+    const int C = a.C, N = a.N;
+    const int j = 16 * m + 4 * io + kap;
+    const int b = tile * 16 + n, bb = min(b, N - 1);
+    const float bh0 = a.bhh[j], bh1 = a.bhh[C + j], bh2 = a.bhh[2 * C + j], bh3 = a.bhh[3 * C + j];
+    const float* g = a.gi + (int64_t)bb * a.gi_b;
+    const int64_t gc = a.gi_c, gt = a.gi_t;
+    const float* sk = a.skip ? a.skip + ((int64_t)bb * C + j) * T : nullptr;
+    float* const orow = a.out + (int64_t)bb * a.out_b + (int64_t)j * a.out_c;
+    float* const cs_slot = a.cstate + (((int64_t)tile * NG + m) * 4 + kap) * 64 + lane;
+    float cst = a.t0 > 0 ? *cs_slot : 0.0f;
+    float g0, g1, g2, g3, skv = 0.0f;
+    {
+        const int64_t ts = a.t0;
+        g0 = g[(int64_t)j * gc + ts * gt]; g1 = g[(int64_t)(C + j) * gc + ts * gt]; g2 = g[(int64_t)(2 * C + j) * gc + ts * gt]; g3 = g[(int64_t)(3 * C + j) * gc + ts * gt];
+        if (sk) skv = sk[ts];
+    }
+    __builtin_amdgcn_s_setprio(3);
+    for (int64_t t = a.t0; t < a.t1; ++t) {
+        if (!lds_wait_ge(c, sync + S1_P + kap * 2, (unsigned)(t + 1)) || !lds_wait_ge(c, sync + S1_P + kap * 2 + 1, (unsigned)(t + 1))) return;
+        const f32x4v* P = reinterpret_cast<const f32x4v*>(part + (((int)(t & 1) * 4 + kap) * 2) * 256) + lane;
+        const f32x4v s01 = P[0], s23 = P[64];
+        const float pi = g0 + ((s01[0] + s23[0]) + bh0), pf = g1 + ((s01[1] + s23[1]) + bh1);
+        const float pg = g2 + ((s01[2] + s23[2]) + bh2), po = g3 + ((s01[3] + s23[3]) + bh3);
+        const float ig = nc_sigmoidf(pi), fg = nc_sigmoidf(pf), gg = nc_tanhf(pg), og = nc_sigmoidf(po);
+        cst = (fg * cst) + (ig * gg);
+        const float h = og * nc_tanhf(cst);
+        float* tr = htr + kap * 64;
+        tr[n * 4 + io] = h;
+        const float yo = sk ? h + skv : h;
+        const int64_t tn = t + 1 < T ? t + 1 : t;
+        g0 = g[(int64_t)j * gc + tn * gt]; g1 = g[(int64_t)(C + j) * gc + tn * gt]; g2 = g[(int64_t)(2 * C + j) * gc + tn * gt]; g3 = g[(int64_t)(3 * C + j) * gc + tn * gt];
+        if (sk) skv = sk[tn];
+        asm volatile("" ::: "memory");
+        if (t + 1 < T) {
+            if (lane < 16) {
+                const f32x4v h4 = *reinterpret_cast<const f32x4v*>(tr + lane * 4);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, h4), c.rs, region_off(c, 0, t) + ((m * 64 + kap * 16 + lane) * 16), 0, 16 /* sc1 */);
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_store((l2_gu32*)(flags + 4 * m + kap), (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (b < N) orow[t * a.out_t] = a.elu_out ? nc_eluf(yo) : yo;
+    }
+    if (a.t1 < T) *cs_slot = cst;                                            // the next chunk launch of this layer resumes from here
+}
+
 }  // namespace
 
 bool lstm2_supported(int C) { return C == 64 || C == 128 || C == 256 || C == 512; }
@@ -362,6 +505,28 @@ void lstm2_pack_image(const float* W, int C, float* image) {
                     image[(((size_t)u * NG + g) * 64 + l) * 4 + e] = W[(size_t)(gate * C + j) * C + 4 * (4 * g + e) + k4];
             }
     }
+}
+
+size_t lstm1_lds_bytes(int C) { return ((size_t)4 * (C / 16) * 256 + L1_PART + L1_HTR + 16) * sizeof(float); }
+
+void lstm1_launch(const LstmSplitArgs& h, int tiles, hipStream_t stream) {
+    if (!lstm2_supported(h.C)) fail(NC_ESTATE, "lstm1_launch: unsupported width");
+    Lstm1Args a{};
+    a.gi = h.gi; a.w = h.w; a.bhh = h.bhh; a.skip = h.skip; a.out = h.out; a.elu_out = h.elu_out; a.S = h.S; a.flags = h.flags; a.tmo = h.tmo;
+    a.cstate = h.cstate; a.gi_b = h.gi_b; a.gi_c = h.gi_c; a.gi_t = h.gi_t; a.out_b = h.out_b; a.out_c = h.out_c; a.out_t = h.out_t;
+    a.N = h.N; a.C = h.C; a.T = h.T; a.t0 = h.t0; a.t1 = h.t1; a.tile0 = h.tile0; a.tiles_total = h.tiles_total;
+    const size_t lds = lstm1_lds_bytes(h.C);
+    auto go = [&](auto kern) {
+        ensure_dynamic_lds((const void*)kern, lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(h.C / 16), (unsigned)tiles), dim3(768), lds, stream, a);
+    };
+    switch (h.C) {
+        case 512: go(lstm1_kernel<32>); break;
+        case 256: go(lstm1_kernel<16>); break;
+        case 128: go(lstm1_kernel<8>); break;
+        default: go(lstm1_kernel<4>); break;
+    }
+    NC_HIP(hipGetLastError());
 }
 
 void lstm2_launch(const Lstm2Args& a, hipStream_t stream) {

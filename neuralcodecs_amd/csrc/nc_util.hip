@@ -60,6 +60,7 @@ const EnvRow kEnv[] = {
     {"NC_NO_IN2", 'b', "summed copies instead of the two-input staging mode"},
     {"NC_NO_CONV3S", 'b', "windowed k = 3 instead of the streaming kernel"},
     {"NC_SYNC_ACQUIRE", 'b', "agent-scope acquire fence behind the persistent LSTM's flag poll and in front of the in-launch GroupNorm finish"},
+    {"NC_LSTM_SPLIT", 'b', "per-layer persistent LSTM with load-only / store-only wave roles and value-validated exchange regions (lstm1_kernel; measured slower)"},
     {"NC_LSTM_STEPWISE", 'b', "one LSTM launch per step"},
     {"NC_LSTM_CHUNKS", 'i', "layer-pipeline chunks of the per-layer persistent LSTM (4; 1 = layers in sequence)"},
     {"NC_LSTM_EVEN_CHUNKS", 'b', "equal LSTM chunks"},

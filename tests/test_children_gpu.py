@@ -80,7 +80,8 @@ FALLBACK_ROWS = [
     {"NC_NO_FUSE": "1", "NC_ENCODEC_NO_FUSE": "1", "NC_DAC_RVQ_STAGEWISE": "1"},       # two-launch residual units, padded copies, stage-wise RVQ
     {"NC_NO_FLAT_GN": "1", "NC_LSTM_NO_ELU": "1", "NC_NO_DIST_SMALL": "1", "NC_LSTM_UB": "2", "NC_NO_SUBPIXEL_ANY": "1"},   # one-clip GroupNorm tiles, ELU in the consumer, segmented staging, 8-wave LSTM
     {"NC_LSTM_FUSED": "1", "NC_SNAC_NO_FUSE": "1", "NC_ATTN_NO_MFMA": "1", "NC_LN_TILE": "0"},   # fused two-layer LSTM; SNAC units in two launches, vector attention, per-column LayerNorm
-    {"NC_SYNC_ACQUIRE": "1"},                                                          # acquire fences in the LSTM exchange and the in-launch GroupNorm finish
+    {"NC_SYNC_ACQUIRE": "1"},
+    {"NC_LSTM_SPLIT": "1"},                                                            # role-split per-layer persistent LSTM (nc_lstm.hip lstm1_kernel)                                                          # acquire fences in the LSTM exchange and the in-launch GroupNorm finish
     {"NC_SNAC_FUSE_MIN_COLS": "0", "NC_LN_TILE": "16"},                                # one-launch SNAC residual units on the small fixtures too
 ]
 
