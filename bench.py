@@ -49,7 +49,10 @@ MFMA_CLASSES = ("conv_k7", "conv_k1", "conv_down", "conv_up", "conv_misc", "lstm
 ALGO = {"dac44k": (201.8e9, 1.057e9), "encodec48k": (12.28e9 * 1.01, 0.47e9 * 1.01), "snac24k": (14.8e9, 0.44e9), "snac44k": (67.9e9, 1.23e9)}
 
 
-def class_table(prof, steps):
+def class_table(prof, steps, traffic=None):
+    """Per kernel class: HIP-event time, launches, algorithmic TFLOP/s and GB/s.  With `traffic` (profiles/traffic.json of this
+    workload: PMC FETCH_SIZE x2 + WRITE_SIZE per launch, a committed constant of the build) also the rate on the HBM side of the L2,
+    `pmc_wire_GBps` = counted bytes per launch x launches / measured time, and its fraction of the 8 TB/s peak."""
     out = {}
     for n, v in prof.items():
         if v["launches"] == 0:
@@ -58,6 +61,11 @@ def class_table(prof, steps):
         out[n] = {"ms_per_step": round(ms / steps, 4), "launches_per_step": round(v["launches"] / steps, 1),
                   "tflops": round(v["flops"] / (ms * 1e-3) / 1e12, 3) if ms > 0 else 0.0,
                   "algo_GBps": round(v["bytes"] / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0}
+        t = (traffic or {}).get(n)
+        if t and ms > 0 and "hbm_bytes_per_launch" in t:
+            wire = t["hbm_bytes_per_launch"] * v["launches"] / (ms * 1e-3) / 1e9
+            out[n]["pmc_wire_GBps"] = round(wire, 1)
+            out[n]["pmc_wire_frac_of_hbm_peak"] = round(wire / HBM_PEAK_GBS, 4)
     return out
 
 
@@ -113,7 +121,7 @@ def extra_configs(dev, steps, warmup, check):
         timed(fn, steps, 0, torch.cuda.synchronize)               # the class table: HIP events around every launch
         prof = m.profile_read()
         m.profile_enable(False)
-        classes = class_table(prof, steps)
+        classes = class_table(prof, steps, load_traffic(algo_key))
         fl, by = ALGO[algo_key]
         e = {"workload": name, "B": B, "clip_seconds": secs, "ms_per_step": round(dt * 1e3, 3), "x_realtime": round(B * secs / dt, 1),
              "whole_step_tflops": round(fl * B * secs / dt / 1e12, 3), "whole_step_algo_GBps": round(by * B * secs / dt / 1e9, 1),
@@ -356,7 +364,7 @@ def main():
     med_ms = sms[len(sms) // 2] if len(sms) % 2 else 0.5 * (sms[len(sms) // 2 - 1] + sms[len(sms) // 2])   # this rank's per-step GPU times
 
     if rank == 0:
-        classes = class_table(prof, args.steps)
+        classes = class_table(prof, args.steps, load_traffic("snac44k" if snac_mode else "dac44k") if (B == (8 if snac_mode else 32)) else None)
         total_kernel_ms = sum(v["ms"] for v in prof.values())
         total_flops = sum(v["flops"] for v in prof.values())
         if snac_mode:
