@@ -4,7 +4,12 @@
 //   of the recurrent contraction; sigma, tanh = nc_math.h; c = (f*c) + (i*g); h = o*tanh(c).  v_mfma_f32_16x16x4_f32 is bitwise a
 //   k-ordered fmaf chain, so every chain below is that chain.
 //
-// Why this shape (round 4; the per-layer kernel it replaces, lstm_seq_kernel in nc_encodec.hip, ran 5.7-6.2 us per step):
+// STATUS: both kernels of this file are bit-exact against the oracle and MEASURED SLOWER than lstm_seq_kernel (nc_encodec.hip), which stays
+// the default: NC_LSTM_FUSED=1 selects lstm2_kernel (C3 9.5-10.0 against 9.05-9.15 ms), NC_LSTM_SPLIT=1 lstm1_kernel (10.1-10.2 ms).  The
+// in-kernel trace (NC_LSTM2_TRACE, tools/probe/lstm2_trace.py) and the reasons are in DESIGN.md 8, round 4.  Kept as working,
+// instrumented starting points and as the record of what the protocol costs.
+//
+// Why this shape (round 4; the per-layer kernel it would replace, lstm_seq_kernel in nc_encodec.hip, runs 5.7-6.2 us per step):
 //   * the step is bound by the exchange of h between the workgroups that share W (4 MB per matrix: no CU can hold it), and the old
 //     protocol serialised four memory round trips per step: payload store -> DRAIN (wait for the write-through acknowledgement) -> flag
 //     -> poll -> payload read.  Here nothing drains: every exchange word is validated by VALUE.  The exchange regions are never reused
@@ -46,7 +51,7 @@ constexpr int L2_IH = 2 * 2 * 256;         // [parity][mid | final][64 x 4]
 constexpr int L2_HTR = 2 * 64;             // [layer][16 clips x 4 units]: transposes a gate wave's h into 16-byte rows
 constexpr int L2_SYNC = 64;                // sync words (unsigned)
 constexpr int L2_GROUP = L2_PART + L2_IH + L2_HTR + L2_SYNC;
-enum { SY_P0A = 0, SY_P0B, SY_P1A, SY_P1B, SY_IHMID, SY_IHFIN, SY_ACKMID, SY_ACKFIN, SY_DEAD, SY_READY0, SY_READY1, SY_G0DONE };
+enum { SY_P0A = 0, SY_P0B, SY_P1A, SY_P1B, SY_IHMID, SY_IHFIN, SY_ACKMID, SY_ACKFIN, SY_DEAD, SY_READY0, SY_READY1 };
 constexpr unsigned L2_SPINS = 1u << 22;
 
 struct Ctx {

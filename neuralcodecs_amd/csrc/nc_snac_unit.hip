@@ -6,13 +6,15 @@
 // Shape: a persistent workgroup of 4 wavefronts keeps W1 (packed [ci][C], the image of the streaming pointwise kernel) in LDS and walks
 // 256-column tiles.  Per tile the input channels go through LDS in blocks of 16: the block's window (256 + 6 d columns) is loaded with
 // 16-byte loads one block ahead, Snake-activated two values per packed instruction and written to LDS; every lane then builds its OWN
-// B fragments of the 8 matrix-core steps of the block from that window -- the 7-tap fma chain, + b7, Snake(a2): the vector ALU work
-// of a lane (about 280 issue slots per block) sits beside 16 x TM x 2 v_mfma_f32_32x32x2_f32 of the same wave (3072 pipe cycles at
-// C = 96), the other co-resident workgroup fills the gaps -- and the epilogue adds b1 and the skip operand (read before any store)
-// and stores.
-// Arithmetic = the two launches it replaces, operation for operation (bit-exact: tests/test_ops_gpu.py fused-unit test, the SNAC
-// suites): Snake and the depthwise chain as dwconv_vec_kernel (k ascending from +0, + bias, Snake), the pointwise chain over ci
-// ascending from +0 on the matrix cores, + bias, + skip, Snake.
+// B fragments of the 8 matrix-core steps of the block from that window -- 7 packed fmas (the lane's two columns per instruction), + b7,
+// packed Snake(a2) -- one step ahead of the step whose 2 TM v_mfma_f32_32x32x2_f32 are being issued; the other co-resident workgroup
+// fills the gaps.  The epilogue goes row block by row block (32 skip reads, fold, Snake, 32 stores) with uniform base + 32-bit lane
+// offsets.  Measured (NC_SNAC_UNIT_TRACE, C = 96): a block 4.5-5 us (1.3 us of matrix-core time: building operands on the vector ALU
+// does not hide under a saturated matrix stream of the same SIMD), staging 1.0 us, epilogue 10 us of a 45 us tile.
+// Arithmetic = the two launches it replaces, operation for operation (bit-exact against the oracle: the SNAC suites run it at the C5
+// size by default and on the reduced-width fixtures under NC_SNAC_FUSE_MIN_COLS=0, tests/test_children_gpu.py): Snake and the depthwise
+// chain as dwconv_vec_kernel (k ascending from +0, + bias, Snake), the pointwise chain over ci ascending from +0 on the matrix cores,
+// + bias, + skip, Snake.
 #include "nc_conv.h"
 #include "nc_elem.h"
 #include "nc_frag.h"

@@ -1,8 +1,22 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: the parity suites under each fallback switch (the non-default code paths stay correct).  A three-row subset of
-# this matrix runs inside `pytest -m gpu` (tests/test_children_gpu.py::test_parity_under_fallback_switches).
+# Runs ON THE GPU BOX: the parity suites under each fallback switch (the non-default code paths stay correct).  A subset of this matrix
+# runs inside `pytest -m gpu` (tests/test_children_gpu.py::test_parity_under_fallback_switches).
+# The hand-picked rows below combine switches that do not mask each other; `envmatrix.sh --each` instead ENUMERATES the engine's one
+# switch table (nc_debug_switches(), csrc/nc_util.hip) and runs the suites once per boolean switch, so a new switch is covered the
+# day it is added to the table.
 cd $GRAFT_REPO_ROOT
 run() { echo "== $*"; env "$@" timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_dac_gpu.py tests/test_encodec_gpu.py tests/test_snac_gpu.py -m gpu -x -q 2>&1 | grep -E "passed|failed|rror" | head -3; }
+if [ "$1" = "--each" ]; then
+  for sw in $(python - <<'PY'
+from neuralcodecs_amd import _lib
+for line in _lib.lib().nc_debug_switches().decode().splitlines():
+    name, kind, _ = line.split("\t")
+    if kind in "bp" and name not in ("NC_LSTM_FAKE_TIMEOUT",):
+        print(name)
+PY
+); do run $sw=1; done
+  exit 0
+fi
 run NC_DEFAULT=1
 run NC_NO_FLAT=1
 run NC_CO_GROUP=1
@@ -17,3 +31,7 @@ run NC_SMALL_ROLLED=1 NC_SMALL_MAX_GRID=100000
 run NC_SMALL_TN=1 NC_SMALL_WIDE_BELOW=100000 NC_RVQ_8WAVES=1 NC_SMALL_K1_COLS=0
 run NC_LSTM_STEPWISE=1 NC_NO_TINY_TILES=1 NC_NO_SUBPIXEL=1
 run NC_NO_FUSE=1 NC_ENCODEC_NO_FUSE=1 NC_DAC_RVQ_STAGEWISE=1
+# round 4
+run NC_LSTM_FUSED=1 NC_SNAC_NO_FUSE=1 NC_ATTN_NO_MFMA=1 NC_LN_TILE=0
+run NC_LSTM_SPLIT=1 NC_SNAC_FUSE_MIN_COLS=0 NC_LN_TILE=16
+run NC_SYNC_ACQUIRE=1
