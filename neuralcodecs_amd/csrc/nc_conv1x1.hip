@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
     constexpr int A_FLOATS = CB * BM;
     constexpr int A_VEC = A_FLOATS / 4;
     constexpr int NA = (A_VEC + 255) / 256;
-    constexpr int PF = 4;                       // B prefetch distance in MFMA steps (divides KP); deeper rings measured slower
+    constexpr int PF = 4;                       // B prefetch distance in MFMA steps (divides KP); an 8-step ring measures the same
     static_assert(KP % PF == 0, "prefetch ring must divide the reduction block");
 
     __shared__ __attribute__((aligned(16))) float As[2][A_FLOATS];
@@ -145,10 +145,20 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
             }
         }
         const float* Ac = As[cur] + hi * BM + nc_a_lane_off<TM>(l31);
+        // A step = the A fragments of the NEXT step, its own matrix-core instructions, THEN the refill of the ring slot they just
+        // consumed (in place) -- fenced with sched_barrier so the order survives the scheduler.  Written as "copy the slot, refill it,
+        // multiply" the refill lands in a fresh register that must be copied back into the loop-carried slot before the back edge, and
+        // the copy waits for the read it was meant to overlap (`s_waitcnt vmcnt(1)` two steps after the issue); left to itself the
+        // scheduler also sinks the refills of a ring turn into one batch behind its last step and the wave then waits for the
+        // batch's first read a few instructions after issuing it (found in the ISA, round 4; sched_group_barrier pins only some
+        // instances).
+        float a[TM];
+        nc_load_a_frag<TM>(Ac, l31, a);
 #pragma unroll
         for (int kp = 0; kp < KP; ++kp) {
-            float a[TM];
-            nc_load_a_frag<TM>(Ac + 2 * kp * BM, l31, a);
+            float an[TM];
+            if (kp + 1 < KP) nc_load_a_frag<TM>(Ac + 2 * (kp + 1) * BM, l31, an);   // the next step's A fragments, ahead of this step's multiplies
+            __builtin_amdgcn_sched_barrier(0);
             f32x2 bv = bq[kp % PF];
             if constexpr (INM) {
                 if (in_mode & 1) {
@@ -161,12 +171,17 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
                     bv[1] = nc_eluf(bv[1]);
                 }
             }
-            const int g = cb * KP + kp + PF;
-            bq[kp % PF] = load_b(g);   // unconditional (clamped): the step is one basic block
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[0], acc[i][0], 0, 0, 0);
                 acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[1], acc[i][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bq[kp % PF] = load_b(cb * KP + kp + PF);   // unconditional (clamped): the step is one basic block
+            __builtin_amdgcn_sched_barrier(0);
+            if (kp + 1 < KP) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = an[i];
             }
         }
         if (more) {
@@ -336,6 +351,12 @@ typedef void (*conv_kernel_fn)(const ConvArgs);
 // tiles: the loop has no barrier at all (waves run free), the B ring is 16 steps deep (8 KB per wave in flight) and runs ACROSS
 // column tiles -- the first steps of tile k+1 are read before the stores of tile k, so no read waits behind a store acknowledgement.
 // Arithmetic unchanged: per output one chain over ci ascending from +0, + bias, + residual (or residual + noise * .), Snake.
+// Schedule note (round 4): the compiler issues the 16 refills of a group as one batch behind its last step and opens the next group
+// with `s_waitcnt vmcnt(0)`.  The "proper" ring -- refill in place behind each step, `vmcnt(15)` per step, units and groups in ONE loop
+// so that the wait-count pass keeps the in-order counter across the epilogue's stores -- was built and measures 2-4 % SLOWER on the
+// C = 192 layers (777 -> 814 us; a 32-step ring the same): with two waves per SIMD the batched form lets one wave run its 16 steps
+// uninterrupted while the other waits for its batch, and that coarse alternation feeds the matrix pipe better than two streams
+// interleaved step by step.  conv1x1_kernel above (3-5 waves per SIMD, tile per workgroup) gains 3-5 % from the in-place ring.
 template <int TM, int MODE>
 __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvArgs p) {
     constexpr int TN = 2, BM = 32 * TM, BNW = 32 * TN, BN = 4 * BNW;
