@@ -378,15 +378,37 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     constexpr int FD = 1;            // fragment reads run FD matrix-core steps ahead (FD + 1 register sets)
     float fa[FD + 1][TM], fb[FD + 1][TN];
     // Ac = current weight buffer + hi*BM (the kk row of this lane half at step 0); xsc = scalar float index of the current window
-    auto load_frag = [&](const float* Ac, int xsc, auto kp_tag) __attribute__((always_inline)) {
+    // Constant row pitch (XR, round 4): the k = 7 instances with 256-column tiles always stage 5 chunks of 64 slots per channel (a
+    // window of 256 + 6 d (+ segment halos) slots, capped at 5 chunks by the staging registers), so xrow == 320 whatever the dilation.
+    // With the pitch a compile-time constant the B-fragment address of step kp is a per-tap lane pointer (tap offset, segment halo and
+    // buffer parity folded in: K * TN pointers, flipped between the two window buffers once per block) plus an IMMEDIATE offset:
+    // no vector ALU instruction per step, where the generic form spends three (found in the ISA: `v_add_lshl_u32`, a copy and the
+    // halo add in front of every pair of `ds_read_b32`; vector instructions are issued in the matrix pipe's time on this SIMD).
+    // The launcher's xrow is checked at run time; any other pitch (a strided k = 7 layer) takes the generic form below.
+    constexpr bool XRCAND = K == 7 && TN == 2 && NW == 4 && SUB == 0 && !IN2 && !SPEC && !DIST;
+    constexpr int XROWC = 320;
+    const float* xq[XRCAND ? TN : 1][XRCAND ? K : 1];
+    if constexpr (XRCAND) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int k = 0; k < K; ++k) xq[j][k] = smem + 2 * A_FLOATS + xt[k] + tap[k] + ej[j];
+    }
+    auto load_frag_x = [&](const float* Ac, int xsc, auto kp_tag, auto xr_tag) __attribute__((always_inline)) {
         constexpr int kp = decltype(kp_tag)::value;
         constexpr int c0 = (2 * kp) / K, k0 = (2 * kp) % K;
-        // (readfirstlane pins the wave-uniform part in a scalar register: vector + scalar is then one add per step)
-        const int o = xt[k0] + __builtin_amdgcn_readfirstlane(xsc + c0 * xrow + tap[k0]);
         nc_load_a_frag<TM>(Ac + 2 * kp * BM, l31, fa[kp % (FD + 1)]);   // Ac carries the lane part: immediate offsets only
+        if constexpr (decltype(xr_tag)::value) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[kp % (FD + 1)][j] = smem[(j == 0 ? o : o + ej[j]) + j * 32];
+            for (int j = 0; j < TN; ++j) fb[kp % (FD + 1)][j] = xq[j][k0][c0 * XROWC + j * 32];
+        } else {
+            // (readfirstlane pins the wave-uniform part in a scalar register: vector + scalar is then one add per step)
+            const int o = xt[k0] + __builtin_amdgcn_readfirstlane(xsc + c0 * xrow + tap[k0]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[kp % (FD + 1)][j] = smem[(j == 0 ? o : o + ej[j]) + j * 32];
+        }
     };
+    auto load_frag = [&](const float* Ac, int xsc, auto kp_tag) __attribute__((always_inline)) { load_frag_x(Ac, xsc, kp_tag, std::false_type{}); };
 
     if constexpr (SPEC) {
         static_assert(!SPEC || !FUSE, "the fused tail has workgroup barriers: not combined with producer waves");
@@ -486,7 +508,9 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         };
         if (alpha_in != nullptr) run_loop(std::true_type{});
         else run_loop(std::false_type{});
-    } else
+    } else {
+    auto main_loop = [&](auto xr_tag) __attribute__((always_inline)) {
+    constexpr bool XR = decltype(xr_tag)::value;
     for (int cb = 0; cb < n_cb; ++cb) {
         const int cur = cb & 1;
         const float* Ac = As0 + cur * A_FLOATS + hi * BM + nc_a_lane_off<TM>(l31);
@@ -494,6 +518,15 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         float* const An = As0 + (cur ^ 1) * A_FLOATS;
         float* const Xn = Xs0 + (cur ^ 1) * xbuf;
         const bool more = cb + 1 < n_cb;
+        if constexpr (XR) {
+            if (cb > 0) {   // the tap pointers follow the window buffer of this block
+                const int dx = cur ? xbuf : -xbuf;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int k = 0; k < K; ++k) xq[j][k] += dx;
+            }
+        }
         if constexpr (SPEC) {
             nc_static_for<FD>([&](auto d) __attribute__((always_inline)) {
                 if constexpr (decltype(d)::value < KP) load_frag(Ac, Xc, d);
@@ -520,11 +553,11 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
             constexpr int kp_lo = seg * KP / NSEG, kp_hi = (seg + 1) * KP / NSEG;
             if constexpr (seg == 0)
                 nc_static_for<FD>([&](auto d) __attribute__((always_inline)) {
-                    if constexpr (decltype(d)::value < KP) load_frag(Ac, Xc, d);
+                    if constexpr (decltype(d)::value < KP) load_frag_x(Ac, Xc, d, xr_tag);
                 });
             nc_static_for<kp_hi - kp_lo>([&](auto d) __attribute__((always_inline)) {
                 constexpr int kp = kp_lo + decltype(d)::value;
-                if constexpr (kp + FD < KP) load_frag(Ac, Xc, std::integral_constant<int, kp + FD>{});
+                if constexpr (kp + FD < KP) load_frag_x(Ac, Xc, std::integral_constant<int, kp + FD>{}, xr_tag);
                 __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of step kp+1 ahead of the MFMAs of step kp
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -534,6 +567,14 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
             });
         });
         __syncthreads();
+    }
+    };
+    if constexpr (XRCAND) {
+        if (xrow == XROWC) main_loop(std::true_type{});
+        else main_loop(std::false_type{});
+    } else {
+        main_loop(std::false_type{});
+    }
     }
     // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*hi][col = l31]
     // Element (row block ib, register r, column j) of this lane lives at tile_base + lane_off[j] + R(ib,r)*cstride with
