@@ -385,8 +385,10 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     // no vector ALU instruction per step, where the generic form spends three (found in the ISA: `v_add_lshl_u32`, a copy and the
     // halo add in front of every pair of `ds_read_b32`; vector instructions are issued in the matrix pipe's time on this SIMD).
     // The launcher's xrow is checked at run time; any other pitch (a strided k = 7 layer) takes the generic form below.
-    constexpr bool XRCAND = K == 7 && TN == 2 && NW == 4 && SUB == 0 && !IN2 && !SPEC && !DIST;
-    constexpr int XROWC = 320;
+    // The two-tap instances (sub-pixel up-convolutions: a window of 256 + 1 (+ halos) slots) have the same pitch for the same reason.
+    // 128-column tiles (TN = 1: the wide fused units): 128 + 6 d <= 182 slots, 3 chunks, pitch 192.
+    constexpr bool XRCAND = ((K == 7 && SUB == 0) || K == 2) && (TN == 2 || TN == 1) && NW == 4 && !IN2 && !SPEC && !DIST;
+    constexpr int XROWC = TN == 2 ? 320 : 192;
     const float* xq[XRCAND ? TN : 1][XRCAND ? K : 1];
     if constexpr (XRCAND) {
 #pragma unroll
