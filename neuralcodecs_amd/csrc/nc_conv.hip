@@ -430,6 +430,7 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
     if (io.alpha_in || (io.epi & ~EPI_NOISE) || T < 2 || (T & 1) || io.x_len != T) return false;
     if (io.alpha_out && (io.epi & EPI_NOISE)) return false;
     if ((io.x_cstride & 1) || (io.x_bstride & 1) || (io.y_cstride & 1) || (io.y_bstride & 1)) return false;
+    if ((int64_t)L.Cin * io.x_cstride * 4 >= ((int64_t)1 << 32)) return false;   // (the B reads are buffer loads over one clip's rows)
     auto al8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; };
     if (!al8(io.x) || !al8(io.y) || (io.res && !al8(io.res)) || (io.noise && !al8(io.noise))) return false;
     if ((io.epi & EPI_NOISE) && (!io.noise || !io.res)) return false;

@@ -101,7 +101,11 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
     const int col = t_tile * BN + wave * BNW + TN * l31;          // first of this lane's TN columns
     const int colc = min(col, T - TN);                             // clamped (T % TN == 0, T >= TN): loads stay inside the row
     const float* const xb = p.x + (int64_t)b * p.x_bstride;       // uniform; the lane part is a 32-bit offset
-    const unsigned x_lane_off = (unsigned)hi * x_cstride + (unsigned)colc;
+    // B reads are buffer loads: resource = this clip's rows (uniform), the lane part a constant 32-bit byte offset, the channel pair of
+    // step g a SCALAR byte offset -- no vector address arithmetic per read (a vector instruction in the step is issued in the matrix
+    // pipe's time).  The launcher admits the layer only when a clip's rows span < 4 GB.
+    const unsigned x_lane_off = 4u * ((unsigned)hi * x_cstride + (unsigned)colc);   // bytes
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)(4u * (unsigned)Cin * x_cstride), 0x00020000);
     const f32x4* const wbase = reinterpret_cast<const f32x4*>(p.w + (int64_t)co_tile * n_cb * A_FLOATS);
 
     f32x16 acc[TM][TN];
@@ -114,12 +118,12 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
 
     // B ring: step g (global MFMA step index) uses channel ci = 2g + hi
     f32x2 bq[PF];
-    // step g reads channel rows 2g (lanes 0-31) and 2g+1 (lanes 32-63): a uniform row pointer (scalar arithmetic, clamped to the
-    // last channel pair -- rows past Cin meet zero weights) plus the lane offset, i.e. no vector address arithmetic per step
+    // step g reads channel rows 2g (lanes 0-31) and 2g+1 (lanes 32-63): the row pair is a scalar offset (clamped to the last channel
+    // pair -- rows past Cin meet zero weights)
     const int last_pair = Cin / 2 - 1;                            // (the launcher admits even Cin only)
+    const unsigned pair_bytes = 8u * x_cstride;
     auto load_b = [&](int g) __attribute__((always_inline)) {
-        const float* row = xb + (size_t)(2 * min(g, last_pair)) * x_cstride;
-        return *reinterpret_cast<const f32x2*>(row + x_lane_off);
+        return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, x_lane_off, (unsigned)min(g, last_pair) * pair_bytes, 0));
     };
 #pragma unroll
     for (int u = 0; u < PF; ++u) bq[u] = load_b(u);
