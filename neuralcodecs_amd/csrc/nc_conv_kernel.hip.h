@@ -387,8 +387,23 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     // The launcher's xrow is checked at run time; any other pitch (a strided k = 7 layer) takes the generic form below.
     // The two-tap instances (sub-pixel up-convolutions: a window of 256 + 1 (+ halos) slots) have the same pitch for the same reason.
     // 128-column tiles (TN = 1: the wide fused units): 128 + 6 d <= 182 slots, 3 chunks, pitch 192.
-    constexpr bool XRCAND = ((K == 7 && SUB == 0) || K == 2) && (TN == 2 || TN == 1) && NW == 4 && !IN2 && !SPEC && !DIST;
-    constexpr int XROWC = TN == 2 ? 320 : 192;
+    // Pointwise instances (K = 1): no halo, the pitch is the tile width.
+    constexpr bool XRCAND = ((K == 7 && SUB == 0) || K == 2 || (K == 1 && SUB == 0)) && (TN == 2 || TN == 1) && NW == 4 && !IN2 && !SPEC && !DIST;
+    constexpr int XROWC = K == 1 ? BN : TN == 2 ? 320 : 192;
+    // Strided down-convolutions (K = 2 s taps, stride s, no dilation: K = 4 / 6 / 8 / 10 / 16 at 256-column tiles): window, phase-row
+    // pitch xwp and channel pitch xrow follow from (K, tile width) alone, and so do the tap offsets (k % s) * xwp + k / s.  The lane
+    // half's tap difference takes two values (xwp, or 1 - (s - 1) xwp where tap k0 + 1 wraps to the next sample: odd s only), so two
+    // lane pointers per column block carry everything that depends on the lane and the rest is an immediate.
+    constexpr int XS_S = K / 2, XS_XW = 257 * XS_S, XS_NCH = (XS_XW + 63) / 64, XS_XWP = (XS_NCH * 64 + XS_S - 1) / XS_S, XS_XROW = XS_S * XS_XWP;
+    constexpr bool XSCAND = (K == 4 || K == 6 || K == 8 || K == 10 || K == 16) && SUB == 0 && TN == 2 && NW == 4 && !IN2 && !SPEC && !DIST && !FUSE;
+    const float* xqs[XSCAND ? TN : 1][2];
+    if constexpr (XSCAND) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            xqs[j][0] = smem + 2 * A_FLOATS + x_lane + ej[j] + (hi ? XS_XWP : 0);
+            xqs[j][1] = smem + 2 * A_FLOATS + x_lane + ej[j] + (hi ? 1 - (XS_S - 1) * XS_XWP : 0);
+        }
+    }
     const float* xq[XRCAND ? TN : 1][XRCAND ? K : 1];
     if constexpr (XRCAND) {
 #pragma unroll
@@ -400,9 +415,14 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         constexpr int kp = decltype(kp_tag)::value;
         constexpr int c0 = (2 * kp) / K, k0 = (2 * kp) % K;
         nc_load_a_frag<TM>(Ac + 2 * kp * BM, l31, fa[kp % (FD + 1)]);   // Ac carries the lane part: immediate offsets only
-        if constexpr (decltype(xr_tag)::value) {
+        if constexpr (decltype(xr_tag)::value == 1) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[kp % (FD + 1)][j] = xq[j][k0][c0 * XROWC + j * 32];
+        } else if constexpr (decltype(xr_tag)::value == 2) {
+            constexpr int cls = (k0 % XS_S == XS_S - 1) ? 1 : 0;                       // (k0 is even: the wrap class exists for odd s only)
+            constexpr int tapc = (k0 % XS_S) * XS_XWP + k0 / XS_S;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[kp % (FD + 1)][j] = xqs[j][cls][c0 * XS_XROW + tapc + j * 32];
         } else {
             // (readfirstlane pins the wave-uniform part in a scalar register: vector + scalar is then one add per step)
             const int o = xt[k0] + __builtin_amdgcn_readfirstlane(xsc + c0 * xrow + tap[k0]);
@@ -410,7 +430,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
             for (int j = 0; j < TN; ++j) fb[kp % (FD + 1)][j] = smem[(j == 0 ? o : o + ej[j]) + j * 32];
         }
     };
-    auto load_frag = [&](const float* Ac, int xsc, auto kp_tag) __attribute__((always_inline)) { load_frag_x(Ac, xsc, kp_tag, std::false_type{}); };
+    auto load_frag = [&](const float* Ac, int xsc, auto kp_tag) __attribute__((always_inline)) { load_frag_x(Ac, xsc, kp_tag, std::integral_constant<int, 0>{}); };
 
     if constexpr (SPEC) {
         static_assert(!SPEC || !FUSE, "the fused tail has workgroup barriers: not combined with producer waves");
@@ -512,7 +532,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         else run_loop(std::false_type{});
     } else {
     auto main_loop = [&](auto xr_tag) __attribute__((always_inline)) {
-    constexpr bool XR = decltype(xr_tag)::value;
+    constexpr int XR = decltype(xr_tag)::value;   // 0 generic, 1 constant pitch (stride 1), 2 constant pitch (stride K / 2)
     for (int cb = 0; cb < n_cb; ++cb) {
         const int cur = cb & 1;
         const float* Ac = As0 + cur * A_FLOATS + hi * BM + nc_a_lane_off<TM>(l31);
@@ -520,13 +540,20 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         float* const An = As0 + (cur ^ 1) * A_FLOATS;
         float* const Xn = Xs0 + (cur ^ 1) * xbuf;
         const bool more = cb + 1 < n_cb;
-        if constexpr (XR) {
+        if constexpr (XR == 1) {
             if (cb > 0) {   // the tap pointers follow the window buffer of this block
                 const int dx = cur ? xbuf : -xbuf;
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int k = 0; k < K; ++k) xq[j][k] += dx;
+            }
+        }
+        if constexpr (XR == 2) {
+            if (cb > 0) {
+                const int dx = cur ? xbuf : -xbuf;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { xqs[j][0] += dx; xqs[j][1] += dx; }
             }
         }
         if constexpr (SPEC) {
@@ -572,10 +599,13 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     }
     };
     if constexpr (XRCAND) {
-        if (xrow == XROWC) main_loop(std::true_type{});
-        else main_loop(std::false_type{});
+        if (xrow == XROWC && s == 1) main_loop(std::integral_constant<int, 1>{});
+        else main_loop(std::integral_constant<int, 0>{});
+    } else if constexpr (XSCAND) {
+        if (s == XS_S && p.dil == 1 && xrow == XS_XROW && xwp == XS_XWP) main_loop(std::integral_constant<int, 2>{});
+        else main_loop(std::integral_constant<int, 0>{});
     } else {
-        main_loop(std::false_type{});
+        main_loop(std::integral_constant<int, 0>{});
     }
     }
     // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*hi][col = l31]

@@ -33,7 +33,7 @@ const EnvRow kEnv[] = {
     {"NC_NO_SUBPIXEL", 'b', "per-phase launches for power-of-two strided transposed convolutions"},
     {"NC_NO_SUBPIXEL_ANY", 'b', "per-phase launches for the other strides (3, 5)"},
     {"NC_NO_CONV1X1", 'b', "pointwise layers through the windowed template"},
-    {"NC_NO_PW_STREAM", 'b', "no streaming pointwise variant"},
+    {"NC_PW_STREAM", 'b', "streaming pointwise variant for the narrow long rows (not the default since round 4)"},
     {"NC_NO_SKINNY", 'b', "no skinny projection kernel (Cout <= 16)"},
     {"NC_NO_THIN", 'b', "PCM heads through the matrix-core template"},
     {"NC_THIN_NO_VEC", 'p', "scalar window loads in the thin-output kernel"},

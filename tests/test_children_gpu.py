@@ -98,6 +98,17 @@ def test_parity_under_fallback_switches(row):
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
 
 
+def test_streaming_pointwise_variant_under_its_switch():
+    """conv1x1_stream_kernel is no longer the default for the narrow long rows (round 4: the tile-per-workgroup kernel overtook it);
+    NC_PW_STREAM=1 selects it, and it stays held to the oracle: its own bit-exactness cases and the SNAC suite (whose 44 kHz units it served)."""
+    e = dict(os.environ, NC_PW_STREAM="1")
+    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+           os.path.join(ROOT, "tests", "test_ops_gpu.py") + "::test_pointwise_streaming_variant_bit_exact",
+           os.path.join(ROOT, "tests", "test_snac_gpu.py")]
+    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
+
+
 # The driver's first multi-GPU run launches bench.py under torch.distributed.run with no chance to debug it; the SAME code path
 # (process group on RCCL, side-stream all-gather of the codes, barrier + max-over-ranks timing, every-slot verification, one JSON line)
 # runs with a single rank under NC_BENCH_FORCE_DIST=1 -- in a fresh child created before this process touches the GPU.

@@ -198,7 +198,8 @@ def test_conv1d_random_shapes_bit_exact(cin, cout, k, s, p, d, T, B, tr):
 
 @pytest.mark.parametrize("C,res,snake", [(64, True, False), (96, True, True), (96, False, False), (192, True, False)])
 def test_pointwise_streaming_variant_bit_exact(C, res, snake):
-    """Long narrow rows take the streaming pointwise kernel (weights resident in LDS, B ring across column tiles): >= 2048 column tiles."""
+    """Long narrow rows (>= 2048 column tiles): the tile-per-workgroup pointwise kernel by default, the streaming kernel (weights resident in
+    LDS, B ring across column tiles) under NC_PW_STREAM=1 -- tests/test_children_gpu.py runs these cases in that form too."""
     rng = np.random.default_rng(C + res + 2 * snake)
     B, T = 8, 66000 if C < 192 else 33100
     x = _rand(rng, B, C, T)

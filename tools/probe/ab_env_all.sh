@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: A/B of environment settings over the DAC headline step and the other configs (codecbench), interleaved.
-#   tools/probe/ab_env_all.sh "NC_NO_PW_STREAM=1" ""        (each argument = one setting; "" = default)
+#   tools/probe/ab_env_all.sh "NC_PW_STREAM=1" ""        (each argument = one setting; "" = default)
 cd $GRAFT_REPO_ROOT
 REPS=${REPS:-2}
 for rep in $(seq 1 $REPS); do
