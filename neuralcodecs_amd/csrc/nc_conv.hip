@@ -816,6 +816,10 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     a.xrow = sx == 1 ? a.nchunk * 64 : sx * a.xwp;
     a.n_co_tiles = (L.rows() + BM - 1) / BM;
     a.n_t_tiles = (a.n_cols + BN - 1) / BN;
+    {
+        static const bool no_xr = env_flag("NC_NO_XR");
+        a.no_xr = no_xr ? 1 : 0;
+    }
     a.Bc = B; a.flat = 0; a.flat_px = a.flat_pc = 0x1fffffff; a.flat_hc = 0;
     if (flat) {   // one column axis over all clips: B = 1 in the tile map
         a.flat = 1; a.flat_pc = (int32_t)flat_pitch; a.flat_hc = flat_hc; a.flat_px = (int32_t)(flat_pitch + flat_hc) * sx;

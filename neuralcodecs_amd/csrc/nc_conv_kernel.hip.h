@@ -394,7 +394,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     // pitch xwp and channel pitch xrow follow from (K, tile width) alone, and so do the tap offsets (k % s) * xwp + k / s.  The lane
     // half's tap difference takes two values (xwp, or 1 - (s - 1) xwp where tap k0 + 1 wraps to the next sample: odd s only), so two
     // lane pointers per column block carry everything that depends on the lane and the rest is an immediate.
-    constexpr int XS_S = K / 2, XS_XW = 257 * XS_S, XS_NCH = (XS_XW + 63) / 64, XS_XWP = (XS_NCH * 64 + XS_S - 1) / XS_S, XS_XROW = XS_S * XS_XWP;
+    constexpr int XS_S = K >= 2 ? K / 2 : 1, XS_XW = 257 * XS_S, XS_NCH = (XS_XW + 63) / 64, XS_XWP = (XS_NCH * 64 + XS_S - 1) / XS_S, XS_XROW = XS_S * XS_XWP;
     constexpr bool XSCAND = (K == 4 || K == 6 || K == 8 || K == 10 || K == 16) && SUB == 0 && TN == 2 && NW == 4 && !IN2 && !SPEC && !DIST && !FUSE;
     const float* xqs[XSCAND ? TN : 1][2];
     if constexpr (XSCAND) {
@@ -599,10 +599,10 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     }
     };
     if constexpr (XRCAND) {
-        if (xrow == XROWC && s == 1) main_loop(std::integral_constant<int, 1>{});
+        if (xrow == XROWC && s == 1 && !p.no_xr) main_loop(std::integral_constant<int, 1>{});
         else main_loop(std::integral_constant<int, 0>{});
     } else if constexpr (XSCAND) {
-        if (s == XS_S && p.dil == 1 && xrow == XS_XROW && xwp == XS_XWP) main_loop(std::integral_constant<int, 2>{});
+        if (s == XS_S && p.dil == 1 && xrow == XS_XROW && xwp == XS_XWP && !p.no_xr) main_loop(std::integral_constant<int, 2>{});
         else main_loop(std::integral_constant<int, 0>{});
     } else {
         main_loop(std::integral_constant<int, 0>{});

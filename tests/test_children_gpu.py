@@ -83,6 +83,7 @@ FALLBACK_ROWS = [
     {"NC_SYNC_ACQUIRE": "1"},
     {"NC_LSTM_SPLIT": "1"},                                                            # role-split per-layer persistent LSTM (nc_lstm.hip lstm1_kernel)                                                          # acquire fences in the LSTM exchange and the in-launch GroupNorm finish
     {"NC_SNAC_FUSE_MIN_COLS": "0", "NC_LN_TILE": "16"},                                # one-launch SNAC residual units on the small fixtures too
+    {"NC_NO_XR": "1", "NC_PW_STREAM": "1"},                                            # generic fragment addressing in the conv template, streaming pointwise kernel
 ]
 
 

@@ -35,3 +35,4 @@ run NC_NO_FUSE=1 NC_ENCODEC_NO_FUSE=1 NC_DAC_RVQ_STAGEWISE=1
 run NC_LSTM_FUSED=1 NC_SNAC_NO_FUSE=1 NC_ATTN_NO_MFMA=1 NC_LN_TILE=0
 run NC_LSTM_SPLIT=1 NC_SNAC_FUSE_MIN_COLS=0 NC_LN_TILE=16
 run NC_SYNC_ACQUIRE=1
+run NC_NO_XR=1 NC_PW_STREAM=1
