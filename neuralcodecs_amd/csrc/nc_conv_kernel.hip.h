@@ -198,13 +198,20 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
             xg[i] = (unsigned)min(sg, p.Bc - 1 - b) * (unsigned)p.x_bstride + (unsigned)min(max(q, 0), p.in_L - 1);
         }
     }
+    // Interior tiles (no padding, no zero extension, no tile overrun anywhere in the window: all but the first / last tile of a clip)
+    // skip the per-item zero select while staging: wave-uniform, decided once.  The compiler keeps the per-item predicates as 64-bit
+    // scalar masks -- 2 NX scalar registers, which the two-tap instances (NX = 20) spill and reload with a vector instruction each,
+    // inside the loop (found in the ISA, round 4).
+    const bool tile_allok = __builtin_amdgcn_ballot_w64(okm != (NX >= 32 ? ~0u : (1u << NX) - 1u)) == 0;
     auto issue_group_to = [&](int cbn, auto gtag, f32x4 (&ra)[GA], float (&rx)[GXX]) __attribute__((always_inline)) {
         constexpr int g = decltype(gtag)::value;
         const f32x4* src = wbase + (size_t)cbn * A_VEC;
         nc_static_for<GX>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value, i = g * GX + u;
             if constexpr (i < NX) {
-                const int ci = min(cbn * CB + xc[i], Cin - 1);           // wave-uniform
+                // (the item's channel is recomputed -- two scalar instructions -- instead of being held: NX pinned scalars pushed the
+                //  two-tap instances, NX = 20, into scalar-register spills whose reloads are vector instructions inside the loop)
+                const int ci = min(cbn * CB + (((swave + SW * i) * chunk_magic) >> 20), Cin - 1);           // wave-uniform
                 const float* row = xb + (size_t)((unsigned)ci * x_cstride);   // uniform base + 32-bit lane offset
                 rx[u] = row[xg[i]];
                 if constexpr (IN2) rx[GX + u] = (xb2 + (size_t)((unsigned)ci * x_cstride))[xg[i]];
@@ -220,9 +227,10 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         });
     };
     auto issue_group = [&](int cbn, auto gtag) __attribute__((always_inline)) { issue_group_to(cbn, gtag, ra, rx); };
-    auto store_group_from = [&](int cbn, float* Ad, float* Xd, auto gtag, auto snake_tag, const f32x4 (&ra)[GA],
-                                const float (&rx)[GXX]) __attribute__((always_inline)) {
+    auto store_group_from_x = [&](int cbn, float* Ad, float* Xd, auto gtag, auto snake_tag, const f32x4 (&ra)[GA],
+                                  const float (&rx)[GXX], auto allok_tag) __attribute__((always_inline)) {
         constexpr int g = decltype(gtag)::value;
+        constexpr bool ALLOK = decltype(allok_tag)::value;       // every window item of this block is a real sample: no zero select
         constexpr int IMODE = (int)decltype(snake_tag)::value;   // 0 plain, 1 (true_type) Snake, 2 Encodec input mode
         constexpr bool SNAKE = IMODE == 1;
         nc_static_for<GA>([&](auto ut) __attribute__((always_inline)) {
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                 const int c = (item * chunk_magic) >> 20;
                 const int ci = cbn * CB + c;
                 const int j = (item - c * nchunk) * 64 + lane;
-                const bool ok = (ci < Cin) & (((okm >> i) & 1u) != 0);  // slots past xw / items past n_items are never read
+                const bool ok = ALLOK || ((ci < Cin) & (((okm >> i) & 1u) != 0));  // slots past xw / items past n_items are never read
                 if constexpr (IMODE == 2) {
                     float t = rx[u];
                     if (in_mode & 1) t = ((t - in_mu) * in_rs) * al[u].x + al[u].y;   // GroupNorm(1,C) apply (NormConv1d.cs:155)
@@ -285,12 +293,23 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
             if constexpr (i < NX) Xd[off[u]] = v[u];
         });
     };
+    auto store_group_from = [&](int cbn, float* Ad, float* Xd, auto gtag, auto snake_tag, const f32x4 (&ra)[GA],
+                                const float (&rx)[GXX]) __attribute__((always_inline)) {
+        store_group_from_x(cbn, Ad, Xd, gtag, snake_tag, ra, rx, std::false_type{});
+    };
     auto store_group = [&](int cbn, float* Ad, float* Xd, auto gtag, auto snake_tag) __attribute__((always_inline)) {
         store_group_from(cbn, Ad, Xd, gtag, snake_tag, ra, rx);
     };
     auto store_group_any = [&](int cbn, float* Ad, float* Xd, auto gtag) __attribute__((always_inline)) {
         if constexpr (!FUSE && !SPEC && !DIST) {
             if (in_mode) { store_group(cbn, Ad, Xd, gtag, std::integral_constant<int, 2>{}); return; }
+        }
+        // (instances with >= 16 window items per lane only: on the k = 7 instances, NX = 10, whose masks fit the scalar file, the extra
+        //  code path cost 1.5 % -- conv_k7 42.2 -> 42.8 ms on one box -- where the two-tap instances gained 2-3 %)
+        if (NX >= 16 && tile_allok && (cbn + 1) * CB <= Cin) {   // wave-uniform
+            if (alpha_in != nullptr) store_group_from_x(cbn, Ad, Xd, gtag, std::true_type{}, ra, rx, std::true_type{});
+            else store_group_from_x(cbn, Ad, Xd, gtag, std::false_type{}, ra, rx, std::true_type{});
+            return;
         }
         if (alpha_in != nullptr)
             store_group(cbn, Ad, Xd, gtag, std::true_type{});
@@ -387,23 +406,11 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     // The launcher's xrow is checked at run time; any other pitch (a strided k = 7 layer) takes the generic form below.
     // The two-tap instances (sub-pixel up-convolutions: a window of 256 + 1 (+ halos) slots) have the same pitch for the same reason.
     // 128-column tiles (TN = 1: the wide fused units): 128 + 6 d <= 182 slots, 3 chunks, pitch 192.
-    // Pointwise instances (K = 1): no halo, the pitch is the tile width.
-    constexpr bool XRCAND = ((K == 7 && SUB == 0) || K == 2 || (K == 1 && SUB == 0)) && (TN == 2 || TN == 1) && NW == 4 && !IN2 && !SPEC && !DIST;
-    constexpr int XROWC = K == 1 ? BN : TN == 2 ? 320 : 192;
-    // Strided down-convolutions (K = 2 s taps, stride s, no dilation: K = 4 / 6 / 8 / 10 / 16 at 256-column tiles): window, phase-row
-    // pitch xwp and channel pitch xrow follow from (K, tile width) alone, and so do the tap offsets (k % s) * xwp + k / s.  The lane
-    // half's tap difference takes two values (xwp, or 1 - (s - 1) xwp where tap k0 + 1 wraps to the next sample: odd s only), so two
-    // lane pointers per column block carry everything that depends on the lane and the rest is an immediate.
-    constexpr int XS_S = K >= 2 ? K / 2 : 1, XS_XW = 257 * XS_S, XS_NCH = (XS_XW + 63) / 64, XS_XWP = (XS_NCH * 64 + XS_S - 1) / XS_S, XS_XROW = XS_S * XS_XWP;
-    constexpr bool XSCAND = (K == 4 || K == 6 || K == 8 || K == 10 || K == 16) && SUB == 0 && TN == 2 && NW == 4 && !IN2 && !SPEC && !DIST && !FUSE;
-    const float* xqs[XSCAND ? TN : 1][2];
-    if constexpr (XSCAND) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            xqs[j][0] = smem + 2 * A_FLOATS + x_lane + ej[j] + (hi ? XS_XWP : 0);
-            xqs[j][1] = smem + 2 * A_FLOATS + x_lane + ej[j] + (hi ? 1 - (XS_S - 1) * XS_XWP : 0);
-        }
-    }
+    constexpr bool XRCAND = ((K == 7 && SUB == 0) || K == 2) && (TN == 2 || TN == 1) && NW == 4 && !IN2 && !SPEC && !DIST;
+    constexpr int XROWC = TN == 2 ? 320 : 192;
+    // (The same for the strided down-convolutions -- pitch, phase-row pitch and tap offsets all follow from (K, tile width), two lane
+    //  pointers per column block -- and for the K = 1 instances was built and measured on one box: strided SLOWER, conv_down 2.82 ->
+    //  2.97 ms on DAC, 4.22 -> 4.78 on SNAC 44 kHz; K = 1 no change.  Not kept.)
     const float* xq[XRCAND ? TN : 1][XRCAND ? K : 1];
     if constexpr (XRCAND) {
 #pragma unroll
@@ -418,11 +425,6 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         if constexpr (decltype(xr_tag)::value == 1) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[kp % (FD + 1)][j] = xq[j][k0][c0 * XROWC + j * 32];
-        } else if constexpr (decltype(xr_tag)::value == 2) {
-            constexpr int cls = (k0 % XS_S == XS_S - 1) ? 1 : 0;                       // (k0 is even: the wrap class exists for odd s only)
-            constexpr int tapc = (k0 % XS_S) * XS_XWP + k0 / XS_S;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[kp % (FD + 1)][j] = xqs[j][cls][c0 * XS_XROW + tapc + j * 32];
         } else {
             // (readfirstlane pins the wave-uniform part in a scalar register: vector + scalar is then one add per step)
             const int o = xt[k0] + __builtin_amdgcn_readfirstlane(xsc + c0 * xrow + tap[k0]);
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         else run_loop(std::false_type{});
     } else {
     auto main_loop = [&](auto xr_tag) __attribute__((always_inline)) {
-    constexpr int XR = decltype(xr_tag)::value;   // 0 generic, 1 constant pitch (stride 1), 2 constant pitch (stride K / 2)
+    constexpr int XR = decltype(xr_tag)::value;   // 0 generic, 1 constant pitch
     for (int cb = 0; cb < n_cb; ++cb) {
         const int cur = cb & 1;
         const float* Ac = As0 + cur * A_FLOATS + hi * BM + nc_a_lane_off<TM>(l31);
@@ -549,13 +551,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                     for (int k = 0; k < K; ++k) xq[j][k] += dx;
             }
         }
-        if constexpr (XR == 2) {
-            if (cb > 0) {
-                const int dx = cur ? xbuf : -xbuf;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) { xqs[j][0] += dx; xqs[j][1] += dx; }
-            }
-        }
+
         if constexpr (SPEC) {
             nc_static_for<FD>([&](auto d) __attribute__((always_inline)) {
                 if constexpr (decltype(d)::value < KP) load_frag(Ac, Xc, d);
@@ -600,9 +596,6 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     };
     if constexpr (XRCAND) {
         if (xrow == XROWC && s == 1 && !p.no_xr) main_loop(std::integral_constant<int, 1>{});
-        else main_loop(std::integral_constant<int, 0>{});
-    } else if constexpr (XSCAND) {
-        if (s == XS_S && p.dil == 1 && xrow == XS_XROW && xwp == XS_XWP && !p.no_xr) main_loop(std::integral_constant<int, 2>{});
         else main_loop(std::integral_constant<int, 0>{});
     } else {
         main_loop(std::integral_constant<int, 0>{});
