@@ -360,7 +360,9 @@ typedef void (*conv_kernel_fn)(const ConvArgs);
 // so that the wait-count pass keeps the in-order counter across the epilogue's stores -- was built and measures 2-4 % SLOWER on the
 // C = 192 layers (777 -> 814 us; a 32-step ring the same): with two waves per SIMD the batched form lets one wave run its 16 steps
 // uninterrupted while the other waits for its batch, and that coarse alternation feeds the matrix pipe better than two streams
-// interleaved step by step.  conv1x1_kernel above (3-5 waves per SIMD, tile per workgroup) gains 3-5 % from the in-place ring.
+// interleaved step by step.  conv1x1_kernel above (3-5 waves per SIMD, tile per workgroup) gains 3-5 % from the in-place ring, and with
+// buffer-load addressing on top it overtook this kernel on these very layers (1-6 % per layer in steady state, DAC conv_k1 class
+// 3.92 -> 3.79 ms): since then this kernel runs only under NC_PW_STREAM=1 (tests/test_children_gpu.py keeps it held to the oracle).
 template <int TM, int MODE>
 __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvArgs p) {
     constexpr int TN = 2, BM = 32 * TM, BNW = 32 * TN, BN = 4 * BNW;
