@@ -321,7 +321,11 @@ static TileChoice choose_tile(const ConvLayer& L, int64_t blocks_per_rowtile, bo
         const int n_co = (L.rows() + c.BM() - 1) / c.BM();
         const double blocks = (double)blocks_per_rowtile * n_co;
         static const int bpc_gen[5] = {0, 4, 3, 2, 2}, bpc_pw[5] = {0, 6, 5, 3, 3};
-        static const double pen[5] = {0, 1.30, 1.10, 1.05, 1.00};
+        static const double pen_gen[5] = {0, 1.30, 1.10, 1.05, 1.00};
+        // pointwise kernel (re-fitted in round 4 after its ring / addressing changes: 96-row tiles are now its most efficient -- C = 384
+        // over 32 x 5568 columns 460 us with 128-row tiles, 427 with 96)
+        static const double pen_pw[5] = {0, 1.30, 1.10, 1.02, 1.06};
+        const double* pen = pointwise_fast ? pen_pw : pen_gen;
         const int bpc = pointwise_fast ? bpc_pw[c.TM] : bpc_gen[c.TM];
         const double rounds = std::ceil(blocks / (256.0 * bpc));
         // (k = 7 at 128 rows x 256 columns runs out of registers -- 212 B of scratch per lane; C = 256: 1.80 ms against 1.65 ms with 64-row tiles)
