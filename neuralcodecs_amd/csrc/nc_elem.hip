@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) void dwconv_vec_kernel(const float* __restrict
         const int wq = (g0 >> 2) + tid + 256 * u;
         if (wq < 0 || wq >= xw4) r[u] = dw_f32x4{0.0f, 0.0f, 0.0f, 0.0f};             // (T % 4 == 0: a word is all in or all out)
         if (alpha_in) {
-            const nc_f2 lo = nc_snakef2(nc_f2{r[u][0], r[u][1]}, nc_f2{ai, ai}, nc_f2{ai_inv, ai_inv});
-            const nc_f2 hi = nc_snakef2(nc_f2{r[u][2], r[u][3]}, nc_f2{ai, ai}, nc_f2{ai_inv, ai_inv});
+            const nc_f2 lo = nc_snakef2_m(nc_f2{r[u][0], r[u][1]}, nc_f2{ai, ai}, nc_f2{ai_inv, ai_inv});
+            const nc_f2 hi = nc_snakef2_m(nc_f2{r[u][2], r[u][3]}, nc_f2{ai, ai}, nc_f2{ai_inv, ai_inv});
             r[u] = dw_f32x4{lo[0], lo[1], hi[0], hi[1]};
         }
         if (tid + 256 * u < NWORDS) reinterpret_cast<dw_f32x4*>(win)[tid + 256 * u] = r[u];
@@ -145,8 +145,8 @@ __global__ __launch_bounds__(256) void dwconv_vec_kernel(const float* __restrict
             o[i] = a + bv;
         }
         if (alpha_out) {
-            const nc_f2 lo = nc_snakef2(nc_f2{o[0], o[1]}, nc_f2{ao, ao}, nc_f2{ao_inv, ao_inv});
-            const nc_f2 hi = nc_snakef2(nc_f2{o[2], o[3]}, nc_f2{ao, ao}, nc_f2{ao_inv, ao_inv});
+            const nc_f2 lo = nc_snakef2_m(nc_f2{o[0], o[1]}, nc_f2{ao, ao}, nc_f2{ao_inv, ao_inv});
+            const nc_f2 hi = nc_snakef2_m(nc_f2{o[2], o[3]}, nc_f2{ao, ao}, nc_f2{ao_inv, ao_inv});
             o[0] = lo[0]; o[1] = lo[1]; o[2] = hi[0]; o[3] = hi[1];
         }
         const int t = t0 + lt;

@@ -99,8 +99,8 @@ __global__ __launch_bounds__(256, 2) void snac_unit_kernel(const UnitArgs p) {
             su_f32x4 r = st[u];
             if (wq < 0 || wq >= xw4) r = su_f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // (T % 4 == 0: a word is all in or all out)
             const float ai = Tb[(cb * CB + item_ch(u)) * 12 + 10], ai_inv = Tb[(cb * CB + item_ch(u)) * 12 + 11];
-            const nc_f2 lo = nc_snakef2(nc_f2{r[0], r[1]}, nc_f2{ai, ai}, nc_f2{ai_inv, ai_inv});
-            const nc_f2 hi2 = nc_snakef2(nc_f2{r[2], r[3]}, nc_f2{ai, ai}, nc_f2{ai_inv, ai_inv});
+            const nc_f2 lo = nc_snakef2_m(nc_f2{r[0], r[1]}, nc_f2{ai, ai}, nc_f2{ai_inv, ai_inv});
+            const nc_f2 hi2 = nc_snakef2_m(nc_f2{r[2], r[3]}, nc_f2{ai, ai}, nc_f2{ai_inv, ai_inv});
             if (tid + 256 * u < NITEM) reinterpret_cast<su_f32x4*>(Xs)[item_ch(u) * XWORDS + item_wq(u)] = su_f32x4{lo[0], lo[1], hi2[0], hi2[1]};
             __builtin_amdgcn_sched_barrier(0);   // one item at a time: interleaved, the Snake temporaries of all items are live at once
         }
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void snac_unit_kernel(const UnitArgs p) {
                 nc_f2 a2 = {0.0f, 0.0f};                                     // the two columns of a lane: one packed fma per tap
 #pragma unroll
                 for (int k = 0; k < K; ++k) a2 = nc_fma2(nc_f2{wk[k], wk[k]}, nc_f2{row[k * DIL], row[32 + k * DIL]}, a2);
-                return nc_snakef2(a2 + nc_f2{bv, bv}, nc_f2{ao, ao}, nc_f2{ao_inv, ao_inv});
+                return nc_snakef2_m(a2 + nc_f2{bv, bv}, nc_f2{ao, ao}, nc_f2{ao_inv, ao_inv});
             };
             nc_f2 h = build_h(0);
             __builtin_amdgcn_sched_barrier(0);
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void snac_unit_kernel(const UnitArgs p) {
                 nc_f2 v = {(acc[i][0][r] + bias) + rs[2 * r], (acc[i][1][r] + bias) + rs[2 * r + 1]};
                 if constexpr (SNK) {
                     const float ao = Ep[C + R + 4 * hi], ao_inv = Ep[2 * C + R + 4 * hi];
-                    v = nc_snakef2(v, nc_f2{ao, ao}, nc_f2{ao_inv, ao_inv});
+                    v = nc_snakef2_m(v, nc_f2{ao, ao}, nc_f2{ao_inv, ao_inv});
                 }
                 acc[i][0][r] = v[0];
                 acc[i][1][r] = v[1];
