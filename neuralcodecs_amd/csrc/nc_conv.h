@@ -19,7 +19,9 @@
 
 namespace nc {
 
-enum : int { EPI_TANH = 1, EPI_RVQ = 2, EPI_NOISE = 4 };
+enum : int { EPI_TANH = 1, EPI_RVQ = 2, EPI_NOISE = 4,
+             EPI_NO_XR = 1 << 20 };   // NC_NO_XR=1 (a test switch riding in the epilogue flags: a field of its own shifted the argument block and
+                                      // cost the k = 7 loop 51 scalar-register reloads)
 
 struct ConvArgs {
     // input activations [B][Cin][x_len] (row stride x_cstride); positions outside [0,x_len) read as 0
@@ -67,7 +69,6 @@ struct ConvArgs {
     // 0x1fffffff).  flat = 1: B = 1 in the tile map, n_t_tiles covers Bc*n_cols columns, flat_pc = n_cols, flat_hc = halo columns per
     // segment, flat_px = (n_cols + flat_hc) * stride window slots per clip.  Bc = number of clips (both modes).
     int32_t flat, flat_px, flat_pc, flat_hc, Bc;
-    int32_t no_xr;                 // NC_NO_XR=1: the generic fragment addressing even where the window pitch is a compile-time constant
     int32_t co_group;              // row tiles per group of the block -> tile order (see the kernel's tile map); >= 1, divides n_co_tiles
     int32_t in_left, in_Lz, in_L;  // bit 2: padded position j reads q = reflect(j - left) over [0,Lz); samples q >= L are the zero extension (D9)
     // two-input form (in_mode bit 3, IN2 kernels): second operand with the geometry of x and its own pending GroupNorm

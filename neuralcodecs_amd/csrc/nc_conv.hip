@@ -822,7 +822,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     a.n_t_tiles = (a.n_cols + BN - 1) / BN;
     {
         static const bool no_xr = env_flag("NC_NO_XR");
-        a.no_xr = no_xr ? 1 : 0;
+        if (no_xr) a.epi |= EPI_NO_XR;
     }
     a.Bc = B; a.flat = 0; a.flat_px = a.flat_pc = 0x1fffffff; a.flat_hc = 0;
     if (flat) {   // one column axis over all clips: B = 1 in the tile map

@@ -595,7 +595,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     }
     };
     if constexpr (XRCAND) {
-        if (xrow == XROWC && s == 1 && !p.no_xr) main_loop(std::integral_constant<int, 1>{});
+        if (xrow == XROWC && s == 1 && !(p.epi & EPI_NO_XR)) main_loop(std::integral_constant<int, 1>{});
         else main_loop(std::integral_constant<int, 0>{});
     } else {
         main_loop(std::integral_constant<int, 0>{});
