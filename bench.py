@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: audio-seconds/sec of DAC-44.1 kHz encode+decode (x real-time), B=32 x 1 s clips per GPU.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1 without WORLD_SIZE: starts N fresh rank processes itself (self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N --local-group ...              # ONE process drives the N devices through nc_group_create_local
 
 One "step" = DAC.Encode (pad -> encoder -> 9-stage RVQ -> int64 codes + zQ) followed by DAC.Decode(zQ) on one
 batch of 32 synthetic 1 s clips that is already resident in HBM.  With N>1 every rank (one process per GPU)
@@ -17,10 +18,11 @@ The JSON line carries
   * `roofline` for the dominant kernel class (the dilated k=7 residual-unit convolutions, fp32 matrix-core implicit
     GEMM: bound "mfma", peak = 157.3 TFLOP/s dense fp32 MFMA on MI355X) measured with HIP events on the launch stream in a
     second pass of the same --steps steps (the per-launch event pairs stay out of the timed region);
-  * `cpu_baseline`: the C oracle (kind "port") timed on the host cores on the step's WHOLE batch once (~35 s), the
+  * `cpu_baseline`: the C oracle (kind "port") timed on the host cores on the step's WHOLE batch, one warm-up + 3 timed passes, median
+    (~35 s per pass), the
     GPU == oracle check on those clips (`gpu_equals_oracle`, outside the timed region) and `aten_proxy`: the same graph
     as a sequence of ATen CPU operators (tools/aten_proxy.py, the closest stand-in for the reference's TorchSharp-CPU path):
-    one warm-up + 3 timed passes over 2 clips, median;
+    one warm-up + 3 timed passes over 8 clips, median;
   * `extra_configs` (N=1 only): BASELINE configs C3 (Encodec 48 kHz stereo, 16 x 2 s), C5's per-GPU share and C1
     (SNAC 24 kHz, 1 x 1 s) on the same GPU: ms, x real-time, per-class HIP-event times, dominant kernel class with its
     roofline fraction, algorithmic vs PMC bytes, and a GPU == oracle check on one clip.
@@ -205,6 +207,199 @@ def cpu_model():
     return "unknown"
 
 
+def visible_gpus():
+    """Devices this host exposes, counted in a FRESH child process: the launcher itself must never touch the GPU (a process that has
+    initialised it may not start replacements of itself on this pool, and a parent that holds no GPU state cannot leak any)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=600)
+        return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else 0
+    except Exception:
+        return 0
+
+
+def self_launch(n, argv, timeout_s):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (how a single host process -- the reference's callers batch in
+    one process, Examples/Program.cs:228-322 -- or the driver's plain command starts it): spawn N fresh rank processes of this file
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, a free rendezvous port), relay rank 0's single JSON line, exit
+    non-zero as soon as any rank does (the others are stopped by PID).  The parent never imports torch or touches a GPU."""
+    import socket
+    import subprocess
+    import threading
+    have = visible_gpus()
+    if have < n:
+        sys.stderr.write(f"bench.py --gpus {n}: this host exposes {have} GPU(s); a multi-GPU run needs one device per rank "
+                         f"(nothing was started)\n")
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), NC_BENCH_FORCE_DIST="1", NC_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.pop("NC_BENCH_SELF_LAUNCH", None)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, text=True,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None))
+    lines = []
+
+    def pump():
+        for ln in procs[0].stdout:
+            lines.append(ln.rstrip("\n"))
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    t0, rc = time.time(), 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc = bad[0][1] if bad[0][1] > 0 else 1
+            sys.stderr.write(f"bench.py: rank {bad[0][0]} exited with code {bad[0][1]}; stopping the other ranks\n")
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() - t0 > timeout_s:
+            sys.stderr.write(f"bench.py: ranks still running after {timeout_s} s; stopping them\n")
+            rc = 124
+            break
+        time.sleep(0.1)
+    if rc:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    th.join(timeout=10)
+    js = [ln for ln in lines if ln.startswith("{")]
+    for ln in lines:
+        if not ln.startswith("{"):
+            sys.stderr.write(ln + "\n")          # RCCL's banner etc.: not part of the one-line contract
+    if rc == 0 and len(js) != 1:
+        sys.stderr.write(f"bench.py: rank 0 printed {len(js)} JSON lines, expected one\n")
+        rc = 1
+    if rc == 0:
+        print(js[0], flush=True)
+    return rc
+
+
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
+def run_local_group(args):
+    """`--local-group`: ONE process drives --gpus devices through nc_group_create_local (ncclCommInitAll + grouped in-place all-gathers on
+    per-device side streams): the layout of a single C# host (Examples/Program.cs:228-322 batches in one process).  Every device holds
+    its block of clips in HBM; a step = nc_group_*_encode_allgather_local_dev (all devices, asynchronous) + the local decodes + nc_group_wait.
+    Timing: device synchronise of every device on both sides of EXACTLY --steps steps (one process: no barrier to take)."""
+    import torch
+    from neuralcodecs_amd import DAC, SNAC, DACConfig, parallel
+    from neuralcodecs_amd.config import SNACConfig
+    from neuralcodecs_amd.weights import dac_synthetic_state_dict, save_blob, snac_noise, snac_synthetic_state_dict, synthetic_pcm
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n} --local-group: this host exposes {have} GPU(s)")
+    snac_mode = args.config == "snac44k"
+    B = args.batch or (8 if snac_mode else 32)
+    seconds = args.seconds or (5.0 if snac_mode else 1.0)
+    cfg = SNACConfig.snac_44khz() if snac_mode else DACConfig.dac_44khz()
+    sr = cfg.sampling_rate if snac_mode else cfg.sample_rate
+    blob = save_blob(snac_synthetic_state_dict(cfg, seed=42) if snac_mode else dac_synthetic_state_dict(cfg, seed=42))
+    T = int(round(seconds * sr))
+    models, blocks, noises = [], [], []
+    for d in range(n):
+        m = (SNAC if snac_mode else DAC)(cfg, device_index=d)
+        m.load_blob(blob)
+        models.append(m)
+        dev = torch.device("cuda", d)
+        blocks.append(torch.from_numpy(synthetic_pcm(B, 1, T, sr, seed=1234 + d * B)).to(dev))
+        if snac_mode:
+            noises.append(m.flat_noise(snac_noise(cfg, B, m.query(T)[1], seed=3 + d), dev))
+    g = parallel.Group.local(models)
+    if args.pack_bits:
+        g.set_code_bits(args.pack_bits)
+    state = {}
+
+    def step():
+        if snac_mode:
+            call, widths = g.snac_encode_allgather_local(blocks, codes_all=state.get("codes_all"))
+            state["codes_all"] = call
+            audio = []
+            for d, m in enumerate(models):
+                local = parallel.split_levels(call[d][d * B:(d + 1) * B], widths)    # (views of the device's own slot)
+                with torch.cuda.device(d):
+                    audio.append(m.decode([c.contiguous() for c in local], noises[d]))
+        else:
+            z, call, _ = g.dac_encode_allgather_local(blocks, codes_all=state.get("codes_all"))
+            state["codes_all"] = call
+            audio = []
+            for d, m in enumerate(models):
+                with torch.cuda.device(d):
+                    audio.append(m.decode(z[d]))
+        g.wait()
+        return call, audio
+
+    def sync():
+        for d in range(n):
+            torch.cuda.synchronize(d)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    with torch.cuda.device(0):
+        marks[0].record()
+    for i in range(args.steps):
+        call, audio = step()
+        with torch.cuda.device(0):
+            marks[i + 1].record()
+    sync()
+    dt = time.perf_counter() - t0
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    for m in models:
+        m.check_errors()
+    ok = None
+    if not args.no_check:
+        # every device's copy of the gathered tensor equals every other's, and slot d equals a plain encode of block d on device d
+        ok = all(torch.equal(call[0].cpu(), call[d].cpu()) for d in range(1, n))
+        for d, m in enumerate(models):
+            with torch.cuda.device(d):
+                want = torch.cat([c.reshape(B, -1) for c in m.encode(blocks[d])], dim=1) if snac_mode else m.encode(blocks[d])[1]
+                torch.cuda.synchronize(d)
+            ok = ok and bool(torch.equal(call[d][d * B:(d + 1) * B].reshape(B, -1), want.reshape(B, -1)))
+    models[0].profile_enable(True)
+    models[0].profile_reset()
+    for _ in range(args.steps):
+        step()
+    sync()
+    prof = models[0].profile_read()
+    models[0].profile_enable(False)
+    classes = class_table(prof, args.steps, None)
+    g.dispose()
+    for m in models:
+        m.dispose()
+    ms = dt / args.steps * 1e3
+    name = "SNAC-44.1kHz B=8 x 5 s per GPU" if snac_mode else "DAC-44.1kHz B=32"
+    out = {"metric": "audio-seconds/sec encode+decode (x real-time), " + name, "value": round(n * B * seconds * args.steps / dt, 2),
+           "unit": "audio-seconds/sec", "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+           "ms_per_step_median": round(median(step_ms), 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": ("SNAC 44.1kHz + LocalMHA" if snac_mode else "DAC 44.1kHz 8kbps") + " encode+decode, batch=%d x %.0f s clips per GPU" % (B, seconds),
+                      "clips_per_gpu": B, "clip_seconds": seconds, "global_batch": n * B, "launch": "one host process, nc_group_create_local",
+                      "collective": "grouped RCCL all_gather of the codes, in place, one side stream per device" + (", %d-bit packed" % args.pack_bits if args.pack_bits else ""),
+                      "gathered_equals_1gpu_every_slot_every_device": ok},
+           "roofline": dict(dominant(classes) or {}, all_classes=classes, note="device 0's launches"), "cpu_baseline": None}
+    assert ok is not False, "gathered codes differ between devices or from the plain encode"
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,12 +411,22 @@ def main():
     ap.add_argument("--pack-bits", type=int, default=0, help="N > 1: all-gather the codes bit-packed (10 for DAC's 1024-entry codebooks, 12 for SNAC)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=0, help="clips in the CPU-baseline sample (default: the whole batch of one step, BASELINE.md 3.1)")
-    ap.add_argument("--cpu-iters", type=int, default=1, help="timed passes of the C-oracle baseline over the sample (median reported; one pass of the C2 batch is ~35 s)")
-    ap.add_argument("--proxy-iters", type=int, default=3, help="timed passes of the ATen operator-sequence proxy (2 clips; median)")
+    ap.add_argument("--cpu-iters", type=int, default=3, help="timed passes of the C-oracle baseline over the sample (BASELINE.md 3.1: >= 3, median reported; one pass of the C2 batch is ~35 s)")
+    ap.add_argument("--proxy-iters", type=int, default=3, help="timed passes of the ATen operator-sequence proxy (median)")
+    ap.add_argument("--proxy-clips", type=int, default=8, help="clips of the step the ATen proxy runs per pass")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs block (C3 / C5 share / C1)")
     ap.add_argument("--no-check", action="store_true", help="skip the GPU == oracle comparisons (outside the timed region)")
     ap.add_argument("--check", action="store_true", help="(default now) kept for compatibility")
+    ap.add_argument("--local-group", action="store_true", help="ONE process drives --gpus devices through nc_group_create_local (single-host layout)")
+    ap.add_argument("--launch-timeout", type=int, default=3300, help="self-launched ranks are stopped after this many seconds")
     args = ap.parse_args()
+
+    if args.local_group:
+        sys.exit(run_local_group(args))
+    # `--gpus N` with no process group in the environment: be the launcher (fresh rank processes; this process never touches a GPU)
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("NC_BENCH_CHILD") != "1" and \
+            (args.gpus > 1 or os.environ.get("NC_BENCH_SELF_LAUNCH") == "1"):
+        sys.exit(self_launch(args.gpus, sys.argv[1:], args.launch_timeout))
 
     import torch
     import torch.distributed as dist
@@ -233,8 +438,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running the {world}-rank job the launcher started\n")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py rank {rank}: no GPU with index {local_rank} on this host ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # NC_BENCH_FORCE_DIST=1 exercises the RCCL path (process group, side-stream all-gather, barrier) with a single rank
@@ -444,7 +650,7 @@ def main():
                                             "pcm_max_abs_diff": float(np.abs(audio[:n].cpu().numpy() - raudio).max())}
             if not snac_mode:
                 try:
-                    cpu["aten_proxy"] = aten_proxy(cfg, sd, pcm_h[:min(2, B)], seconds, args.proxy_iters)
+                    cpu["aten_proxy"] = aten_proxy(cfg, sd, pcm_h[:max(1, min(args.proxy_clips, B))], seconds, args.proxy_iters)
                 except Exception as e:   # the proxy is informational: never lose the bench line to it
                     cpu["aten_proxy"] = {"error": repr(e)}
         if snac_mode:

@@ -100,6 +100,11 @@ NC_API nc_status nc_codec_synchronize(nc_codec* h);
  * for a failure of the previous one first.  NC_EDEVICE = the results of that call are invalid; the handle has switched to the
  * step-wise kernels, so repeating the call succeeds (the host-pointer entry points repeat it themselves). */
 NC_API nc_status nc_codec_check_errors(nc_codec* h);
+/* Encodec handles: which LSTM kernels the handle runs (SLSTM.cs:40-57) -- *stepwise = 1 once a persistent launch has timed out (or the
+ * device cannot hold one) -- and how many such timeouts this handle has seen.  Persistent LSTM sections of DIFFERENT handles on one
+ * device are ordered one after the other on the GPU (a per-device ticket inside the engine: their workgroups must be co-resident and two
+ * handles' worth do not fit), so concurrent handles keep the persistent kernels; only other PROCESSES sharing the device can starve them. */
+NC_API nc_status nc_encodec_lstm_stats(const nc_codec* h, int32_t* stepwise, int64_t* timeouts);
 
 /* Shape helper for DAC.Preprocess (Models/DAC.cs:141-154): padded length and frame count T'. */
 NC_API nc_status nc_dac_query(const nc_codec* h, int64_t T, int64_t* T_padded, int64_t* frames);
@@ -318,7 +323,9 @@ NC_API nc_status nc_group_info(const nc_group* g, int32_t* world, int32_t* rank 
 /* Payload of the code all-gather: bits = 0 (default) moves the int64 codes as they are; 1..24 moves them bit-packed in the wire layout of
  * the reference's BitPacker (Modules/Encodec/BitPacker.cs: `bits` per value, LSB first, one packed row per clip; bits = 10 for 1024-entry
  * codebooks, 12 for SNAC's 4096) -- 64 / bits times fewer bytes on xGMI; pack and unpack run on the device around the collective and
- * the caller's tensors stay int64.  A code that does not fit `bits` is truncated to its low bits: pick bits >= log2(codebook size). */
+ * the caller's tensors stay int64.  A code that does not fit `bits` is truncated to its low bits: pick bits >= log2(codebook size).
+ * Rank mode: EVERY rank must set the same value before the next gather (the byte counts of the collective follow from it; a mismatch is
+ * not detectable without another collective and hangs the gather). */
 NC_API nc_status nc_group_set_code_bits(nc_group* g, int32_t bits);
 /* rank mode, device pointers, asynchronous: encode this rank's B_local clips (nc_dac_encode_dev / nc_snac_encode_dev semantics) with the
  * codes written straight into slot `rank` of codes_all [world*B_local, ...], then the in-place all-gather on the group's side stream.
@@ -335,6 +342,17 @@ NC_API nc_status nc_group_wait(nc_group* g);
 NC_API nc_status nc_group_dac_encode_allgather(nc_group* g, const float* pcm, int32_t B_total, int64_t T, int32_t sample_rate, int32_t n_q,
                                                int64_t* codes, float* z);
 NC_API nc_status nc_group_snac_encode_allgather(nc_group* g, const float* pcm, int32_t B_total, int64_t T, int64_t* codes);
+/* local mode, device pointers, asynchronous (the single-host layout of Examples/Program.cs:228-322 with the batch already split and
+ * resident): pcm[d] [B_local[d],1,T] lives on member d's GPU and is encoded on member d's stream (nc_dac_encode_dev / nc_snac_encode_dev
+ * semantics; z_local / latents_local nullable arrays of per-device outputs) with the codes written into slot d of codes_all[d], member
+ * d's OWN copy of the gathered tensor [ndev * B_max, ...] (B_max = the largest block; a shorter block's slot is zero-padded); the grouped
+ * in-place all-gather runs on the members' side streams, so every device ends up holding every block.  Nothing waits on the host:
+ * nc_group_wait orders each codec's stream behind its gather; the decode of the local block can be queued before it. */
+NC_API nc_status nc_group_dac_encode_allgather_local_dev(nc_group* g, const float* const* pcm, const int32_t* B_local, int64_t T,
+                                                         int32_t sample_rate, int32_t n_q, int64_t* const* codes_all, float* const* z_local,
+                                                         float* const* latents_local);
+NC_API nc_status nc_group_snac_encode_allgather_local_dev(nc_group* g, const float* const* pcm, const int32_t* B_local, int64_t T,
+                                                          int64_t* const* codes_all);
 
 /* ------------------------------------------------------------------------------------ profiling
  * Per-kernel-class timing with HIP events recorded on the handle's stream around every launch

@@ -76,6 +76,7 @@ SYMBOLS = [
     ("nc_codec_reset_stream", C.c_int, [_P]),
     ("nc_codec_synchronize", C.c_int, [_P]),
     ("nc_codec_check_errors", C.c_int, [_P]),
+    ("nc_encodec_lstm_stats", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     ("nc_dac_query", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("nc_dac_encode", C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P]),
     ("nc_dac_encode_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P]),
@@ -134,6 +135,9 @@ SYMBOLS = [
     ("nc_group_wait", C.c_int, [_P]),
     ("nc_group_dac_encode_allgather", C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     ("nc_group_snac_encode_allgather", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
+    ("nc_group_dac_encode_allgather_local_dev", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int64, C.c_int32, C.c_int32, C.POINTER(_P),
+                                                          C.POINTER(_P), C.POINTER(_P)]),
+    ("nc_group_snac_encode_allgather_local_dev", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int64, C.POINTER(_P)]),
     ("nc_codec_profile_enable", C.c_int, [_P, C.c_int32]),
     ("nc_codec_profile_reset", C.c_int, [_P]),
     ("nc_codec_profile_read", C.c_int, [_P, C.POINTER(NcProfileEntry)]),

@@ -54,7 +54,11 @@ void d2h(void* h, const void* d, size_t n, hipStream_t s) { NC_HIP(hipMemcpyAsyn
 extern "C" {
 
 const char* nc_last_error(void) { return get_last_error(); }
+#ifdef NC_EXPERIMENTS
+const char* nc_version(void) { return "nc_mi355x 0.1 (gfx950) +experiments"; }   // make EXPERIMENTS=1: measured-and-rejected kernels and their switches
+#else
 const char* nc_version(void) { return "nc_mi355x 0.1 (gfx950)"; }
+#endif
 
 const char* nc_debug_switches(void) { return env_switch_table(); }
 
@@ -150,6 +154,14 @@ nc_status nc_codec_check_errors(nc_codec* h) {
     return guard([&] {
         if (!h || !h->impl) fail(NC_EINVAL, "null codec handle");
         h->impl->check_async_errors();
+    });
+}
+
+nc_status nc_encodec_lstm_stats(const nc_codec* h, int32_t* stepwise, int64_t* timeouts) {
+    return guard([&] {
+        EncodecModel& m = as_encodec(const_cast<nc_codec*>(h));
+        if (stepwise) *stepwise = m.lstm_force_stepwise ? 1 : 0;
+        if (timeouts) *timeouts = m.lstm_timeouts;
     });
 }
 

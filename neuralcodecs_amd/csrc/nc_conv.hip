@@ -95,7 +95,11 @@ static conv_kernel_fn in2_kernel(int Ktaps, bool sub, int TM, int TN) {
     return nullptr;
 }
 conv_kernel_fn conv1x1_kernel_table(int, int);
-conv_kernel_fn conv1x1_stream_kernel_table(int, int);
+#ifdef NC_EXPERIMENTS
+conv_kernel_fn conv1x1_stream_kernel_table(int, int);   // (round 2's streaming pointwise variant: overtaken in round 4, EXPERIMENTS=1 builds only)
+#else
+static conv_kernel_fn conv1x1_stream_kernel_table(int, int) { return nullptr; }
+#endif
 bool launch_conv_thin(const float* x, int64_t x_bstride, int64_t x_cstride, int Cin, int x_len, const float* w_dense, const float* bias, float* y,
                       int64_t y_bstride, int64_t y_cstride, int B, int Cout, int K, int pad, int dil, int64_t Tout, bool tanh_out, hipStream_t s);
 bool launch_conv_stem(const float* x, int64_t x_bstride, int x_len, const float* w_dense, const float* bias, const float* alpha_out, float* y,
@@ -464,9 +468,13 @@ static bool launch_conv1x1(const ConvLayer& L, const ConvIO& io, int B, hipStrea
     size_t lds = 0;
     {   // streaming variant: narrow long rows, whole weight tile of a row tile resident in LDS (see conv1x1_stream_kernel)
         // (not the default since round 4: with the in-place B ring and buffer-load addressing the tile-per-workgroup kernel is 1-6 % faster on
-        // these layers in steady state, DAC conv_k1 class 3.92 -> 3.79 ms; NC_PW_STREAM=1 selects the streaming variant, and the parity
-        // suites run under it in tests/test_children_gpu.py)
+        // these layers in steady state, DAC conv_k1 class 3.92 -> 3.79 ms; round 5: the streaming variant is compiled by `make EXPERIMENTS=1`
+        // only, where NC_PW_STREAM=1 selects it -- tools/probe/envmatrix.sh builds that library and runs the parity suites under it)
+#ifdef NC_EXPERIMENTS
         static const bool no_stream = !env_flag("NC_PW_STREAM");
+#else
+        constexpr bool no_stream = true;
+#endif
         const size_t need = sizeof(float) * ((size_t)L.Cin * BM + 3 * (size_t)BM);
         conv_kernel_fn sfn = (!no_stream && !in_mode && mode <= 4 && L.Cin % 32 == 0 && L.Cin <= 192 && L.Cout % BM == 0 && need <= 76 * 1024 &&
                               grid >= 2048)

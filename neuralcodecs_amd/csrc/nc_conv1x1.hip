@@ -347,6 +347,7 @@ __global__ __launch_bounds__(256, conv1x1_occupancy(TM)) void conv1x1_kernel(con
 
 typedef void (*conv_kernel_fn)(const ConvArgs);
 
+#ifdef NC_EXPERIMENTS   // measured-and-overtaken variant: `make EXPERIMENTS=1` only
 // Streaming pointwise convolution for the narrow long rows (Cin <= 192: the SNAC residual / noise / attention projections at
 // 5 s x 44.1 kHz, the DAC C = 192 units): these layers move 12*C bytes per 2*C*C flops -- 16-32 flop/B, the HBM side of the machine
 // balance -- and the tile-per-workgroup kernel above reaches 3.0-3.5 TB/s on them: its B ring holds 4 steps (2 KB per wave) and
@@ -518,6 +519,7 @@ conv_kernel_fn conv1x1_stream_kernel_table(int TM, int mode) {
     }
     return nullptr;
 }
+#endif  // NC_EXPERIMENTS
 
 // Skinny projection: 1x1 conv with Cout <= 16 (the RVQ in_proj 1024 -> 8, VectorQuantizer.cs:47,76) over N = B*T frames.  The
 // generic tile would run one workgroup per clip with a barrier every 16 channels; here one wavefront owns 16 frames and walks the

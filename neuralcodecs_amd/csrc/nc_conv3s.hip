@@ -57,7 +57,7 @@ template <int TM, bool XV2>
 __global__ __launch_bounds__(256, conv3s_occupancy(TM)) void conv3_stream_kernel(const ConvArgs p) {
     constexpr int TN = 2, CB = 16, K = 3;
     constexpr int BM = 32 * TM, BNW = 32 * TN, BN = 4 * BNW;
-    constexpr int KB = CB * K, KP = KB / 2;          // 24 matrix-core steps per reduction block = 8 channel pairs x 3
+    constexpr int KB = CB * K;                       // 24 matrix-core steps per reduction block = 8 channel pairs x 3
     constexpr int A_FLOATS = KB * BM, A_VEC = A_FLOATS / 4, NA = (A_VEC + 255) / 256;
     constexpr int PF = 4;                            // channel pairs in flight (divides the 8 pairs of a block)
 

@@ -10,6 +10,7 @@
 // Arithmetic is the canonical arithmetic of DESIGN.md (same sequences as oracle/c/nc_ref_encodec.c).
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 
 #include "nc_gn.h"
 #include "nc_math.h"
@@ -817,6 +818,7 @@ void EncodecModel::load_lstm(const Blob& b, const std::string& key, Lstm& l, int
         }
         upload(y.bhh, static_cast<const float*>(bhh.data), (size_t)4 * C);
         upload(y.bih, static_cast<const float*>(bih.data), (size_t)4 * C);
+#ifdef NC_EXPERIMENTS
         if (lstm2_supported(C)) {   // fragment images of nc_lstm.hip: W_hh of every layer (per-layer split kernel), W_ih of the upper one (fused kernel)
             std::vector<float> img((size_t)4 * C * C);
             lstm2_pack_image(static_cast<const float*>(whh.data), C, img.data());
@@ -826,6 +828,7 @@ void EncodecModel::load_lstm(const Blob& b, const std::string& key, Lstm& l, int
                 upload(y.w2ih, img.data(), img.size());
             }
         }
+#endif
     }
 }
 
@@ -904,6 +907,42 @@ void EncodecModel::load(const Blob& b) {
     loaded = true;
 }
 
+// ---- per-device ticket of the persistent LSTM sections (include/nc_mi355x.h "threading": distinct handles may run concurrently) --------
+// A persistent launch needs ALL its workgroups resident (one per CU at ~140 KB of LDS); a handle budgets its own launches for that (<= 64
+// workgroups per launch, two pipelined layers, a concurrent tail-segment group: <= 192 of the 256 CUs).  Two handles driven from two host
+// threads on ONE device would double that: partially resident launches then spin for CUs that other partially resident launches hold, until
+// the bounded spins time out and both handles drop to the step-wise kernels for good.  So the LSTM sections of DIFFERENT handles on one
+// device run one after the other on the GPU: a section waits for the event recorded behind the previous section (of any handle) and
+// records it again behind itself -- stream-ordered, no host wait; the mutex only keeps two host threads from interleaving their enqueues
+// (held for the ~100 us a section takes to enqueue).  A device with one LSTM-running handle never waits.  Everything else of the two
+// handles (convolutions, quantizer) still overlaps.  Other PROCESSES on the same device are outside its reach (the timeout path remains).
+struct LstmTicket {
+    std::mutex mu;
+    hipEvent_t ev = nullptr;   // behind the last persistent section enqueued on this device
+    int live = 0;              // handles on this device that have run a persistent section
+};
+static LstmTicket& lstm_ticket_of(int device) {
+    static std::mutex m;
+    static std::map<int, std::unique_ptr<LstmTicket>> t;
+    std::lock_guard<std::mutex> lk(m);
+    auto& p = t[device];
+    if (!p) p.reset(new LstmTicket());
+    return *p;
+}
+namespace {
+struct LstmSection {
+    LstmTicket& t;
+    hipStream_t s;
+    std::unique_lock<std::mutex> lk;
+    LstmSection(EncodecModel& m, hipStream_t stream) : t(m.lstm_ticket ? *m.lstm_ticket : lstm_ticket_of(m.device)), s(stream), lk(t.mu) {
+        if (!m.lstm_ticket) { m.lstm_ticket = &t; ++t.live; }
+        if (!t.ev) NC_HIP(hipEventCreateWithFlags(&t.ev, hipEventDisableTiming));
+        else if (t.live > 1) NC_HIP(hipStreamWaitEvent(s, t.ev, 0));
+    }
+    ~LstmSection() { if (t.ev) (void)hipEventRecord(t.ev, s); }
+};
+}  // namespace
+
 EncodecModel::~EncodecModel() {
     for (int i = 0; i < 2; ++i) {
         if (side_stream[i]) (void)hipStreamDestroy(side_stream[i]);
@@ -916,6 +955,10 @@ EncodecModel::~EncodecModel() {
         if (e) (void)hipEventDestroy(e);
     if (ola_pin) (void)hipHostFree(ola_pin);
     if (lstm_tmo_host) (void)hipHostFree(lstm_tmo_host);
+    if (lstm_ticket) {
+        std::lock_guard<std::mutex> lk(lstm_ticket->mu);
+        --lstm_ticket->live;
+    }
 }
 
 // Called where the host knows the stream is idle (nc_codec_synchronize, the host-pointer entry points, nc_codec_check_errors) and at the
@@ -929,6 +972,7 @@ void EncodecModel::check_async_errors() {
     (void)hipStreamSynchronize(stream);
     *reinterpret_cast<volatile unsigned*>(lstm_tmo_host) = 0;
     lstm_force_stepwise = true;
+    ++lstm_timeouts;
     fail(NC_EDEVICE, "persistent LSTM kernel: a workgroup exchange timed out (its workgroups were not co-resident); the results of that call are "
                      "invalid -- this handle now runs the step-wise LSTM kernels, repeat the call");
 }
@@ -941,6 +985,7 @@ void EncodecModel::absorb_stale_timeout() {
     (void)hipStreamSynchronize(stream);
     *reinterpret_cast<volatile unsigned*>(lstm_tmo_host) = 0;
     lstm_force_stepwise = true;
+    ++lstm_timeouts;
 }
 
 // ---- launch helpers --------------------------------------------------------------------------------
@@ -1143,6 +1188,7 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
         io.y = gi; io.y_bstride = (int64_t)4 * C * T; io.y_cstride = T;
         launch_conv(y.ih, io, N, s, &prof);
     };
+#ifdef NC_EXPERIMENTS   // measured-and-rejected: `make EXPERIMENTS=1` compiles nc_lstm.hip and these two branches
     // Fused two-layer launch (nc_lstm.hip, NC_LSTM_FUSED=1): every step of both layers in ONE persistent launch per pair of column tiles
     // -- no drain in the exchange (values validated against a sentinel), chain wavefronts that never store, no tensors between the
     // layers, no chunked projection GEMMs.  Bit-exact, but MEASURED SLOWER than the per-layer kernels below on two tiles (C3 9.5-9.8
@@ -1155,6 +1201,7 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
     const size_t ex_floats = lstm2_exchange_floats(C, T, std::min(n_tiles2, 2));
     if (!stepwise && !per_layer_env && nl == 2 && lstm2_supported(C) && l.layers[1]->w2ih.p && cu_count >= C / 4 &&
         lds_per_cu >= lstm2_lds_bytes(C, std::min(n_tiles2, 2)) && ex_floats * 4 < ((size_t)1 << 31) && (int64_t)4 * C * T * N < ((int64_t)1 << 31)) {
+        LstmSection section(*this, stream);
         {   // NC_LSTM_FAKE_TIMEOUT=1 (tests): the first persistent launch of the process is reported as timed out
             static bool fake = env_flag("NC_LSTM_FAKE_TIMEOUT");
             if (fake) { fake = false; *reinterpret_cast<volatile unsigned*>(lstm_tmo_host) = 1; }
@@ -1210,7 +1257,9 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
         }
         return out;
     }
+#endif  // NC_EXPERIMENTS
     if (!stepwise && C % 64 == 0 && (KS == 128 || KS == 16)) {
+        LstmSection section(*this, stream);   // (see LstmTicket: sections of different handles on one device run one after the other)
         // Persistent layer kernel: a launch runs a range of steps for a group of column tiles (<= 64 co-resident workgroups, so the
         // two layers of a pipelined call plus a concurrent segment group still fit the chip's 256 CUs at one workgroup per CU).
         // Layer pipelining: layer l+1 at step t needs only h^l_t, so the sequence is cut into chunks and chunk k of layer l+1 (with its
@@ -1259,9 +1308,13 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
         // with the flags polled by a gate wave and by a (load-only) chain wave alike: without the drain the hint flags run ahead of
         // the payload, so operand loads are retried, and the LDS post / wait hops between chain, gate and polling waves cost more than
         // the two workgroup barriers they replace.  Not the default; DESIGN 8 round 4.
+#ifdef NC_EXPERIMENTS
         static const bool want_split = env_flag("NC_LSTM_SPLIT");
         const bool split = want_split && lstm2_supported(C) && l.layers[0]->w2hh.p && lds_per_cu >= lstm1_lds_bytes(C) &&
                            (size_t)T * n_tiles * C * 16 * 4 < ((size_t)1 << 31);
+#else
+        constexpr bool split = false;
+#endif
         std::vector<float*> gi(nl), out(nl), hx(nl), cs(nl);
         std::vector<unsigned*> flags(nl);
         for (int li = 0; li < nl; ++li) {
@@ -1298,6 +1351,7 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
             const bool last = li + 1 == nl;
             const double n = (double)N * (double)(t1 - t0);
             if (prof.on) prof.begin(s, NC_KC_LSTM, 2.0 * 4 * C * C * n, 4.0 * 6 * C * n);
+#ifdef NC_EXPERIMENTS
             for (int tl = 0; split && tl < n_tiles; tl += 4) {                         // (C / 16 workgroups per tile: up to four tiles per launch)
                 const int nt = std::min(4, n_tiles - tl);
                 LstmSplitArgs a{};
@@ -1310,6 +1364,7 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
                 a.N = N; a.C = C; a.T = T; a.t0 = t0; a.t1 = t1; a.tile0 = tl; a.tiles_total = n_tiles;
                 lstm1_launch(a, nt, s);
             }
+#endif
             for (int tl = 0; !split && tl < n_tiles; tl += per_launch) {
                 const int nt = std::min(per_launch, n_tiles - tl);
                 LstmSeqArgs a{};
@@ -1455,6 +1510,7 @@ void EncodecModel::encode_batch(const float* x, int N, int64_t L, int64_t Tz, in
         // all stages in one launch, cross terms on the matrix cores (the residual block stays in LDS between the stages)
         // (NC_RVQ_8WAVES=1: 8 wavefronts per workgroup, 128 codes each -- measured the same 236 us on C3's 150-workgroup grid as the
         // 4-wave form: the stage is bound by its serial phases and the codebook stream, not by the matrix-core chain)
+#ifdef NC_EXPERIMENTS
         static const bool rvq8 = env_flag("NC_RVQ_8WAVES");
         const bool wide = rvq8 && Nc % 1024 == 0 && (total + EM_F - 1) / EM_F <= 256;
         if (wide)
@@ -1462,6 +1518,7 @@ void EncodecModel::encode_batch(const float* x, int N, int64_t L, int64_t Tz, in
                                book_ptrsT.as<const float*>(), book_ptrs.as<const float*>(), book_ptrs2.as<const float*>(), n_q, Nc, N, Tz, codes,
                                (int64_t)n_q * Tz);
         else
+#endif
         hipLaunchKernelGGL(euclid_rvq_mfma_kernel<128>, dim3((unsigned)((total + EM_F - 1) / EM_F)), dim3(256), 0, stream, residual,
                            book_ptrsT.as<const float*>(), book_ptrs.as<const float*>(), book_ptrs2.as<const float*>(), n_q, Nc, N, Tz, codes,
                            (int64_t)n_q * Tz);

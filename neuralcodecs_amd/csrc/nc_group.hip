@@ -175,22 +175,50 @@ int64_t encode_into_slot(nc_group::Member& x, int kind, int slot, const float* p
     return per_rank;
 }
 
-// The all-gather of one member on its side stream.  code_bits == 0: the int64 slots in place.  code_bits > 0 (nc_group_set_code_bits): the
-// member packs its own slot into the wire layout of the reference's BitPacker (Modules/Encodec/BitPacker.cs: `bits` per value, LSB
-// first; one packed row per clip, csrc/nc_pack.hip), the collective moves the packed rows -- 64 / bits times fewer bytes -- and every
-// slot is unpacked back into the int64 tensor the caller sees.  rows = clips per slot, per_clip = values per clip.
-void gather_slots(nc_group* g, nc_group::Member& x, int slot, int64_t* codes_all, int rows, int64_t per_clip) {
+// The all-gather of one member on its side stream, in two halves so that local mode keeps ONLY the collectives between ncclGroupStart and
+// ncclGroupEnd (no allocation, kernel launch or throwing call inside an open RCCL group).  code_bits == 0: the int64 slots in place.
+// code_bits > 0 (nc_group_set_code_bits): the member packs its own slot into the wire layout of the reference's BitPacker
+// (Modules/Encodec/BitPacker.cs: `bits` per value, LSB first; one packed row per clip, csrc/nc_pack.hip), the collective moves the packed
+// rows -- 64 / bits times fewer bytes -- and every slot is unpacked back into the int64 tensor the caller sees.  rows = clips per slot,
+// per_clip = values per clip.
+void prepare_slot(nc_group* g, nc_group::Member& x, int slot, int64_t* codes_all, int rows, int64_t per_clip) {
+    if (g->code_bits <= 0) return;
     const int64_t per_rank = (int64_t)rows * per_clip;
-    if (g->code_bits <= 0) {
-        NC_RCCL(rccl().AllGather(codes_all + (int64_t)slot * per_rank, codes_all, (size_t)per_rank, ncclInt64, x.comm, x.side));
-        return;
-    }
     const int64_t row_bytes = nc_packed_bytes(per_clip, g->code_bits), slot_bytes = (int64_t)rows * row_bytes;
     x.packed_all.reserve((size_t)slot_bytes * g->world);
     uint8_t* pk = x.packed_all.as<uint8_t>();
     nc_status st = nc_pack_codes_dev(x.device, codes_all + (int64_t)slot * per_rank, rows, 1, per_clip, g->code_bits, pk + (int64_t)slot * slot_bytes, x.side);
     if (st != NC_OK) fail(st, "%s", get_last_error());
-    NC_RCCL(rccl().AllGather(pk + (int64_t)slot * slot_bytes, pk, (size_t)slot_bytes, ncclUint8, x.comm, x.side));
+}
+ncclResult_t issue_gather(nc_group* g, nc_group::Member& x, int slot, int64_t* codes_all, int rows, int64_t per_clip) {
+    const int64_t per_rank = (int64_t)rows * per_clip;
+    if (g->code_bits <= 0) return rccl().AllGather(codes_all + (int64_t)slot * per_rank, codes_all, (size_t)per_rank, ncclInt64, x.comm, x.side);
+    const int64_t slot_bytes = (int64_t)rows * nc_packed_bytes(per_clip, g->code_bits);
+    uint8_t* pk = x.packed_all.as<uint8_t>();
+    return rccl().AllGather(pk + (int64_t)slot * slot_bytes, pk, (size_t)slot_bytes, ncclUint8, x.comm, x.side);
+}
+void gather_slots(nc_group* g, nc_group::Member& x, int slot, int64_t* codes_all, int rows, int64_t per_clip) {
+    prepare_slot(g, x, slot, codes_all, rows, per_clip);
+    NC_RCCL(issue_gather(g, x, slot, codes_all, rows, per_clip));
+}
+// local mode: every member's collective inside ONE RCCL group; the group is closed on the error path too
+void grouped_gather(nc_group* g, const std::vector<int64_t*>& codes_all, int rows, int64_t per_clip) {
+    const int W = g->world;
+    for (int d = 0; d < W; ++d) {
+        nc_group::Member& x = g->m[(size_t)d];
+        NC_HIP(hipSetDevice(x.device));
+        prepare_slot(g, x, d, codes_all[(size_t)d], rows, per_clip);
+    }
+    NC_RCCL(rccl().GroupStart());
+    ncclResult_t bad = ncclSuccess;
+    for (int d = 0; d < W && bad == ncclSuccess; ++d) {
+        nc_group::Member& x = g->m[(size_t)d];
+        if (hipSetDevice(x.device) != hipSuccess) { bad = ncclUnhandledCudaError; break; }
+        bad = issue_gather(g, x, d, codes_all[(size_t)d], rows, per_clip);
+    }
+    const ncclResult_t end = rccl().GroupEnd();
+    if (bad != ncclSuccess) fail(NC_EDEVICE, "ncclAllGather failed inside the group: %s", rccl().GetErrorString(bad));
+    if (end != ncclSuccess) fail(NC_EDEVICE, "ncclGroupEnd failed: %s", rccl().GetErrorString(end));
 }
 void unpack_slots(nc_group* g, nc_group::Member& x, int64_t* codes_all, int rows, int64_t per_clip) {
     if (g->code_bits <= 0) return;
@@ -282,13 +310,11 @@ void local_encode_allgather(nc_group* g, int kind, const float* pcm, int B_total
                 NC_HIP(hipMemsetAsync(x.codes_all.as<int64_t>() + (int64_t)d * per_rank + (int64_t)n_of(d) * per_clip, 0,
                                       (size_t)(B_max - n_of(d)) * per_clip * 8, x.side));
             }
-    NC_RCCL(rccl().GroupStart());
-    for (int d = 0; d < W; ++d) {
-        nc_group::Member& x = g->m[(size_t)d];
-        (void)hipSetDevice(x.device);
-        gather_slots(g, x, d, x.codes_all.as<int64_t>(), B_max, per_clip);
+    {
+        std::vector<int64_t*> slots((size_t)W);
+        for (int d = 0; d < W; ++d) slots[(size_t)d] = g->m[(size_t)d].codes_all.as<int64_t>();
+        grouped_gather(g, slots, B_max, per_clip);
     }
-    NC_RCCL(rccl().GroupEnd());
     {   // only device 0's copy goes back to the host: it alone unpacks
         nc_group::Member& x = g->m[0];
         (void)hipSetDevice(x.device);
@@ -311,6 +337,60 @@ void local_encode_allgather(nc_group* g, int kind, const float* pcm, int B_total
     const int64_t* all = static_cast<const int64_t*>(g->m[0].pin_out.p);
     for (int d = 0; d < W; ++d)
         if (n_of(d) > 0) std::memcpy(codes + (int64_t)lo_of(d) * per_clip, all + (int64_t)d * per_rank, (size_t)n_of(d) * per_clip * 8);
+}
+
+// Local mode with DEVICE-resident clips (the single-host layout of Examples/Program.cs:228-322 with the batch already split and uploaded):
+// member d encodes its own block pcm[d] [B_local[d], 1, T] on its codec's stream with the codes written straight into slot d of ITS copy of
+// the gathered tensor codes_all[d] [W * B_max, ...]; the grouped in-place all-gather then runs on the members' side streams, so whatever the
+// caller queues next on a codec's stream (the local decode) overlaps it.  Nothing here waits on the host.
+void local_encode_allgather_dev(nc_group* g, int kind, const float* const* pcm, const int32_t* B_local, int64_t T, int sample_rate, int n_q,
+                                int64_t* const* codes_all, float* const* z, float* const* lat) {
+    if (!g || g->rank >= 0) fail(NC_EINVAL, "group was not created with nc_group_create_local");
+    if (!pcm || !B_local || !codes_all || T <= 0) fail(NC_EINVAL, "bad arguments");
+    const int W = g->world;
+    int B_max = 0;
+    for (int d = 0; d < W; ++d) {
+        if (g->m[(size_t)d].h->kind != kind) fail(NC_EINVAL, kind == 0 ? "handle is not a DAC codec" : "handle is not a SNAC codec");
+        if (B_local[d] < 0 || !codes_all[d] || (B_local[d] > 0 && !pcm[d])) fail(NC_EINVAL, "bad block for device %d", d);
+        B_max = std::max(B_max, (int)B_local[d]);
+    }
+    if (B_max <= 0) fail(NC_EINVAL, "no clips");
+    int64_t per_clip = 0;
+    {
+        Codec& c0 = *g->m[0].h->impl;
+        if (kind == 0) {
+            DacModel& m = static_cast<DacModel&>(c0);
+            const int nq = (n_q <= 0 || n_q > m.cfg.n_codebooks) ? m.cfg.n_codebooks : n_q;
+            per_clip = (int64_t)nq * m.frames(T);
+        } else {
+            SnacModel& m = static_cast<SnacModel&>(c0);
+            per_clip = m.codes_per_clip(m.padded_len(T) / m.hop);
+        }
+    }
+    const int64_t per_rank = (int64_t)B_max * per_clip;
+    for (int d = 0; d < W; ++d) {
+        nc_group::Member& x = g->m[(size_t)d];
+        Codec& c = *x.h->impl;
+        c.use_device();
+        const int B = B_local[d];
+        int64_t* slot = codes_all[d] + (int64_t)d * per_rank;
+        if (B > 0) {
+            if (kind == 0) static_cast<DacModel&>(c).encode_dev(pcm[d], B, T, sample_rate, n_q, slot, z ? z[d] : nullptr, lat ? lat[d] : nullptr);
+            else static_cast<SnacModel&>(c).encode_dev(pcm[d], B, T, slot, nullptr, nullptr, true);
+        }
+        NC_HIP(hipEventRecord(x.ev_enc, c.stream));
+        NC_HIP(hipStreamWaitEvent(x.side, x.ev_enc, 0));
+        if (B < B_max)   // (the rest of a short block's slot is padding: defined values for the packed payload and for the caller)
+            NC_HIP(hipMemsetAsync(slot + (int64_t)B * per_clip, 0, (size_t)(B_max - B) * per_clip * 8, x.side));
+    }
+    std::vector<int64_t*> slots(codes_all, codes_all + W);
+    grouped_gather(g, slots, B_max, per_clip);
+    for (int d = 0; d < W; ++d) {
+        nc_group::Member& x = g->m[(size_t)d];
+        NC_HIP(hipSetDevice(x.device));
+        unpack_slots(g, x, codes_all[d], B_max, per_clip);
+        NC_HIP(hipEventRecord(x.ev_gather, x.side));
+    }
 }
 
 }  // namespace
@@ -412,6 +492,15 @@ nc_status nc_group_dac_encode_allgather(nc_group* g, const float* pcm, int32_t B
 
 nc_status nc_group_snac_encode_allgather(nc_group* g, const float* pcm, int32_t B_total, int64_t T, int64_t* codes) {
     return guard([&] { local_encode_allgather(g, 1, pcm, B_total, T, 0, 0, codes, nullptr); });
+}
+
+nc_status nc_group_dac_encode_allgather_local_dev(nc_group* g, const float* const* pcm, const int32_t* B_local, int64_t T, int32_t sample_rate,
+                                                  int32_t n_q, int64_t* const* codes_all, float* const* z_local, float* const* latents_local) {
+    return guard([&] { local_encode_allgather_dev(g, 0, pcm, B_local, T, sample_rate, n_q, codes_all, z_local, latents_local); });
+}
+
+nc_status nc_group_snac_encode_allgather_local_dev(nc_group* g, const float* const* pcm, const int32_t* B_local, int64_t T, int64_t* const* codes_all) {
+    return guard([&] { local_encode_allgather_dev(g, 1, pcm, B_local, T, 0, 0, codes_all, nullptr, nullptr); });
 }
 
 }  // extern "C"

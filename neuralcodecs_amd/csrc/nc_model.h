@@ -230,6 +230,8 @@ struct EncodecModel : Codec {
     unsigned* lstm_tmo_host = nullptr;
     unsigned* lstm_tmo_dev = nullptr;
     bool lstm_force_stepwise = false;
+    int64_t lstm_timeouts = 0;                   // timeouts this handle has seen (nc_encodec_lstm_stats)
+    struct LstmTicket* lstm_ticket = nullptr;    // per-device serialisation of persistent LSTM sections across handles (nc_encodec.hip)
     bool lstm_timed_out() const { return lstm_tmo_host && *reinterpret_cast<volatile unsigned*>(lstm_tmo_host) != 0; }
     // segment groups of one call are independent until the overlap-add: the first runs on the handle's stream, the others on side
     // streams (forked / joined with events), so the short tail segment of a clip hides behind the full-length batch

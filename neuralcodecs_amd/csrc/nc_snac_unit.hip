@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void snac_unit_kernel(const UnitArgs p) {
         //      operand into the accumulators (every global read of the tile before its first store), phase B stores.
         const int b = unit / p.n_t, t = unit - b * p.n_t;
         const int col = t * BN + wave * 64 + l31;
-        // uniform 64-bit base of the clip + 32-bit lane offsets (C * T < 2^30: the host checks): one offset register per access instead of
+        // uniform 64-bit base of the clip + 32-bit lane offsets (C * T < 2^30: SnacFusedUnit::usable checks): one offset register per access instead of
         // a 64-bit pointer pair -- with pointer arithmetic per row the tile's ~200 addresses cost the kernel its register budget
         const float* const xr = p.x + (int64_t)b * C * T;
         float* const yr = p.y + (int64_t)b * C * T;
@@ -271,7 +271,10 @@ void SnacFusedUnit::build(int C_, int dil_, const float* w7, const float* b7, co
 bool SnacFusedUnit::usable(const float* x, const float* y, int64_t T, int B) const {
     static const bool off = env_flag("NC_SNAC_NO_FUSE");
     static const int64_t min_cols = env_int("NC_SNAC_FUSE_MIN_COLS", 65536);
-    return ready && !off && (T & 3) == 0 && T >= 256 && (int64_t)B * T >= min_cols && T < ((int64_t)1 << 30) &&
+    // the epilogue addresses a clip's [C][T] block with 32-bit BYTE offsets off a uniform 64-bit base: C * T floats must stay below 2^30
+    // (the bound had been on T alone -- a 254 s clip at C = 96 wrapped); longer clips take the two-launch path
+    static const int64_t max_elems = std::min<int64_t>(env_int("NC_SNAC_FUSE_MAX_ELEMS", 1 << 30), (int64_t)1 << 30);
+    return ready && !off && (T & 3) == 0 && T >= 256 && (int64_t)B * T >= min_cols && (int64_t)C * T < max_elems &&
            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
 }
 

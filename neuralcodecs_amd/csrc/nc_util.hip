@@ -34,7 +34,7 @@ const EnvRow kEnv[] = {
     {"NC_NO_SUBPIXEL", 'b', "per-phase launches for power-of-two strided transposed convolutions"},
     {"NC_NO_SUBPIXEL_ANY", 'b', "per-phase launches for the other strides (3, 5)"},
     {"NC_NO_CONV1X1", 'b', "pointwise layers through the windowed template"},
-    {"NC_PW_STREAM", 'b', "streaming pointwise variant for the narrow long rows (not the default since round 4)"},
+    {"NC_PW_STREAM", 'b', "EXPERIMENTS=1 builds: streaming pointwise variant for the narrow long rows (overtaken in round 4)"},
     {"NC_NO_SKINNY", 'b', "no skinny projection kernel (Cout <= 16)"},
     {"NC_NO_THIN", 'b', "PCM heads through the matrix-core template"},
     {"NC_THIN_NO_VEC", 'p', "scalar window loads in the thin-output kernel"},
@@ -52,7 +52,7 @@ const EnvRow kEnv[] = {
     {"NC_SMALL_TN", 'i', "force the short-row column tiles (1 | 2 | 4)"},
     {"NC_SMALL_ROLLED", 'b', "rolled short-row loop"},
     {"NC_DAC_RVQ_STAGEWISE", 'p', "DAC quantizer stage by stage"},
-    {"NC_RVQ_8WAVES", 'b', "8-wavefront Euclidean RVQ workgroups"},
+    {"NC_RVQ_8WAVES", 'b', "EXPERIMENTS=1 builds: 8-wavefront Euclidean RVQ workgroups (measured equal)"},
     {"NC_EUCLID_NO_MFMA", 'p', "vector Euclidean codebook search"},
     {"NC_ENCODEC_NO_FUSE", 'b', "padded / activated copies instead of the fused SConv1d input mode"},
     {"NC_ENCODEC_NO_OVERLAP", 'b', "segment groups one after the other"},
@@ -61,17 +61,18 @@ const EnvRow kEnv[] = {
     {"NC_NO_IN2", 'b', "summed copies instead of the two-input staging mode"},
     {"NC_NO_CONV3S", 'b', "windowed k = 3 instead of the streaming kernel"},
     {"NC_SYNC_ACQUIRE", 'b', "agent-scope acquire fence behind the persistent LSTM's flag poll and in front of the in-launch GroupNorm finish"},
-    {"NC_LSTM_SPLIT", 'b', "per-layer persistent LSTM with load-only / store-only wave roles and value-validated exchange regions (lstm1_kernel; measured slower)"},
+    {"NC_LSTM_SPLIT", 'b', "EXPERIMENTS=1 builds: per-layer persistent LSTM with load-only / store-only wave roles and value-validated exchange regions (lstm1_kernel; measured slower)"},
     {"NC_LSTM_STEPWISE", 'b', "one LSTM launch per step"},
     {"NC_LSTM_CHUNKS", 'i', "layer-pipeline chunks of the per-layer persistent LSTM (4; 1 = layers in sequence)"},
     {"NC_LSTM_EVEN_CHUNKS", 'b', "equal LSTM chunks"},
     {"NC_LSTM_UB", 'i', "hidden-unit blocks per LSTM workgroup (2 | 4)"},
     {"NC_LSTM_NO_ELU", 'b', "the consumer applies the ELU behind an SLSTM"},
-    {"NC_LSTM_FUSED", 'b', "fused two-layer persistent LSTM (nc_lstm.hip)"},
-    {"NC_LSTM2_TRACE", 's', "file for the in-kernel stamps of the fused LSTM (tools/probe/lstm2_trace.py)"},
+    {"NC_LSTM_FUSED", 'b', "EXPERIMENTS=1 builds: fused two-layer persistent LSTM (nc_lstm.hip; measured slower)"},
+    {"NC_LSTM2_TRACE", 's', "EXPERIMENTS=1 builds: file for the in-kernel stamps of the fused LSTM (tools/probe/lstm2_trace.py)"},
     {"NC_LSTM_FAKE_TIMEOUT", 'b', "tests: report the first persistent LSTM launch as timed out"},
     {"NC_SNAC_NO_FUSE", 'b', "SNAC residual units in two launches (depthwise, pointwise)"},
     {"NC_SNAC_FUSE_MIN_COLS", 'i', "columns (clips x steps) from which the one-launch SNAC residual unit is taken (65536)"},
+    {"NC_SNAC_FUSE_MAX_ELEMS", 'i', "channels x steps of ONE clip up to which the one-launch SNAC residual unit is taken (2^30: its 32-bit lane offsets; tests lower it)"},
     {"NC_SNAC_UNIT_TRACE", 's', "file for the in-kernel stamps of the first one-launch SNAC residual unit at C = 96"},
     {"NC_DW_NO_VEC", 'b', "scalar depthwise kernel"},
     {"NC_LN_TILE", 'i', "LayerNorm tile width (8 | 16; 0 = one thread per column)"},

@@ -105,7 +105,7 @@ class DAC(_lib.ProfileMixin):
 
     def _bind_torch_stream(self):
         import torch
-        _lib.check(_lib.lib().nc_codec_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        _lib.check(_lib.lib().nc_codec_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device_index).cuda_stream)))   # (the handle's OWN device: one process may drive several)
 
     def synchronize(self) -> None:
         _lib.check(_lib.lib().nc_codec_synchronize(self._h))
@@ -128,10 +128,9 @@ class DAC(_lib.ProfileMixin):
             self._bind_torch_stream()
             _lib.check(_lib.lib().nc_dac_encode_dev(self._h, x.data_ptr(), B, T, sr, nq, codes.data_ptr(), z.data_ptr(),
                                                     lat.data_ptr()))
-            zeros = self.__dict__.setdefault("_zero_losses", {})      # commitment / codebook loss: 0 in eval mode; allocated once per device
-            if x.device not in zeros:
-                zeros[x.device] = (torch.zeros((), device=x.device), torch.zeros((), device=x.device))
-            return (z, codes, lat) + zeros[x.device]
+            # commitment / codebook loss: 0 in eval mode (ResidualVectorQuantizer.cs:143-156).  Fresh, distinct tensors on every call, as
+            # in the reference: a caller may accumulate into them in place (two scalar fills; a cached pair would be shared state)
+            return z, codes, lat, torch.zeros((), device=x.device), torch.zeros((), device=x.device)
         x = np.ascontiguousarray(audio_data, dtype=np.float32)
         codes = np.empty((B, nq, Tz), np.int64)
         z = np.empty((B, self.latent_dim, Tz), np.float32)

@@ -46,6 +46,7 @@ class Encodec(_lib.ProfileMixin):
         if config.bandwidth is None or config.bandwidth not in tuple(config.target_bandwidths):
             raise ValueError(f"Invalid bandwidth {config.bandwidth}. Select one of {list(config.target_bandwidths)}")   # Encodec.cs:49-54
         self.config = config
+        self.device_index = device_index
         hop = config.hop_length
         self.frame_rate = int(math.ceil(config.sampling_rate / float(hop)))                                # Encodec.cs:83
         self.bits_per_codebook = int(math.log2(config.codebook_size))
@@ -119,9 +120,16 @@ class Encodec(_lib.ProfileMixin):
         _lib.check(_lib.lib().nc_encodec_query(self._h, T, C.byref(nf), C.byref(nq), lens, nf.value, C.byref(dl)))
         return nf.value, nq.value, [lens[i] for i in range(nf.value)], dl.value
 
+    def lstm_stats(self):
+        """(stepwise, timeouts): whether the handle has dropped to the step-wise LSTM kernels and how many persistent-launch timeouts it has
+        seen (nc_encodec_lstm_stats)."""
+        sw, tmo = C.c_int32(0), C.c_int64(0)
+        _lib.check(_lib.lib().nc_encodec_lstm_stats(self._h, C.byref(sw), C.byref(tmo)))
+        return bool(sw.value), int(tmo.value)
+
     def _bind_torch_stream(self):
         import torch
-        _lib.check(_lib.lib().nc_codec_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        _lib.check(_lib.lib().nc_codec_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device_index).cuda_stream)))   # (the handle's OWN device: one process may drive several)
 
     # ---- Encode ----------------------------------------------------------------------------
     def _validate(self, x):

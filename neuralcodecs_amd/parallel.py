@@ -32,7 +32,9 @@ def _pack_rows(codes, bits: int):
     if not codes.is_cuda:
         raise ValueError("bit-packed all-gather payloads are packed by device kernels: the codes must live on the GPU")
     b = int(codes.shape[0])
-    per = int(codes[0].numel()) if b else 0
+    per = 1                                    # values per clip from the SHAPE: a rank without clips (ragged shards, world > n_clips)
+    for d in codes.shape[1:]:                  # must still size its packed rows like every other rank, or the collective's byte
+        per *= int(d)                          # counts differ across ranks
     L = _lib.lib()
     nb = int(L.nc_packed_bytes(per, bits))
     out = torch.empty((b, nb), dtype=torch.uint8, device=codes.device)
@@ -203,6 +205,60 @@ class Group:
     def wait(self):
         from . import _lib
         _lib.check(_lib.lib().nc_group_wait(self._g))
+
+    # ---- local mode, device-resident blocks: torch CUDA tensors (one per device), asynchronous ------------------------------------------
+    def _local_ptr_arrays(self, pcm_blocks):
+        import ctypes as C
+        import torch
+        if self.rank_id >= 0 or len(pcm_blocks) != self.world:
+            raise ValueError("local-mode group: one block of clips per device")
+        xs = [None if x is None else x.contiguous().to(torch.float32) for x in pcm_blocks]
+        for d, (x, m) in enumerate(zip(xs, self._codecs)):
+            if x is not None and (not x.is_cuda or (x.device.index or 0) != m.device_index):
+                raise ValueError(f"block {d} must live on device {m.device_index}")
+        nb = (C.c_int32 * self.world)(*[0 if x is None else int(x.shape[0]) for x in xs])
+        ptrs = (C.c_void_p * self.world)(*[None if x is None or x.shape[0] == 0 else x.data_ptr() for x in xs])
+        T = next(int(x.shape[-1]) for x in xs if x is not None and x.shape[0] > 0)
+        return xs, nb, ptrs, T, max(nb)
+
+    def dac_encode_allgather_local(self, pcm_blocks, n_quantizers: int = 0, codes_all=None):
+        """pcm_blocks[d]: [B_d,1,T] on device d (None / empty for a device without clips).  Returns (z[d], codes_all[d], latents[d]) lists:
+        codes_all[d] = device d's copy of the gathered [ndev*B_max, n_q, T'] tensor (valid on the codec's stream after wait())."""
+        import ctypes as C
+        import torch
+        from . import _lib
+        xs, nb, ptrs, T, bmax = self._local_ptr_arrays(pcm_blocks)
+        m0 = self._codecs[0]
+        Tz = m0.frames(T)
+        nq = n_quantizers if 0 < n_quantizers <= m0.config.n_codebooks else m0.config.n_codebooks
+        devs = [torch.device("cuda", m.device_index) for m in self._codecs]
+        if codes_all is None:
+            codes_all = [torch.empty((self.world * bmax, nq, Tz), dtype=torch.int64, device=dv) for dv in devs]
+        z = [torch.empty((nb[d], m0.latent_dim, Tz), dtype=torch.float32, device=devs[d]) for d in range(self.world)]
+        lat = [torch.empty((nb[d], nq * m0.config.codebook_dim, Tz), dtype=torch.float32, device=devs[d]) for d in range(self.world)]
+        arr = lambda ts: (C.c_void_p * self.world)(*[t.data_ptr() if t.numel() else None for t in ts])
+        for m in self._codecs:
+            m._bind_torch_stream()
+        _lib.check(_lib.lib().nc_group_dac_encode_allgather_local_dev(self._g, ptrs, nb, T, m0.config.sample_rate, n_quantizers,
+                                                                      (C.c_void_p * self.world)(*[t.data_ptr() for t in codes_all]), arr(z), arr(lat)))
+        self._keep = (xs,)                      # (the blocks handed to the asynchronous call stay referenced until the next call)
+        return z, codes_all, lat
+
+    def snac_encode_allgather_local(self, pcm_blocks, codes_all=None):
+        """SNAC form: codes_all[d] [ndev*B_max, sum(level widths)] on every device; returns (codes_all, widths)."""
+        import ctypes as C
+        import torch
+        from . import _lib
+        xs, nb, ptrs, T, bmax = self._local_ptr_arrays(pcm_blocks)
+        m0 = self._codecs[0]
+        widths = m0.query(T)[2]
+        if codes_all is None:
+            codes_all = [torch.empty((self.world * bmax, sum(widths)), dtype=torch.int64, device=torch.device("cuda", m.device_index)) for m in self._codecs]
+        for m in self._codecs:
+            m._bind_torch_stream()
+        _lib.check(_lib.lib().nc_group_snac_encode_allgather_local_dev(self._g, ptrs, nb, T, (C.c_void_p * self.world)(*[t.data_ptr() for t in codes_all])))
+        self._keep = (xs,)
+        return codes_all, widths
 
     # ---- local mode: numpy in / numpy out, synchronous ----------------------------------------------------------------------------
     def dac_encode_allgather_host(self, pcm, n_quantizers: int = 0, return_z: bool = False):

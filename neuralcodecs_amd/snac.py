@@ -37,6 +37,7 @@ class SNAC(_lib.ProfileMixin):
         if config is None:
             raise ValueError("config must not be null")
         self.config = config
+        self.device_index = device_index
         c = _lib.NcSnacConfig()
         c.sample_rate, c.encoder_dim, c.decoder_dim = config.sampling_rate, config.encoder_dim, config.decoder_dim
         c.n_encoder_rates, c.n_decoder_rates, c.n_vq_strides = len(config.encoder_rates), len(config.decoder_rates), len(config.vq_strides)
@@ -113,7 +114,7 @@ class SNAC(_lib.ProfileMixin):
 
     def _bind_torch_stream(self):
         import torch
-        _lib.check(_lib.lib().nc_codec_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        _lib.check(_lib.lib().nc_codec_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device_index).cuda_stream)))   # (the handle's OWN device: one process may drive several)
 
     def synchronize(self) -> None:
         _lib.check(_lib.lib().nc_codec_synchronize(self._h))

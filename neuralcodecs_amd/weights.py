@@ -412,3 +412,19 @@ def synthetic_pcm(batch: int, channels: int, length: int, sample_rate: int, seed
                 + 0.08 * _parabolic_sine(n * (f0 * 7 + 3) + sample_rate // 3, sample_rate)
             out[b, c] = np.clip(nz + tone, -1.0, 1.0).astype(np.float32)
     return out
+
+
+def tie_codebooks(sd, dead_every: int = 7):
+    """Adversarial quantizer weights (in place; returns sd): every codebook's upper half DUPLICATES its lower half row for row, so the two
+    best distances of EVERY frame are an exact tie, and every `dead_every`-th row of the lower half is pushed far away (a dead code: never
+    the nearest).  The reference's argmin (ATen: DAC/VectorQuantizer.cs:121, SNAC/VectorQuantizer.cs:137, EuclideanCodebook.cs:181) returns
+    the FIRST index of a tie -- all emitted codes must lie in the lower half and avoid the dead rows."""
+    for k in list(sd):
+        if k.endswith(".codebook.weight") or k.endswith(".codebook.embed"):
+            w = np.array(sd[k], dtype=np.float32, copy=True)
+            half = w.shape[0] // 2
+            if dead_every > 0:
+                w[0:half:dead_every] += np.float32(64.0)
+            w[half:2 * half] = w[:half]
+            sd[k] = w
+    return sd

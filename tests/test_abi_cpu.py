@@ -165,3 +165,21 @@ def test_every_diagnostic_switch_is_in_the_one_table_and_documented():
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     missing = sorted(n for n in names if n not in design)
     assert not missing, f"DESIGN.md 10 does not mention {missing}"
+
+
+def test_gpu_side_c_consumer_compiles_and_fails_loudly_without_a_device(tmp_path):
+    """tests/abi_consumer.c (the C99 program the GPU suite runs through encode + decode) builds against the header with -Werror; on a host
+    without a device it stops at nc_device_count with exit code 3 -- no silent host computation."""
+    import subprocess
+    import struct
+    exe = tmp_path / "abi_consumer"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi_consumer.c"),
+                           "-o", str(exe), "-L", libdir, "-l:libnc_mi355x.so", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-lm"])
+    if _lib.lib().nc_device_count() > 0:
+        pytest.skip("GPU present: tests/test_dac_gpu.py runs the program")
+    import ctypes as C
+    (tmp_path / "config.bin").write_bytes(b"\0" * C.sizeof(_lib.NcDacConfig))
+    (tmp_path / "pcm.f32").write_bytes(struct.pack("<4f", 0, 0, 0, 0))
+    r = subprocess.run([str(exe), str(tmp_path / "config.bin"), "none", str(tmp_path / "pcm.f32"), "1", "4", "none", "none"], capture_output=True, text=True)
+    assert r.returncode == 3 and "no gfx950 device" in r.stderr, (r.returncode, r.stderr)

@@ -128,3 +128,22 @@ def test_encodec_errors_ragged_and_device_api():
     assert all(np.array_equal(a.codes.cpu().numpy(), b.codes) for a, b in zip(dframes, frames))
     assert np.array_equal(da.cpu().numpy(), m.decode(frames, 5000))
     m.dispose()
+
+
+@pytest.mark.parametrize("preset,bw", [("encodec_48khz", 12.0), ("encodec_24khz", 24.0)])
+def test_encodec_tied_codebooks_first_index_full_width(preset, bw):
+    """Both presets (Config/Encodec/EncodecConfig.cs) at full width with adversarial codebooks: every embedding row twice (an exact tie in every
+    frame of every stage; the matrix-core distance kernel scans 1024 codes per frame) and dead codes.  EuclideanCodebook.Quantize's argmin
+    (EuclideanCodebook.cs:181, ATen) returns the first index: codes in the lower half only, engine == C oracle bit for bit.  24 kHz at
+    24 kbps runs all 32 stages."""
+    from neuralcodecs_amd.config import EncodecConfig
+    from neuralcodecs_amd.weights import tie_codebooks
+    import dataclasses
+    cfg = dataclasses.replace(getattr(EncodecConfig, preset)(), bandwidth=bw)
+    blob = save_blob(tie_codebooks(encodec_synthetic_state_dict(cfg, seed=42)))
+    pcm = synthetic_pcm(2, cfg.channels, 2 * cfg.sampling_rate, cfg.sampling_rate, seed=19)
+    with Encodec(cfg) as m:
+        m.load_blob(blob)
+        frames, _, _ = _check_vs_oracle(m, c_oracle.RefEncodec(cfg, blob), pcm)
+    for f in frames:
+        assert f.codes.max() < cfg.codebook_size // 2 and not np.any(f.codes % 7 == 0), "a tie was not resolved to the first index"

@@ -119,3 +119,18 @@ def test_bit_packed_all_gather_payload_equals_the_plain_one():
     finally:
         dist.destroy_process_group()
     m.dispose()
+
+
+def test_packed_rows_of_a_rank_without_clips_keep_the_row_width():
+    """parallel._pack_rows sized its packed rows from codes[0] -- a rank holding NO clips (ragged shards, world > n_clips) packed
+    [0, 0] while the others packed [b, nb], and the padded all_gather_into_tensor sizes then differed across ranks.  The row width must come
+    from the tensor's shape alone."""
+    import torch
+    from neuralcodecs_amd import _lib
+    empty = torch.empty((0, 9, 87), dtype=torch.int64, device="cuda")
+    some = torch.randint(0, 1024, (3, 9, 87), dtype=torch.int64, device="cuda")
+    nb = int(_lib.lib().nc_packed_bytes(9 * 87, 10))
+    assert tuple(parallel._pack_rows(empty, 10).shape) == (0, nb)
+    packed = parallel._pack_rows(some, 10)
+    assert tuple(packed.shape) == (3, nb)
+    assert torch.equal(parallel._unpack_rows(packed, (9, 87), 10), some)

@@ -70,3 +70,24 @@ def test_two_rank_gather_equals_single_process(tmp_path, n_clips):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, n_clips, str(tmp_path)), nprocs=2, join=True)
     assert np.load(tmp_path / "ok.npy")[0] == 1
+
+
+def test_bench_gpus2_without_devices_fails_fast_with_a_clear_message():
+    """`python bench.py --gpus 2` with no WORLD_SIZE is its own launcher (bench.self_launch).  On a host with fewer than two GPUs it must
+    say so and exit non-zero -- before starting any rank, without a rendezvous to hang in."""
+    import subprocess
+    import sys
+    import time
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("this host could really run two ranks")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "NC_BENCH_CHILD")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-1000:])
+    assert "GPU(s)" in r.stderr and "nothing was started" in r.stderr
+    assert r.stdout.strip() == ""
+    assert time.time() - t0 < 240

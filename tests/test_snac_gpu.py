@@ -211,3 +211,27 @@ def test_snac_encode_tensor_overload_as_written():
     assert audit_snac_levels([c[:1] for c in codes], g, GAP_TOL) == 0
     assert np.abs(zq[:1, ::16, :] - g["zq_slice"]).max() < LATENT_TOL
     m.dispose()
+
+
+@pytest.mark.parametrize("preset,seconds", [("snac_44khz", 1), ("snac_32khz", 1), ("snac_24khz", 1)])
+def test_snac_tied_codebooks_first_index_and_other_presets_full_width(preset, seconds):
+    """Every preset the reference ships (Config/SNAC/SNACConfig.cs: 24 / 32 / 44.1 kHz) at full width with ADVERSARIAL codebooks: every row
+    of the 4096-entry codebooks twice (an exact tie in every frame of every level) and dead codes (neuralcodecs_amd.weights.tie_codebooks).
+    ATen's argmin (SNAC/VectorQuantizer.cs:137) returns the first index of a tie: all codes in the lower half, none on a dead row, and the
+    engine equal to the C oracle bit for bit (whose tie rule tests/test_oracle_snac_cpu.py holds to the ATen restatement)."""
+    from neuralcodecs_amd.config import SNACConfig
+    from neuralcodecs_amd.weights import tie_codebooks
+    cfg = getattr(SNACConfig, preset)()
+    blob = save_blob(tie_codebooks(snac_synthetic_state_dict(cfg, seed=42)))
+    pcm = synthetic_pcm(2, 1, seconds * cfg.sampling_rate, cfg.sampling_rate, seed=31)
+    ref = c_oracle.RefSNAC(cfg, blob)
+    with SNAC(cfg) as m:
+        m.load_blob(blob)
+        codes = m.encode(pcm)
+        nz = snac_noise(cfg, 2, codes[-1].shape[1], seed=8)
+        audio = m.decode(codes, nz)
+    _, _, rcodes = ref.encode(pcm)
+    for a, b in zip(codes, rcodes):
+        assert np.array_equal(a, b)
+        assert a.max() < cfg.codebook_size // 2 and not np.any(a % 7 == 0), "a tie was not resolved to the first index"
+    assert np.array_equal(audio, ref.decode(rcodes, nz))

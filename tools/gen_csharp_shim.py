@@ -93,6 +93,8 @@ def cs_param(cty, name):
     m = re.match(r"(\w+)\s*\*\s*const\s*\*$", cty.replace("const nc_", "nc_", 1)) or re.match(r"(\w+)\s*\*\s*const\s*\*$", t)
     if m and m.group(1) in OPAQUE:
         return "IntPtr[]"
+    if re.match(r"(\w+)\s*\*\s*const\s*\*$", t) and re.match(r"(\w+)", t).group(1) in SCALARS:
+        return "IntPtr[]"           # an array of per-device DEVICE pointers (local-mode groups): opaque addresses on the managed side
     if t.endswith("**"):
         base = t[:-2].strip()
         if base in OPAQUE:

@@ -23,7 +23,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from conftest import load_golden, dac_cfg_from_meta, encodec_cfg_from_meta, snac_cfg_from_meta  # noqa: E402
+from functools import partial  # noqa: E402
 from neuralcodecs_amd import DAC, SNAC, Encodec  # noqa: E402
+from neuralcodecs_amd.config import DACConfig, EncodecConfig, SNACConfig  # noqa: E402
 from neuralcodecs_amd.weights import (dac_synthetic_state_dict, encodec_synthetic_state_dict, save_blob, snac_noise,  # noqa: E402
                                       snac_synthetic_state_dict, synthetic_pcm)
 from oracle import c_oracle  # noqa: E402
@@ -40,8 +42,8 @@ def _maxabs(a, b):
     return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) if a.size else 0.0
 
 
-def sweep_dac(wseeds, pseeds, clips):
-    cfg = dac_cfg_from_meta(load_golden("dac44k_b1")["meta"])
+def sweep_dac(wseeds, pseeds, clips, preset=None):
+    cfg = getattr(DACConfig, preset)() if preset else dac_cfg_from_meta(load_golden("dac44k_b1")["meta"])
     rows = []
     for ws in wseeds:
         blob = save_blob(dac_synthetic_state_dict(cfg, seed=ws))
@@ -60,8 +62,8 @@ def sweep_dac(wseeds, pseeds, clips):
     return rows
 
 
-def sweep_encodec(wseeds, pseeds, clips):
-    cfg = encodec_cfg_from_meta(load_golden("encodec48k_b1")["meta"])
+def sweep_encodec(wseeds, pseeds, clips, preset=None):
+    cfg = getattr(EncodecConfig, preset)() if preset else encodec_cfg_from_meta(load_golden("encodec48k_b1")["meta"])
     T = 2 * cfg.sampling_rate
     rows = []
     for ws in wseeds:
@@ -69,7 +71,7 @@ def sweep_encodec(wseeds, pseeds, clips):
         m = Encodec(cfg); m.load_blob(blob)
         ref = c_oracle.RefEncodec(cfg, blob)
         for ps in pseeds:
-            pcm = synthetic_pcm(clips, 2, T, cfg.sampling_rate, seed=ps)
+            pcm = synthetic_pcm(clips, cfg.channels, T, cfg.sampling_rate, seed=ps)
             frames = m.encode(pcm)
             audio = m.decode(frames, T)
             rfr = ref.encode(pcm)
@@ -82,9 +84,9 @@ def sweep_encodec(wseeds, pseeds, clips):
     return rows
 
 
-def sweep_snac(wseeds, pseeds, clips):
-    cfg = snac_cfg_from_meta(load_golden("snac44k_short")["meta"])
-    T = 5 * cfg.sampling_rate
+def sweep_snac(wseeds, pseeds, clips, preset=None, seconds=5):
+    cfg = getattr(SNACConfig, preset)() if preset else snac_cfg_from_meta(load_golden("snac44k_short")["meta"])
+    T = seconds * cfg.sampling_rate
     rows = []
     for ws in wseeds:
         blob = save_blob(snac_synthetic_state_dict(cfg, seed=ws))
@@ -112,11 +114,19 @@ def main():
     ap.add_argument("--dac-clips", type=int, default=8)
     ap.add_argument("--encodec-clips", type=int, default=4)
     ap.add_argument("--snac-clips", type=int, default=2)
+    ap.add_argument("--presets", action="store_true", help="also every other preset the reference ships, at full width (round 5)")
+    ap.add_argument("--preset-clips", type=int, default=4)
     a = ap.parse_args()
     ws = [int(v) for v in a.weight_seeds.split(",")]
     ps = [int(v) for v in a.pcm_seeds.split(",")]
     out = {"what": "HIP engine (C ABI) vs C oracle, every clip of every (weight seed, clip seed) combination; mismatches and max-abs must be 0"}
-    for name, fn, n in (("dac44k_1s", sweep_dac, a.dac_clips), ("encodec48k_2s", sweep_encodec, a.encodec_clips), ("snac44k_5s", sweep_snac, a.snac_clips)):
+    plan = [("dac44k_1s", sweep_dac, a.dac_clips), ("encodec48k_2s", sweep_encodec, a.encodec_clips), ("snac44k_5s", sweep_snac, a.snac_clips)]
+    if a.presets:   # Config/DAC/DACConfig.cs:103-135, Config/SNAC/SNACConfig.cs, Config/Encodec/EncodecConfig.cs
+        n = a.preset_clips
+        plan += [("dac44k_16kbps_1s", partial(sweep_dac, preset="dac_44khz_16kbps"), n), ("dac24k_1s", partial(sweep_dac, preset="dac_24khz"), n),
+                 ("dac16k_1s", partial(sweep_dac, preset="dac_16khz"), n), ("snac32k_2s", partial(sweep_snac, preset="snac_32khz", seconds=2), n),
+                 ("snac24k_2s", partial(sweep_snac, preset="snac_24khz", seconds=2), n), ("encodec24k_2s", partial(sweep_encodec, preset="encodec_24khz"), n)]
+    for name, fn, n in plan:
         t0 = time.time()
         rows = fn(ws, ps, n)
         tot = {"clips": sum(r["clips"] for r in rows), "codes": sum(r["codes"] for r in rows),

@@ -37,15 +37,20 @@ def top2_gap(dists):
     return np.stack(g, 0)  # [nq, B*T']
 
 
-def dac_case(name, cfg_kw, B, T, wseed, pseed, full):
+def dac_case(name, cfg_kw, B, T, wseed, pseed, full, ties=False):
     cfg = DACConfig(**cfg_kw)
     sd = dac_synthetic_state_dict(cfg, seed=wseed)
+    if ties:            # duplicated codebook rows + dead codes: exact ties in every frame (neuralcodecs_amd.weights.tie_codebooks)
+        from neuralcodecs_amd.weights import tie_codebooks
+        tie_codebooks(sd)
     m = TorchDAC(cfg, sd)
     pcm = synthetic_pcm(B, 1, T, cfg.sample_rate, seed=pseed)
     zq, codes, lat, dists = m.encode(pcm, want_dist=True)
     audio = m.decode(zq)
     z_from = m.from_codes(codes)
     meta = dict(cfg=cfg_kw, B=B, T=T, weight_seed=wseed, pcm_seed=pseed)
+    if ties:
+        meta["ties"] = True
     out = dict(meta=json.dumps(meta), codes=codes.numpy().astype(np.int16), gap=top2_gap(dists).astype(np.float32))
     if full:
         out.update(zq_slice=zq.numpy()[:, ::16, :], audio_slice=audio.numpy()[:, :, ::29],
@@ -122,6 +127,12 @@ if __name__ == "__main__":
         # SNAC.Encode(Tensor) as written (D7): 24 kHz model on an un-padded, non-multiple length (22628 samples -> 44 frames, not 48)
         snac_case("snac24k_tensor_b1", dict(), 1, 22628, 42, 1234, 77, True, tensor_overload=True)
         snac_case("snac_small_tensor", SNAC_SMALL, 2, 3100, 5, 3, 99, False, tensor_overload=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "--round5":   # fixtures added in round 5 (the older files stay byte-identical)
+        # full-size DAC 24 kHz (Config/DAC/DACConfig.cs:115-124: 32 codebooks, rates 2-4-5-8 -- stride 5 at full width), one 1 s clip
+        dac_case("dac24k_b1", dict(sample_rate=24000, n_codebooks=32, encoder_rates=(2, 4, 5, 8), decoder_rates=(8, 5, 4, 2)), 1, 24000, 42, 1234, True)
+        # adversarial quantizer at full size: duplicated codebook rows (an exact tie in EVERY frame) and dead codes -> ATen's first index
+        dac_case("dac44k_ties_b1", dict(), 1, 44100, 42, 1234, True, ties=True)
         sys.exit(0)
     # reduced width, ragged length (not a hop multiple), odd stride 5 (DAC-16/24 kHz presets use it)
     dac_case("dac_small", SMALL, 2, 2000, 7, 11, False)

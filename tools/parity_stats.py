@@ -8,7 +8,7 @@ the flipped frames (a flip must be a near-tie of the ATen argmin to be explainab
 latents and of the decoded PCM, and the SHA-256 of the C oracle's code tensor (tests/test_parity_stats_cpu.py recomputes a subset of
 these hashes, so the record cannot drift from the oracle).  Only counts and hashes are stored, no tensors.
 
-    python tools/parity_stats.py [--codec dac|encodec|snac|all] [--dac-clips 32] [--encodec-clips 16] [--snac-clips 8] [--out tests/golden/parity_stats.json]
+    python tools/parity_stats.py [--codec dac|encodec|snac|presets|all] [--dac-clips 32] [--encodec-clips 16] [--snac-clips 8] [--out tests/golden/parity_stats.json]
 """
 import argparse
 import hashlib
@@ -39,18 +39,18 @@ def frames_flipped(codes, ref):
     return int(bad.sum()), first
 
 
-def dac_clip(wseed, pseed, cache):
+def dac_clip(wseed, pseed, cache, preset="dac_44khz"):
     import torch
     from neuralcodecs_amd.config import DACConfig
     from neuralcodecs_amd.weights import dac_synthetic_state_dict, save_blob, synthetic_pcm
     from oracle import c_oracle
     from oracle.torch_ref.dac import TorchDAC
-    cfg = DACConfig.dac_44khz()
-    if ("dac", wseed) not in cache:
+    cfg = getattr(DACConfig, preset)()          # every preset the reference ships: Config/DAC/DACConfig.cs:103-135
+    if (preset, wseed) not in cache:
         sd = dac_synthetic_state_dict(cfg, seed=wseed)
         cache.clear()
-        cache[("dac", wseed)] = (TorchDAC(cfg, sd), c_oracle.RefDAC(cfg, save_blob(sd)))
-    tm, ref = cache[("dac", wseed)]
+        cache[(preset, wseed)] = (TorchDAC(cfg, sd), c_oracle.RefDAC(cfg, save_blob(sd)))
+    tm, ref = cache[(preset, wseed)]
     pcm = synthetic_pcm(1, 1, cfg.sample_rate, cfg.sample_rate, seed=pseed)
     zq, codes, lat, dists = tm.encode(pcm, want_dist=True)
     audio = tm.decode(zq)
@@ -70,18 +70,18 @@ def dac_clip(wseed, pseed, cache):
     return e
 
 
-def encodec_clip(wseed, pseed, cache):
+def encodec_clip(wseed, pseed, cache, preset="encodec_48khz"):
     import torch
     from neuralcodecs_amd.config import EncodecConfig
     from neuralcodecs_amd.weights import encodec_synthetic_state_dict, save_blob, synthetic_pcm
     from oracle import c_oracle
     from oracle.torch_ref.encodec import TorchEncodec
-    cfg = EncodecConfig.encodec_48khz()
-    if ("enc", wseed) not in cache:
+    cfg = getattr(EncodecConfig, preset)()      # Config/Encodec/EncodecConfig.cs:9-64
+    if (preset, wseed) not in cache:
         sd = encodec_synthetic_state_dict(cfg, seed=wseed)
         cache.clear()
-        cache[("enc", wseed)] = (TorchEncodec(cfg, sd), c_oracle.RefEncodec(cfg, save_blob(sd)))
-    tm, ref = cache[("enc", wseed)]
+        cache[(preset, wseed)] = (TorchEncodec(cfg, sd), c_oracle.RefEncodec(cfg, save_blob(sd)))
+    tm, ref = cache[(preset, wseed)]
     pcm = synthetic_pcm(1, cfg.channels, 2 * cfg.sampling_rate, cfg.sampling_rate, seed=pseed)
     frames = tm.encode(pcm, want_dist=True)
     audio = tm.decode(frames)
@@ -107,18 +107,18 @@ def encodec_clip(wseed, pseed, cache):
     return e
 
 
-def snac_clip(wseed, pseed, cache, seconds=5.0):
+def snac_clip(wseed, pseed, cache, seconds=5.0, preset="snac_44khz"):
     import torch
     from neuralcodecs_amd.config import SNACConfig
     from neuralcodecs_amd.weights import save_blob, snac_noise, snac_synthetic_state_dict, synthetic_pcm
     from oracle import c_oracle
     from oracle.torch_ref.snac import TorchSNAC
-    cfg = SNACConfig.snac_44khz()
-    if ("snac", wseed) not in cache:
+    cfg = getattr(SNACConfig, preset)()         # Config/SNAC/SNACConfig.cs
+    if (preset, wseed) not in cache:
         sd = snac_synthetic_state_dict(cfg, seed=wseed)
         cache.clear()
-        cache[("snac", wseed)] = (TorchSNAC(cfg, sd), c_oracle.RefSNAC(cfg, save_blob(sd)))
-    tm, ref = cache[("snac", wseed)]
+        cache[(preset, wseed)] = (TorchSNAC(cfg, sd), c_oracle.RefSNAC(cfg, save_blob(sd)))
+    tm, ref = cache[(preset, wseed)]
     pcm = synthetic_pcm(1, 1, int(seconds * cfg.sampling_rate), cfg.sampling_rate, seed=pseed)
     z, zq, codes, dists = tm.encode(pcm, want_dist=True)
     noises = snac_noise(cfg, 1, z.shape[-1], seed=pseed + 7)
@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--dac-clips", type=int, default=32)
     ap.add_argument("--encodec-clips", type=int, default=16)
     ap.add_argument("--snac-clips", type=int, default=8)
+    ap.add_argument("--preset-clips", type=int, default=4, help="clips per OTHER preset of the reference (--codec presets | all)")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "parity_stats.json"))
     a = ap.parse_args()
     import torch
@@ -173,6 +174,14 @@ def main():
         plan.append(("encodec48k", encodec_clip, a.encodec_clips))
     if a.codec in ("all", "snac"):
         plan.append(("snac44k", snac_clip, a.snac_clips))
+    if a.codec in ("all", "presets"):
+        # round 5: every other preset the reference ships, at full width -- DAC 44 kHz-16 kbps (18 codebooks, latent 128),
+        # 24 kHz (32 codebooks, stride 5) and 16 kHz (Config/DAC/DACConfig.cs:103-135), SNAC 32 kHz and 24 kHz, Encodec 24 kHz (causal, weight norm)
+        from functools import partial
+        for name, fn in (("dac44k_16kbps", partial(dac_clip, preset="dac_44khz_16kbps")), ("dac24k", partial(dac_clip, preset="dac_24khz")),
+                         ("dac16k", partial(dac_clip, preset="dac_16khz")), ("snac32k", partial(snac_clip, seconds=2.0, preset="snac_32khz")),
+                         ("snac24k", partial(snac_clip, seconds=2.0, preset="snac_24khz")), ("encodec24k", partial(encodec_clip, preset="encodec_24khz"))):
+            plan.append((name, fn, a.preset_clips))
     for name, fn, n in plan:
         clips, cache = [], {}
         for i in range(n):
