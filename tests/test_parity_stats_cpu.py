@@ -45,3 +45,25 @@ def test_one_clip_recomputed_matches_the_record(codec):
     assert got["n_codes"] == want["n_codes"] and got["flipped_frames"] == want["flipped_frames"]
     if "pcm_max_abs" in want:
         assert got["pcm_max_abs"] <= PCM_TOL
+
+
+# round 5: the reference's OTHER presets at full width -- DAC 44 kHz-16 kbps / 24 kHz / 16 kHz (Config/DAC/DACConfig.cs:103-135),
+# SNAC 32 / 24 kHz, Encodec 24 kHz -- four clips each, two weight sets (tools/parity_stats.py --codec presets)
+OTHER_PRESETS = ["dac44k_16kbps", "dac24k", "dac16k", "snac32k", "snac24k", "encodec24k"]
+
+
+@pytest.mark.parametrize("codec", OTHER_PRESETS)
+def test_other_presets_recorded_statistics(codec):
+    s = _rec()[codec]["summary"]
+    assert s["clips"] >= 4 and len(s["weight_seeds"]) >= 2 and s["n_codes"] >= 600
+    assert s["flipped_frames"] <= max(1, 1e-3 * s["n_frames"]) and s["max_flip_gap"] < GAP_TOL
+    assert s["pcm_max_abs"] <= PCM_TOL and s["latents_max_abs"] <= LATENT_TOL
+
+
+@pytest.mark.parametrize("codec", ["dac24k", "dac44k_16kbps"])
+def test_one_clip_of_another_preset_recomputed_matches_the_record(codec):
+    pytest.importorskip("torch")
+    import parity_stats as ps
+    want = _rec()[codec]["clips"][0]
+    got = ps.dac_clip(want["weight_seed"], want["pcm_seed"], {}, preset={"dac24k": "dac_24khz", "dac44k_16kbps": "dac_44khz_16kbps"}[codec])
+    assert got["codes_sha256"] == want["codes_sha256"] and got["n_codes"] == want["n_codes"] and got["flipped_frames"] == want["flipped_frames"]
