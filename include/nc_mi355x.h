@@ -122,7 +122,9 @@ NC_API nc_status nc_dac_encode(nc_codec* h, const float* pcm, int32_t B, int64_t
 NC_API nc_status nc_dac_encode_dev(nc_codec* h, const float* pcm, int32_t B, int64_t T, int32_t sample_rate, int32_t n_q,
                                    int64_t* codes, float* z, float* latents);
 
-/* replaces: DAC.Decode(Tensor z[B,latent,T'])  -> [B,1,T'*hop]   Models/DAC.cs:231-234 (no trim: D6) */
+/* replaces: DAC.Decode(Tensor z[B,latent,T'])  -> [B,1,L]   Models/DAC.cs:231-234 (no trim: D6).  L = T'*hop when every decoder stride is
+ * even (the 44.1 kHz presets); each DecoderBlock maps L -> (L - 1) s - 2 ceil(s / 2) + 2 s (DecoderBlock.cs:20-44), so a stride-5 block
+ * (the 16 / 24 kHz presets, DACConfig.cs:115-135) yields 5 L - 1: a caller sizes `pcm` for T'*hop (= nc_dac_query's T_padded), never less. */
 NC_API nc_status nc_dac_decode(nc_codec* h, const float* z, int32_t B, int64_t frames, float* pcm);
 NC_API nc_status nc_dac_decode_dev(nc_codec* h, const float* z, int32_t B, int64_t frames, float* pcm);
 
@@ -132,7 +134,7 @@ NC_API nc_status nc_dac_from_codes_dev(nc_codec* h, const int64_t* codes, int32_
 
 /* replaces: Dia.Decode(Tensor audioCodes[T, n_q])  Models/Dia.cs:973-981  (FromCodes(codes.unsqueeze(0).transpose(1, 2)) -> Decode) and
  *           AudioUtils.Decode(DAC, codes)           Modules/Dia/AudioUtils.cs:189-199, batched: codes_tq int64 [B, T', n_q] (Dia's layout)
- *           -> pcm [B, 1, T'*hop].  The transpose to DAC's [B, n_q, T'] is a device kernel.
+ *           -> pcm [B, 1, L] (L as for nc_dac_decode).  The transpose to DAC's [B, n_q, T'] is a device kernel.
  * replaces: Dia.Encode(Tensor audio[1, T])          Models/Dia.cs:989-1002 (Encode -> squeeze(0).transpose(0, 1)), batched:
  *           pcm [B, 1, T] -> codes_tq int64 [B, T', n_q] (all codebooks) */
 NC_API nc_status nc_dac_decode_code_matrix(nc_codec* h, const int64_t* codes_tq, int32_t B, int64_t frames, int32_t n_q, float* pcm);

@@ -20,8 +20,9 @@
 namespace nc {
 
 enum : int { EPI_TANH = 1, EPI_RVQ = 2, EPI_NOISE = 4,
-             EPI_NO_XR = 1 << 20 };   // NC_NO_XR=1 (a test switch riding in the epilogue flags: a field of its own shifted the argument block and
-                                      // cost the k = 7 loop 51 scalar-register reloads)
+             EPI_NO_XR = 1 << 20,   // NC_NO_XR=1 (a test switch riding in the epilogue flags: a field of its own shifted the argument block and
+                                    // cost the k = 7 loop 51 scalar-register reloads)
+             EPI_XVEC = 1 << 21 };  // vectorised window staging granted by the host (two-tap sub-pixel instances: the kernel's XV note)
 
 struct ConvArgs {
     // input activations [B][Cin][x_len] (row stride x_cstride); positions outside [0,x_len) read as 0

@@ -822,7 +822,27 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     }
     const int ad = a.dil < 0 ? -a.dil : a.dil;
     a.xneg = a.dil < 0 ? (L.Ktaps - 1) * ad : 0;
-    a.xw = (BN - 1 + (flat ? (flat_S - 1) * flat_hc : 0)) * sx + (L.Ktaps - 1) * ad + 1;
+    int xv_extra = 0;
+    {   // XV (round 5): vectorised window staging of the two-tap sub-pixel instances (the kernel's XV note) -- plain input, rows and window
+        // start on 16-byte boundaries (xneg is raised by up to 3 slots for that: the window still fits its 320-slot pitch), whole float4s
+        static const bool no_xv = env_flag("NC_NO_XV");
+        static const bool no_xr = env_flag("NC_NO_XR");
+        const bool two_tap = L.sub_stride && L.n_phase == 1 && c.K == 2 && c.CB == 16 && !io.alpha_in && !io.fuse_k1;
+#if defined(NC_XV_K7) && NC_XV_K7
+        const bool k7 = !L.transposed && !L.sub_stride && c.K == 7 && c.CB == 8 && L.stride == 1;      // (the fused units included)
+#else
+        const bool k7 = false;
+#endif
+        const int vw = two_tap ? 4 : 2;   // floats per staged word
+        if (!no_xv && !no_xr && (two_tap || k7) && c.TN == 2 && c.NW == 4 && !narrow && !flat && !dist_small_fn && !n_prod && !light && !wide && !dist &&
+            !slim && !in_mode && !io.x2 && sx == 1 && L.Cin % c.CB == 0 && io.x_len % vw == 0 && io.x_cstride % vw == 0 && io.x_bstride % vw == 0 &&
+            (reinterpret_cast<uintptr_t>(io.x) & 15) == 0) {
+            xv_extra = (vw - (a.pad + a.xneg) % vw) % vw;
+            if ((BN - 1) * sx + (L.Ktaps - 1) * ad + 1 + xv_extra <= 320) { a.xneg += xv_extra; a.epi |= EPI_XVEC; }
+            else xv_extra = 0;
+        }
+    }
+    a.xw = (BN - 1 + (flat ? (flat_S - 1) * flat_hc : 0)) * sx + (L.Ktaps - 1) * ad + 1 + xv_extra;
     a.nchunk = (a.xw + 63) / 64;
     a.xwp = (a.nchunk * 64 + sx - 1) / sx;   // rows are padded to whole 64-slot chunks: every staging store is in-bounds
     a.xrow = sx == 1 ? a.nchunk * 64 : sx * a.xwp;

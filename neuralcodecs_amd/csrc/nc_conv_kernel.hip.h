@@ -10,6 +10,13 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef NC_XV_K7
+#define NC_XV_K7 0          // 1: XV staging for the k = 7 instances as well (experiment; the host side reads the same macro)
+#endif
+#ifndef NC_XV_STORE_SEG
+#define NC_XV_STORE_SEG 2   // XV staging: the window words issued at the head of segment 0 are written at the head of this segment
+#endif
+
 namespace nc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -203,6 +210,89 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     // scalar masks -- 2 NX scalar registers, which the two-tap instances (NX = 20) spill and reload with a vector instruction each,
     // inside the loop (found in the ISA, round 4).
     const bool tile_allok = __builtin_amdgcn_ballot_w64(okm != (NX >= 32 ? ~0u : (1u << NX) - 1u)) == 0;
+    // ---- XV (round 5): vectorised window staging of the two-tap (sub-pixel up-convolution) instances.  With the constant row pitch the
+    // window image of a reduction block is one linear array [CB][XROWC] = CB * 80 float4 words: thread t copies words t + NT * n -- FIVE
+    // 16-byte loads and five `ds_write_b128` per thread and block where the item form spends twenty dword loads, twenty `ds_write_b32`
+    // and an address instruction each -- and holds 5 offsets instead of 20.  With so few registers per block the reads can stay in
+    // flight for a WHOLE block (rotating schedule in the main loop) instead of one matrix-core segment: a segment of these 16-step
+    // blocks is 1.3 us of matrix-pipe time, less than a loaded L2 / HBM round trip -- measured on DAC's up-convolutions (same box,
+    // 60 launches per layer): item form = XV written one or two segments after its reads (no gain: 2.33 ms), written three segments
+    // after them -2.7 ... -4.4 % per layer; the latency cover is what these short-reduction classes were missing.  The host
+    // (launch_conv: EPI_XVEC) grants it for plain inputs with 16-byte aligned rows, a window start that is a multiple of 4 samples (xneg
+    // is raised for that) and row lengths that are multiples of 4, so that a float4 is inside the row or outside it as a whole.
+    // K = 7 (NC_XV_K7 builds, experiment): the same for the dilated residual-unit convolutions with 8-byte words -- [8][320] floats = 5
+    // float2 per thread, so the Snake work per thread stays exactly the item form's 10 elements, as packed pairs of one channel.
+    constexpr bool XVCAND = TN == 2 && NW == 4 && !IN2 && !SPEC && !DIST &&
+                            ((K == 2 && SUB != 0 && !FUSE) || (NC_XV_K7 != 0 && K == 7 && SUB == 0));
+    constexpr int XVW = K == 2 ? 4 : 2;                          // floats per staged word
+    constexpr int XVROW = 320;                                   // (== XROWC of the 256-column tiles, defined with the fragment reads below)
+    constexpr int XVN = CB * XVROW / XVW;                        // words of the window image
+    constexpr int NV = XVCAND ? (XVN + NT - 1) / NT : 1;
+    typedef float xv_t __attribute__((ext_vector_type(XVW)));
+    const bool use_xv = XVCAND && (p.epi & EPI_XVEC) != 0;       // wave-uniform (kernel argument)
+    unsigned xvo[NV];                                            // float offset of word n from the first channel row of a reduction block
+    unsigned xvok = 0;                                           // bit n: word n lies inside its row (else zero padding)
+    int xvc[(XVCAND && K == 7) ? NV : 1];                        // K = 7: channel (within the block) of word n, for its Snake operands
+    xv_t rxv[NV];
+    f32x4 rav[XVCAND ? NA : 1];
+    if constexpr (XVCAND) {
+        if (use_xv) {
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const int f = min(tid + NT * n, XVN - 1);
+                const int ch = f / (XVROW / XVW), q = f - ch * (XVROW / XVW);
+                const int gp = xs0 + XVW * q;
+                const bool ok = (gp >= 0) & (gp + XVW - 1 < x_len);
+                xvo[n] = (unsigned)ch * x_cstride + (unsigned)(ok ? gp : 0);
+                if constexpr (K == 7) xvc[n] = ch;
+                if (ok) xvok |= 1u << n;
+            }
+        }
+    }
+    const bool xv_allok = __builtin_amdgcn_ballot_w64(xvok != (1u << NV) - 1u) == 0;
+    auto xv_issue = [&](int cbn) __attribute__((always_inline)) {
+        if constexpr (XVCAND) {
+            const float* base = xb + (size_t)((unsigned)(cbn * CB) * x_cstride);   // uniform
+#pragma unroll
+            for (int n = 0; n < NV; ++n) rxv[n] = *reinterpret_cast<const xv_t*>(base + xvo[n]);
+            const f32x4* src = wbase + (size_t)cbn * A_VEC;
+#pragma unroll
+            for (int n = 0; n < NA; ++n) rav[n] = (src + SNT * n)[(A_VEC % SNT == 0) ? (unsigned)stid : min((unsigned)stid, (unsigned)(A_VEC - 1 - SNT * n))];
+        }
+    };
+    auto xv_store = [&](int cbn, float* Ad, float* Xd, auto allok_tag, auto snake_tag) __attribute__((always_inline)) {
+        if constexpr (XVCAND) {
+#pragma unroll
+            for (int n = 0; n < NA; ++n)
+                if ((A_VEC % SNT == 0) || stid + SNT * n < A_VEC) reinterpret_cast<f32x4*>(Ad)[stid + SNT * n] = rav[n];
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                xv_t v = rxv[n];
+                if constexpr (!decltype(allok_tag)::value)
+                    if (!((xvok >> n) & 1u)) v = xv_t(0.0f);
+                if constexpr (K == 7 && decltype(snake_tag)::value) {   // Snake of the consumed tensor (snake(0) == 0: the zero padding survives it)
+                    const float2 al = Al[cbn * CB + xvc[n]];
+                    float v0 = v[0], v1 = v[1];
+                    nc_snake_pair(v0, v1, al.x, al.y, al.x, al.y);
+                    v[0] = v0; v[1] = v1;
+                }
+                if ((XVN % NT == 0) || tid + NT * n < XVN) reinterpret_cast<xv_t*>(Xd)[tid + NT * n] = v;
+            }
+        }
+    };
+    // one rotation of the XV schedule inside block cb: the words of block cb + 1 to the idle buffers, the reads of block cb + 2 behind them
+    auto xv_stage = [&](int cb, float* An, float* Xn) __attribute__((always_inline)) {
+        if constexpr (XVCAND) {
+            if (K == 7 && alpha_in != nullptr) {
+                if (xv_allok) xv_store(cb + 1, An, Xn, std::true_type{}, std::true_type{});
+                else xv_store(cb + 1, An, Xn, std::false_type{}, std::true_type{});
+            } else {
+                if (xv_allok) xv_store(cb + 1, An, Xn, std::true_type{}, std::false_type{});
+                else xv_store(cb + 1, An, Xn, std::false_type{}, std::false_type{});
+            }
+            if (cb + 2 < n_cb) xv_issue(cb + 2);
+        }
+    };
     auto issue_group_to = [&](int cbn, auto gtag, f32x4 (&ra)[GA], float (&rx)[GXX]) __attribute__((always_inline)) {
         constexpr int g = decltype(gtag)::value;
         const f32x4* src = wbase + (size_t)cbn * A_VEC;
@@ -535,6 +625,9 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     } else {
     auto main_loop = [&](auto xr_tag) __attribute__((always_inline)) {
     constexpr int XR = decltype(xr_tag)::value;   // 0 generic, 1 constant pitch
+    if constexpr (XVCAND && XR == 1) {
+        if (use_xv && n_cb > 1) xv_issue(1);      // (block 0 came through the prologue; see the rotating schedule below)
+    }
     for (int cb = 0; cb < n_cb; ++cb) {
         const int cur = cb & 1;
         const float* Ac = As0 + cur * A_FLOATS + hi * BM + nc_a_lane_off<TM>(l31);
@@ -570,8 +663,16 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         nc_static_for<NSEG>([&](auto seg_tag) __attribute__((always_inline)) {
             constexpr int seg = decltype(seg_tag)::value;
             if (more) {
-                if constexpr (seg >= 1) store_group_any(cb + 1, An, Xn, std::integral_constant<int, (seg >= 1 ? seg - 1 : 0)>{});
-                if constexpr (seg < NG) issue_group(cb + 1, seg_tag);
+                if (XVCAND && XR == 1 && use_xv) {   // (compile-time false for every other instance: the branch folds away)
+                    // rotating schedule: ONE register set.  At the head of segment NC_XV_STORE_SEG the words of block cb + 1 (in flight
+                    // since the same point of the block before: a whole block of latency cover) go to the idle LDS buffers, and the
+                    // reads of block cb + 2 are issued straight behind them (that block's buffers are the ones being read now, but its
+                    // words stay in registers until this block's closing barrier has passed).
+                    if constexpr (seg == NC_XV_STORE_SEG) xv_stage(cb, An, Xn);
+                } else {
+                    if constexpr (seg >= 1) store_group_any(cb + 1, An, Xn, std::integral_constant<int, (seg >= 1 ? seg - 1 : 0)>{});
+                    if constexpr (seg < NG) issue_group(cb + 1, seg_tag);
+                }
             }
             // ---- matrix-core steps of this segment, ascending kk; fragments of step kp+1 are read before
             //      the MFMAs of step kp are issued (register double buffer fa/fb)
@@ -591,6 +692,9 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp % (FD + 1)][i], fb[kp % (FD + 1)][j], acc[i][j], 0, 0, 0);
             });
         });
+        if constexpr (XVCAND && XR == 1 && NC_XV_STORE_SEG >= NSEG) {   // (experiment: the words written behind the block's last matrix-core step)
+            if (more && use_xv) xv_stage(cb, An, Xn);
+        }
         __syncthreads();
     }
     };

@@ -29,6 +29,7 @@ const EnvRow kEnv[] = {
     {"NC_TN_THRESH", 'i', "column-tile width threshold"},
     {"NC_NO_TN_ROUNDS", 'b', "no round-count rule for the column-tile width"},
     {"NC_NO_XR", 'b', "generic B-fragment addressing in the conv template (no constant-pitch immediate offsets)"},
+    {"NC_NO_XV", 'b', "item-wise window staging in the two-tap sub-pixel instances (no vectorised float4 staging)"},
     {"NC_NO_NARROW", 'b', "no 3-wave narrow variants"},
     {"NC_NO_SLIM", 'b', "no half-size reduction blocks for narrow long rows"},
     {"NC_NO_SUBPIXEL", 'b', "per-phase launches for power-of-two strided transposed convolutions"},

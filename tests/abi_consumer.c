@@ -47,7 +47,15 @@ int main(int argc, char** argv) {
     CHECK(nc_dac_query(h, T, &T_pad, &frames));                                /* DAC.Preprocess */
     const int32_t nq = cfg->n_codebooks;
     const size_t n_codes = (size_t)B * (size_t)nq * (size_t)frames, n_z = (size_t)B * (size_t)cfg->latent_dim * (size_t)frames;
-    const size_t n_out = (size_t)B * (size_t)T_pad;
+    /* decoded length: every DecoderBlock's transposed convolution maps L -> (L - 1) s - 2 ceil(s / 2) + 2 s (DecoderBlock.cs:20-44,
+     * WNConvTranspose1d.cs:142-163): = T_pad for even strides, shorter when a stride is odd (the 16 / 24 kHz presets' stride 5) */
+    int64_t L_out = frames;
+    for (int i = 0; i < cfg->n_decoder_rates; ++i) {
+        const int64_t st = cfg->decoder_rates[i];
+        L_out = (L_out - 1) * st - 2 * ((st + 1) / 2) + 2 * st;
+    }
+    if (L_out > T_pad) { fprintf(stderr, "decoded length %lld exceeds the padded input %lld\n", (long long)L_out, (long long)T_pad); return 1; }
+    const size_t n_out = (size_t)B * (size_t)L_out;
     int64_t* codes = (int64_t*)malloc(n_codes * sizeof(int64_t));
     float* z = (float*)malloc(n_z * sizeof(float));
     float* out = (float*)malloc(n_out * sizeof(float));

@@ -78,7 +78,7 @@ def sweep_encodec(wseeds, pseeds, clips, preset=None):
             raudio = ref.decode(rfr)
             rows.append({"weight_seed": ws, "pcm_seed": ps, "clips": clips, "codes": int(sum(f.codes.size for f in frames)),
                          "code_mismatches": int(sum(np.count_nonzero(f.codes != r[0]) for f, r in zip(frames, rfr))),
-                         "scale_max_abs": max(_maxabs(f.scale, r[1]) for f, r in zip(frames, rfr)),
+                         "scale_max_abs": max((_maxabs(f.scale, r[1]) if f.scale is not None else 0.0) for f, r in zip(frames, rfr)),   # (24 kHz: no scale)
                          "pcm_max_abs": _maxabs(audio, raudio), "codes_sha256_16": _sha([f.codes for f in frames])})
         m.dispose()
     return rows

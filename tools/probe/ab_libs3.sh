@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: parity suites + headline class table + the other configurations' step times for the shipped library (with and
+# without the environment settings given as arguments) and every build_abl/lib_*.so, interleaved, 2 rounds, on one box.
+#   ab_libs3.sh [ENV=val ...]
+cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/ab_libs3.txt; : > $OUT
+for f in build_abl/lib_*.so; do
+  echo "== parity $f" | tee -a $OUT
+  NC_MI355X_LIB=$PWD/$f timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_dac_gpu.py tests/test_snac_gpu.py -m gpu -x -q 2>&1 | tail -2 | tee -a $OUT
+done
+for rep in 1 2; do
+  for setting in NC_DEFAULT=1 "$@" $(ls build_abl/lib_*.so 2>/dev/null | sed "s|^|NC_MI355X_LIB=$PWD/|"); do
+    echo "== bench rep $rep $setting" | tee -a $OUT
+    env $setting python bench.py --no-cpu-baseline --no-extra --no-check --steps 20 --warmup 5 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], {k: round(v['ms_per_step'],3) for k, v in d['roofline']['all_classes'].items()})" | tee -a $OUT
+    env $setting python tools/codecbench.py --steps 10 --warmup 3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('  ', {k: v['ms'] for k, v in d.items()})" | tee -a $OUT
+  done
+done
