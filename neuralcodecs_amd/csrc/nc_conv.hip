@@ -55,6 +55,15 @@ static conv_kernel_fn conv_kernel_table_spec_k7(int, int) { return nullptr; }
 static conv_kernel_fn conv_kernel_table_dist_k7(int, int) { return nullptr; }
 static int experiment_mode(const char*) { return 0; }
 #endif
+#ifdef NC_EXPERIMENTS   // XV-only k = 7 instances: bit-exact, measured NEUTRAL against the legacy instances: EXPERIMENTS=1 builds
+conv_kernel_fn conv_kernel_table_xv_k7(int);
+conv_kernel_fn conv_kernel_table_xv_fused_k7(int);
+#else
+static conv_kernel_fn conv_kernel_table_xv_k7(int) { return nullptr; }
+static conv_kernel_fn conv_kernel_table_xv_fused_k7(int) { return nullptr; }
+#endif
+conv_kernel_fn conv_kernel_table_xv_sub_k2(int);
+conv_kernel_fn conv_kernel_table_xv_subg_k2(int);
 conv_kernel_fn conv_kernel_table_sub_k2(int, int);
 conv_kernel_fn conv_kernel_table_subg_k2(int, int);
 conv_kernel_fn conv_kernel_table_dist_k16(int, int);
@@ -333,7 +342,15 @@ static TileChoice choose_tile(const ConvLayer& L, int64_t blocks_per_rowtile, bo
         const int bpc = pointwise_fast ? bpc_pw[c.TM] : bpc_gen[c.TM];
         const double rounds = std::ceil(blocks / (256.0 * bpc));
         // (k = 7 at 128 rows x 256 columns runs out of registers -- 212 B of scratch per lane; C = 256: 1.80 ms against 1.65 ms with 64-row tiles)
-        return rounds * bpc * c.TM * pen[c.TM] * ((c.TM == 4 && c.K == 7 && !pointwise_fast) ? 1.12 : 1.0);
+        double inst = (c.TM == 4 && c.K == 7 && !pointwise_fast) ? 1.12 : 1.0;
+        // Two-tap sub-pixel up-convolutions with SHORT reductions (Cin <= 384: 12-24 reduction blocks per tile): a tile's prologue and
+        // epilogue -- an output-heavy epilogue: stride x more samples out than in -- are 10-15 % of its life, and the 64-row instance is the
+        // only one of the three that does not spill (241 registers; 96 rows: 256 + 26 spilled, 128 rows: 256 + 136).  Measured with the XV
+        // staging (tools/probe/tm_pick_up.sh, one box): 192 -> 96 at 32 x 22 272 columns 1079 us with 96-row tiles, 980 with 64-row tiles
+        // (SNAC's at 8 x 110 592: 1318 / 1200); 384 -> 192: 1943 / 1834; from 768 input channels on the 96-row tiles win (2119 / 2215).
+        static const bool xv_off = env_flag("NC_NO_XV") || env_flag("NC_NO_XR");   // (the legacy 64-row instance does not win: conv_up 5.94 -> 6.15 ms)
+        if (!xv_off && L.sub_stride && c.K == 2 && c.TM == 2 && L.Cin <= 384) inst = 0.88;
+        return rounds * bpc * c.TM * pen[c.TM] * inst;
     };
     TileChoice best{L.cfg, L.w.as<float>(), L.w_phase_stride};
     double bc = cost(L.cfg);
@@ -823,22 +840,28 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     const int ad = a.dil < 0 ? -a.dil : a.dil;
     a.xneg = a.dil < 0 ? (L.Ktaps - 1) * ad : 0;
     int xv_extra = 0;
+    conv_kernel_fn xv_fn = nullptr;   // XV-only instance of this launch (nc_conv_kernel.hip.h "XVK"), when its staging form applies
     {   // XV (round 5): vectorised window staging of the two-tap sub-pixel instances (the kernel's XV note) -- plain input, rows and window
         // start on 16-byte boundaries (xneg is raised by up to 3 slots for that: the window still fits its 320-slot pitch), whole float4s
         static const bool no_xv = env_flag("NC_NO_XV");
         static const bool no_xr = env_flag("NC_NO_XR");
-        const bool two_tap = L.sub_stride && L.n_phase == 1 && c.K == 2 && c.CB == 16 && !io.alpha_in && !io.fuse_k1;
-#if defined(NC_XV_K7) && NC_XV_K7
-        const bool k7 = !L.transposed && !L.sub_stride && c.K == 7 && c.CB == 8 && L.stride == 1;      // (the fused units included)
+#ifdef NC_EXPERIMENTS
+        static const bool xv_k7 = env_flag("NC_XV_K7");
 #else
-        const bool k7 = false;
+        constexpr bool xv_k7 = false;
 #endif
+        const bool two_tap = L.sub_stride && L.n_phase == 1 && c.K == 2 && c.CB == 16 && !io.alpha_in && !io.fuse_k1;
+        const bool k7 = xv_k7 && !L.transposed && !L.sub_stride && c.K == 7 && c.CB == 8 && L.stride == 1 && !fused_wide;   // (the fused units included)
         const int vw = two_tap ? 4 : 2;   // floats per staged word
-        if (!no_xv && !no_xr && (two_tap || k7) && c.TN == 2 && c.NW == 4 && !narrow && !flat && !dist_small_fn && !n_prod && !light && !wide && !dist &&
-            !slim && !in_mode && !io.x2 && sx == 1 && L.Cin % c.CB == 0 && io.x_len % vw == 0 && io.x_cstride % vw == 0 && io.x_bstride % vw == 0 &&
-            (reinterpret_cast<uintptr_t>(io.x) & 15) == 0) {
+        if (!no_xv && !no_xr && (two_tap || k7) && c.TN == 2 && c.NW == 4 && c.TM >= 2 && c.TM <= 4 && !narrow && !flat && !dist_small_fn && !n_prod &&
+            !light && !wide && !dist && !slim && !in_mode && !io.x2 && !io.gn_part && sx == 1 && L.Cin % c.CB == 0 && io.x_len % vw == 0 &&
+            io.x_cstride % vw == 0 && io.x_bstride % vw == 0 && (reinterpret_cast<uintptr_t>(io.x) & 15) == 0) {
             xv_extra = (vw - (a.pad + a.xneg) % vw) % vw;
-            if ((BN - 1) * sx + (L.Ktaps - 1) * ad + 1 + xv_extra <= 320) { a.xneg += xv_extra; a.epi |= EPI_XVEC; }
+            if ((BN - 1) * sx + (L.Ktaps - 1) * ad + 1 + xv_extra <= 320) {
+                xv_fn = two_tap ? (L.sub_shift ? conv_kernel_table_xv_sub_k2(c.TM) : conv_kernel_table_xv_subg_k2(c.TM))
+                                : (io.fuse_k1 ? conv_kernel_table_xv_fused_k7(c.TM) : conv_kernel_table_xv_k7(c.TM));
+            }
+            if (xv_fn) { a.xneg += xv_extra; a.epi |= EPI_XVEC; }
             else xv_extra = 0;
         }
     }
@@ -884,6 +907,9 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         a.alpha_out2 = io.alpha_out2;
         fn = fused_wide ? conv_kernel_table_fusedw_k7(c.TM, c.TN) : conv_kernel_table_fused_k7(c.TM, c.TN);
         if (!fn) fail(NC_EUNSUPPORTED, "no fused residual-unit kernel for TM=%d TN=%d", c.TM, c.TN);
+        if (xv_fn) fn = xv_fn;
+    } else if (xv_fn) {
+        fn = xv_fn;
     } else if (dist_small_fn) {
         fn = dist_small_fn;
     } else if (dist) {
@@ -930,9 +956,40 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         if (io.fuse_k1) fl += io.fuse_k1->flops(B, io.Tin);
         prof->begin(stream, L.kclass, fl, bytes);
     }
+#ifdef NC_CONV_TRACE
+    // diagnostic builds: NC_CONV_TRACE_FILE=<path> + NC_CONV_TRACE_SEL="K,Cin,dil" picks the first matching launch (see the kernel's NC_STAMP)
+    static const char* trace_file = env_str("NC_CONV_TRACE_FILE");
+    static bool traced = false;
+    DevBuf trace_buf;
+    bool trace_now = false;
+    if (trace_file && !traced && !io.x2) {
+        int tk = 7, tc = 384, td = 1;
+        if (const char* sel = env_str("NC_CONV_TRACE_SEL")) std::sscanf(sel, "%d,%d,%d", &tk, &tc, &td);
+        if (c.K == tk && L.Cin == tc && (L.dil == td || L.transposed) && a.n_cb >= 16) {
+            trace_buf.reserve((size_t)16 * 8 * 8 * 8 * 8);
+            NC_HIP(hipMemsetAsync(trace_buf.p, 0, (size_t)16 * 8 * 8 * 8 * 8, stream));
+            a.x2 = trace_buf.as<float>();
+            trace_now = traced = true;
+        }
+    }
+#endif
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64 * (c.NW + n_prod)), lds, stream, a);
     NC_HIP(hipGetLastError());
     if (prof && prof->on) prof->end(stream);
+#ifdef NC_CONV_TRACE
+    if (trace_now) {
+        std::vector<unsigned long long> hb((size_t)16 * 8 * 8 * 8);
+        NC_HIP(hipStreamSynchronize(stream));
+        NC_HIP(hipMemcpy(hb.data(), trace_buf.p, hb.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = std::fopen(trace_file, "wb")) {
+            const int hdr[8] = {16, c.NW + n_prod, 8, 8, c.TM, c.TN, c.K, (a.epi & EPI_XVEC) ? 1 : 0};
+            std::fwrite(hdr, sizeof(int), 8, f);
+            std::fwrite(hb.data(), 8, hb.size(), f);
+            std::fclose(f);
+        }
+        trace_buf.release();
+    }
+#endif
     {   // NC_LAUNCH_LOG=<path>: one line per conv-template launch (class, threads, shape) in launch order.  The template serves several
         // kernel classes under one kernel name; tools/pmc_classes.py zips this log with the rocprofv3 counter rows of the same
         // kernel name (dispatch order) to attribute HBM traffic / matrix-core busy cycles to exactly the launches a class counts.

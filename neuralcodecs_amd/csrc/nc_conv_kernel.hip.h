@@ -10,12 +10,22 @@
 #include <type_traits>
 #include <utility>
 
-#ifndef NC_XV_K7
-#define NC_XV_K7 0          // 1: XV staging for the k = 7 instances as well (experiment; the host side reads the same macro)
+#ifdef NC_CONV_TRACE
+#define NC_TRACE_WGS 16
+#ifndef NC_TRACE_WG0
+#define NC_TRACE_WG0 1024   // first traced workgroup: well behind the launch front, where the workgroups of the chip have drifted apart
+#endif
+#define NC_TRACE_CB0 8
+#define NC_TRACE_NCB 8
+#endif
+#ifndef NC_STAGE_PRIO
+#define NC_STAGE_PRIO 0     // experiment: s_setprio of the staging runs of the segmented pipeline (0 = leave the priority alone)
 #endif
 #ifndef NC_XV_STORE_SEG
-#define NC_XV_STORE_SEG 2   // XV staging: the window words issued at the head of segment 0 are written at the head of this segment
-#endif
+#define NC_XV_STORE_SEG 3   // XV staging: the block's one staging run sits at the head of this matrix-core segment (0 .. 3; 4 = behind the last).
+#endif                      // Measured on one box (DAC conv_up class, ms per step): item form 6.54; XV at segment 1 / 2: 6.52 (no gain); at
+                            // segment 0: 6.25, 3: 6.21, 4: 6.27 -- ONE staging run per block next to the barrier, not the vector loads and not
+                            // the latency cover (the rotating schedule gives every position a whole block of it), is what pays: see DESIGN 8 r5.
 
 namespace nc {
 
@@ -73,8 +83,13 @@ typedef __attribute__((address_space(3))) void* nc_lptr;
 // IN2: two-input form of the Encodec input mode (the sum of a residual block's shortcut and branch, each a raw conv output with its own
 // pending GroupNorm: SEANetResnetBlock.cs:72-85 feeding the next SConv1d / SConvTranspose1d): both operands are read with the same
 // window addresses, normalised separately, added, then ELU + pad -- the summed / activated / padded copy is never written.
+// XVK (round 5): the XV-ONLY instances.  One staging form (vectorised words, one run per block, rotating register set: see the XV note
+// below), launched by the host only where that form applies (plain or Snake input with aligned rows, one-clip tiles, constant window pitch),
+// with everything else compiled OUT: no Encodec input mode, no flattened column axis, no item-form staging state, no generic-pitch loop,
+// no GroupNorm epilogue.  This is the "scalar-register diet" of VERDICT r4: the legacy instances keep every run-time mode and pay for it
+// in spilled scalar registers whose reloads are vector instructions.
 template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0, bool DIST = false, int SUB = 0,
-          bool IN2 = false>
+          bool IN2 = false, bool XVK = false>
 __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const ConvArgs p) {
     constexpr bool SPEC = NP > 0;
     constexpr int NT = 64 * (NW + NP);             // threads per workgroup
@@ -105,6 +120,22 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int hi = lane >> 5;
+#ifdef NC_CONV_TRACE
+    // In-kernel phase trace (diagnostic builds only: -DNC_CONV_TRACE; VERDICT r4 item 3 iv).  Workgroups [NC_TRACE_WG0, + NC_TRACE_WGS) stamp the
+    // shader clock (s_memtime) at 8 points of reduction blocks [NC_TRACE_CB0, +NC_TRACE_NCB): 0 = block top (behind the barrier), 1 / 2 =
+    // before / behind the staging work at the head of segment 1, 3 / 4 segment 2, 5 / 6 segment 3, 7 = in front of the closing barrier.
+    // One lane per wavefront stores; the buffer rides in ConvArgs::x2 (unused outside the two-input instances), set by launch_conv for the
+    // launch NC_CONV_TRACE_FILE selects.  tools/probe/conv_trace.py prints segment, staging and barrier-wait times per wavefront.
+    unsigned long long* const trace_p = (!IN2 && p.x2 != nullptr && blockIdx.x >= NC_TRACE_WG0 && blockIdx.x < NC_TRACE_WG0 + NC_TRACE_WGS)
+        ? reinterpret_cast<unsigned long long*>(const_cast<float*>(p.x2)) + ((size_t)(blockIdx.x - NC_TRACE_WG0) * 8 + (tid >> 6)) * NC_TRACE_NCB * 8 : nullptr;
+#define NC_STAMP(cb, slot)                                                                                         \
+    do {                                                                                                            \
+        if (trace_p && (cb) >= NC_TRACE_CB0 && (cb) < NC_TRACE_CB0 + NC_TRACE_NCB && (tid & 63) == 0)               \
+            trace_p[((cb) - NC_TRACE_CB0) * 8 + (slot)] = __builtin_amdgcn_s_memtime();                             \
+    } while (0)
+#else
+#define NC_STAMP(cb, slot) do {} while (0)
+#endif
     const bool producer = SPEC && wave >= NW;
     const int swave = SPEC ? wave - NW : wave;     // index among the staging waves (consumers of the specialised variant: unused)
     const int stid = SPEC ? tid - 64 * NW : tid;
@@ -142,9 +173,11 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     // and every formula below reduces to the one-clip tile: b = clip of the tile, col0 = its first column.
     // (With GroupNorm sums in the epilogue the clip pitch p.flat_pc is n_cols rounded up to whole 32-column blocks, so every 32x32
     // accumulator tile is ONE canonical block of ONE sample; the columns between n_cols and the pitch are padding.)
-    const int b = __builtin_amdgcn_readfirstlane(p.flat ? (t_tile * BN) / p.flat_pc : lin % p.B);   // first clip of the tile
-    const int col0 = p.flat ? t_tile * BN - b * p.flat_pc : t_tile * BN;                              // first column, within clip b
-    const int flat_px = p.flat_px, flat_pc = p.flat_pc;
+    const bool flatm = XVK ? false : (p.flat != 0);
+    const int b = __builtin_amdgcn_readfirstlane(flatm ? (t_tile * BN) / p.flat_pc : lin % p.B);   // first clip of the tile
+    const int col0 = flatm ? t_tile * BN - b * p.flat_pc : t_tile * BN;                              // first column, within clip b
+    const int flat_px = XVK ? 0x1fffffff : p.flat_px, flat_pc = XVK ? 0x1fffffff : p.flat_pc;
+    const int flat_hc = XVK ? 0 : p.flat_hc;
     auto seg_of = [&](int r, int pitch) __attribute__((always_inline)) -> int { return (int)(r >= pitch) + (int)(r >= 2 * pitch) + (int)(r >= 3 * pitch); };
 
     const int s = p.stride;
@@ -164,7 +197,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     const unsigned x_cstride = (unsigned)p.x_cstride;
     const float* const alpha_in = p.alpha_in;
     // Encodec input mode (ConvArgs::in_mode): pending GroupNorm + ELU + reflect pad applied while staging
-    const int in_mode = p.in_mode;
+    const int in_mode = XVK ? 0 : p.in_mode;
     const float in_mu = (in_mode & 1) ? p.in_stats[2 * b] : 0.0f, in_rs = (in_mode & 1) ? p.in_stats[2 * b + 1] : 1.0f;
     const float in_mu2 = (IN2 && (in_mode & 1)) ? p.in_stats2[2 * b] : 0.0f, in_rs2 = (IN2 && (in_mode & 1)) ? p.in_stats2[2 * b + 1] : 1.0f;
     int tap[K];  // window slot of tap k (wave-uniform scalars)
@@ -188,6 +221,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     unsigned xg[NX];
     int xc[NX];
     unsigned okm = 0;   // bit i = window item i of this lane reads a real sample (else zero padding / the zero extension / tile overrun)
+    if constexpr (!XVK)
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         const int item = swave + SW * i;
@@ -220,23 +254,24 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     // after them -2.7 ... -4.4 % per layer; the latency cover is what these short-reduction classes were missing.  The host
     // (launch_conv: EPI_XVEC) grants it for plain inputs with 16-byte aligned rows, a window start that is a multiple of 4 samples (xneg
     // is raised for that) and row lengths that are multiples of 4, so that a float4 is inside the row or outside it as a whole.
-    // K = 7 (NC_XV_K7 builds, experiment): the same for the dilated residual-unit convolutions with 8-byte words -- [8][320] floats = 5
+    // K = 7 (NC_XV_K7=1 at run time, experiment): the same for the dilated residual-unit convolutions with 8-byte words -- [8][320] floats = 5
     // float2 per thread, so the Snake work per thread stays exactly the item form's 10 elements, as packed pairs of one channel.
-    constexpr bool XVCAND = TN == 2 && NW == 4 && !IN2 && !SPEC && !DIST &&
-                            ((K == 2 && SUB != 0 && !FUSE) || (NC_XV_K7 != 0 && K == 7 && SUB == 0));
+    constexpr bool XVCAND = XVK;
+    static_assert(!XVK || (TN == 2 && NW == 4 && !IN2 && !SPEC && !DIST && ((K == 2 && SUB != 0 && !FUSE) || (K == 7 && SUB == 0))),
+                  "XV-only instances: two-tap sub-pixel or k = 7, 256-column tiles");
     constexpr int XVW = K == 2 ? 4 : 2;                          // floats per staged word
     constexpr int XVROW = 320;                                   // (== XROWC of the 256-column tiles, defined with the fragment reads below)
     constexpr int XVN = CB * XVROW / XVW;                        // words of the window image
     constexpr int NV = XVCAND ? (XVN + NT - 1) / NT : 1;
     typedef float xv_t __attribute__((ext_vector_type(XVW)));
-    const bool use_xv = XVCAND && (p.epi & EPI_XVEC) != 0;       // wave-uniform (kernel argument)
+    constexpr bool use_xv = XVCAND;                              // (the host launches these instances only where the form applies)
     unsigned xvo[NV];                                            // float offset of word n from the first channel row of a reduction block
     unsigned xvok = 0;                                           // bit n: word n lies inside its row (else zero padding)
     int xvc[(XVCAND && K == 7) ? NV : 1];                        // K = 7: channel (within the block) of word n, for its Snake operands
     xv_t rxv[NV];
     f32x4 rav[XVCAND ? NA : 1];
     if constexpr (XVCAND) {
-        if (use_xv) {
+        {
 #pragma unroll
             for (int n = 0; n < NV; ++n) {
                 const int f = min(tid + NT * n, XVN - 1);
@@ -417,8 +452,10 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     // ---- prologue: stage reduction block 0.  Every global read of the prologue -- the first tile's groups and the operands of
     // the two LDS tables -- is issued before anything waits: one memory round trip in all.
     {
-        f32x4 ra0[NG][GA];
-        float rx0[NG][GXX];
+        f32x4 ra0[XVK ? 1 : NG][GA];
+        float rx0[XVK ? 1 : NG][GXX];
+        if constexpr (XVK) xv_issue(0);
+        else
         if (!SPEC || producer)
             nc_static_for<NG>([&](auto g) __attribute__((always_inline)) { issue_group_to(0, g, ra0[decltype(g)::value], rx0[decltype(g)::value]); });
         // Snake alphas of all input channels -> (alpha, 1/alpha), 4 reads per thread in flight per pass
@@ -454,6 +491,10 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
             }
         }
         __syncthreads();   // the alpha table is complete before the Snake of the first tile reads it
+        if constexpr (XVK) {
+            if (K == 7 && alpha_in != nullptr) xv_store(0, As0, Xs0, std::false_type{}, std::true_type{});
+            else xv_store(0, As0, Xs0, std::false_type{}, std::false_type{});
+        } else
         if (!SPEC || producer)
             nc_static_for<NG>([&](auto g) __attribute__((always_inline)) {
                 constexpr int gi = decltype(g)::value;
@@ -472,8 +513,8 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
 #pragma unroll
     for (int j = 0; j < TN; ++j) sgc[j] = seg_of(col0 + wave * BNW + j * 32 + l31, flat_pc);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) ej[j] = (sgc[j] - sgc[0]) * p.flat_hc;
-    const int x_lane = wave * BNW + l31 + sgc[0] * p.flat_hc;
+    for (int j = 0; j < TN; ++j) ej[j] = (sgc[j] - sgc[0]) * flat_hc;
+    const int x_lane = wave * BNW + l31 + sgc[0] * flat_hc;
     // B-fragment addressing: MFMA step kp pairs kk = 2kp (lanes 0-31) with kk+1 (lanes 32-63), i.e. tap k0 of channel c0 with the
     // next tap (or tap 0 of the next channel).  The lane-half difference depends only on k0: one base per k0, so a step's address
     // is base[k0] + (wave-uniform offset of (c0, k0)) -- one vector add per step.
@@ -662,8 +703,13 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         } else
         nc_static_for<NSEG>([&](auto seg_tag) __attribute__((always_inline)) {
             constexpr int seg = decltype(seg_tag)::value;
+            if constexpr (seg == 0) NC_STAMP(cb, 0);
+            else if constexpr (seg <= 3) NC_STAMP(cb, 2 * seg - 1);
+#if NC_STAGE_PRIO
+            if (more) __builtin_amdgcn_s_setprio(NC_STAGE_PRIO);   // (experiment: the staging run at raised issue priority)
+#endif
             if (more) {
-                if (XVCAND && XR == 1 && use_xv) {   // (compile-time false for every other instance: the branch folds away)
+                if constexpr (XVCAND && XR == 1) {   // (the XV-only instances)
                     // rotating schedule: ONE register set.  At the head of segment NC_XV_STORE_SEG the words of block cb + 1 (in flight
                     // since the same point of the block before: a whole block of latency cover) go to the idle LDS buffers, and the
                     // reads of block cb + 2 are issued straight behind them (that block's buffers are the ones being read now, but its
@@ -674,6 +720,10 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                     if constexpr (seg < NG) issue_group(cb + 1, seg_tag);
                 }
             }
+#if NC_STAGE_PRIO
+            if (more) __builtin_amdgcn_s_setprio(0);
+#endif
+            if constexpr (seg >= 1 && seg <= 3) NC_STAMP(cb, 2 * seg);
             // ---- matrix-core steps of this segment, ascending kk; fragments of step kp+1 are read before
             //      the MFMAs of step kp are issued (register double buffer fa/fb)
             constexpr int kp_lo = seg * KP / NSEG, kp_hi = (seg + 1) * KP / NSEG;
@@ -695,10 +745,13 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         if constexpr (XVCAND && XR == 1 && NC_XV_STORE_SEG >= NSEG) {   // (experiment: the words written behind the block's last matrix-core step)
             if (more && use_xv) xv_stage(cb, An, Xn);
         }
+        NC_STAMP(cb, 7);
         __syncthreads();
     }
     };
-    if constexpr (XRCAND) {
+    if constexpr (XVK) {
+        main_loop(std::integral_constant<int, 1>{});   // (the host guarantees the constant pitch)
+    } else if constexpr (XRCAND) {
         if (xrow == XROWC && s == 1 && !(p.epi & EPI_NO_XR)) main_loop(std::integral_constant<int, 1>{});
         else main_loop(std::integral_constant<int, 0>{});
     } else {
@@ -909,7 +962,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
         });
     };
 
-    if constexpr (!FUSE && !SPEC) {
+    if constexpr (!FUSE && !SPEC && !XVK) {
         // GroupNorm(1,C) block sums of the output (Encodec's NormConv1d, NormConv1d.cs:155): every 32x32 accumulator tile is reduced in
         // registers in the canonical order of nc_gn.h and leaves ONE (S1, S2) pair -- the tensor is not read back for its statistics.
         if (p.gn_part != nullptr) {
@@ -946,7 +999,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
             // the last workgroup of the sample to arrive turns the block sums into (mean, rstd): no follow-up launch.  (Reads -- the
             // arrival's returned count, the last arriver's loads -- all precede this workgroup's first output store.)
             if (p.gn_count != nullptr) {
-                if (p.flat) {   // arrivals counted in block sums: this tile holds inc[m] of them for sample b + m
+                if (flatm) {   // arrivals counted in block sums: this tile holds inc[m] of them for sample b + m
                     const int rb = min(TM, p.gn_nrb - co_tile * TM), f0 = t_tile * BN;
                     unsigned inc[4];
 #pragma unroll
@@ -1144,9 +1197,9 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
 typedef void (*conv_kernel_fn)(const ConvArgs);
 
 template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0, bool DIST = false, int SUB = 0,
-          bool IN2 = false>
+          bool IN2 = false, bool XVK = false>
 inline conv_kernel_fn get_conv_kernel() {
-    return &conv_mfma_kernel<TM, TN, K, CB, NX, FUSE, OCC, NW, NP, DIST, SUB, IN2>;
+    return &conv_mfma_kernel<TM, TN, K, CB, NX, FUSE, OCC, NW, NP, DIST, SUB, IN2, XVK>;
 }
 
 }  // namespace nc
@@ -1359,6 +1412,19 @@ inline conv_kernel_fn get_conv_kernel() {
             case 32: return get_conv_kernel<3, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, 2>();         \
             case 41: return get_conv_kernel<4, 1, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, 2>();         \
             case 42: return get_conv_kernel<4, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, 2>();         \
+        }                                                                                                  \
+        return nullptr;                                                                                    \
+    }                                                                                                      \
+    }
+
+// XV-only instances (see XVK above): NAME_k<K>(TM) for the 256-column tiles; FUSEV selects the fused residual unit, SUBV the sub-pixel form.
+#define NC_INSTANTIATE_CONV_XV(NAME, KVAL, CBVAL, NXVAL, FUSEV, SUBV)                                       \
+    namespace nc {                                                                                         \
+    conv_kernel_fn conv_kernel_table_##NAME(int TM) {                                                      \
+        switch (TM) {                                                                                      \
+            case 2: return get_conv_kernel<2, 2, KVAL, CBVAL, NXVAL, FUSEV, 2, 4, 0, false, SUBV, false, true>(); \
+            case 3: return get_conv_kernel<3, 2, KVAL, CBVAL, NXVAL, FUSEV, 2, 4, 0, false, SUBV, false, true>(); \
+            case 4: return get_conv_kernel<4, 2, KVAL, CBVAL, NXVAL, FUSEV, 2, 4, 0, false, SUBV, false, true>(); \
         }                                                                                                  \
         return nullptr;                                                                                    \
     }                                                                                                      \

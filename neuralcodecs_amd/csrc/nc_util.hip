@@ -29,7 +29,8 @@ const EnvRow kEnv[] = {
     {"NC_TN_THRESH", 'i', "column-tile width threshold"},
     {"NC_NO_TN_ROUNDS", 'b', "no round-count rule for the column-tile width"},
     {"NC_NO_XR", 'b', "generic B-fragment addressing in the conv template (no constant-pitch immediate offsets)"},
-    {"NC_NO_XV", 'b', "item-wise window staging in the two-tap sub-pixel instances (no vectorised float4 staging)"},
+    {"NC_NO_XV", 'b', "legacy instances with item-wise window staging everywhere (no XV-only instances)"},
+    {"NC_XV_K7", 'b', "EXPERIMENTS=1 builds: XV-only instances for the k = 7 residual-unit convolutions as well (measured neutral)"},
     {"NC_NO_NARROW", 'b', "no 3-wave narrow variants"},
     {"NC_NO_SLIM", 'b', "no half-size reduction blocks for narrow long rows"},
     {"NC_NO_SUBPIXEL", 'b', "per-phase launches for power-of-two strided transposed convolutions"},
@@ -80,6 +81,8 @@ const EnvRow kEnv[] = {
     {"NC_ATTN_NO_MFMA", 'b', "vector local-attention kernel"},
     {"NC_RCCL_LIB", 's', "the one RCCL library to open"},
     {"NC_LAUNCH_LOG", 's', "launch log for the per-class PMC attribution"},
+    {"NC_CONV_TRACE_FILE", 's', "-DNC_CONV_TRACE builds: file for the in-kernel phase trace of the convolution template (tools/probe/conv_trace.py)"},
+    {"NC_CONV_TRACE_SEL", 's', "-DNC_CONV_TRACE builds: \"K,Cin,dilation\" of the launch to trace (default 7,384,1)"},
     {"NC_LIGHT", 'i', "EXPERIMENTS=1 builds: light k = 7 variant"},
     {"NC_WIDE", 'i', "EXPERIMENTS=1 builds: 8-wave k = 7 variant"},
     {"NC_SPEC", 'i', "EXPERIMENTS=1 builds: producer / consumer k = 7 variant"},
