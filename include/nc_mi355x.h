@@ -356,6 +356,15 @@ NC_API nc_status nc_group_dac_encode_allgather_local_dev(nc_group* g, const floa
 NC_API nc_status nc_group_snac_encode_allgather_local_dev(nc_group* g, const float* const* pcm, const int32_t* B_local, int64_t T,
                                                           int64_t* const* codes_all);
 
+/* Encodec (Models/Encodec.cs:259-285: Encode emits one EncodedFrame per segment).  A rank's block is what nc_encodec_encode_dev writes: the
+ * frames' code tensors [B_local, n_q, T'_f] end to end in segment order (n_q * sum T'_f values per clip) and scales [n_frames, B_local].
+ * codes_all = [world][that block], scales_all = [world][n_frames][B_local] (nullable unless the model normalises): two collectives on the
+ * side stream; rank r's frames are the views of block r.  Equal B_local everywhere.  nc_group_wait as above. */
+NC_API nc_status nc_group_encodec_encode_allgather_dev(nc_group* g, const float* pcm, int32_t B_local, int64_t T, int64_t* codes_all,
+                                                       float* scales_all);
+NC_API nc_status nc_group_encodec_encode_allgather_local_dev(nc_group* g, const float* const* pcm, const int32_t* B_local, int64_t T,
+                                                             int64_t* const* codes_all, float* const* scales_all);
+
 /* ------------------------------------------------------------------------------------ profiling
  * Per-kernel-class timing with HIP events recorded on the handle's stream around every launch
  * (used by bench.py for the roofline object).  Classes are stable small integers. */

@@ -138,6 +138,8 @@ SYMBOLS = [
     ("nc_group_dac_encode_allgather_local_dev", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int64, C.c_int32, C.c_int32, C.POINTER(_P),
                                                           C.POINTER(_P), C.POINTER(_P)]),
     ("nc_group_snac_encode_allgather_local_dev", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int64, C.POINTER(_P)]),
+    ("nc_group_encodec_encode_allgather_dev", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P]),
+    ("nc_group_encodec_encode_allgather_local_dev", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int64, C.POINTER(_P), C.POINTER(_P)]),
     ("nc_codec_profile_enable", C.c_int, [_P, C.c_int32]),
     ("nc_codec_profile_reset", C.c_int, [_P]),
     ("nc_codec_profile_read", C.c_int, [_P, C.POINTER(NcProfileEntry)]),

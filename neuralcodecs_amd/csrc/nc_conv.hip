@@ -58,9 +58,11 @@ static int experiment_mode(const char*) { return 0; }
 #ifdef NC_EXPERIMENTS   // XV-only k = 7 instances: bit-exact, measured NEUTRAL against the legacy instances: EXPERIMENTS=1 builds
 conv_kernel_fn conv_kernel_table_xv_k7(int);
 conv_kernel_fn conv_kernel_table_xv_fused_k7(int);
+conv_kernel_fn conv_kernel_table_duo_k7(int);   // (their DUO form, NC_DUO=1: bit-exact, 6 % slower on the k = 7 class)
 #else
 static conv_kernel_fn conv_kernel_table_xv_k7(int) { return nullptr; }
 static conv_kernel_fn conv_kernel_table_xv_fused_k7(int) { return nullptr; }
+static conv_kernel_fn conv_kernel_table_duo_k7(int) { return nullptr; }
 #endif
 conv_kernel_fn conv_kernel_table_xv_sub_k2(int);
 conv_kernel_fn conv_kernel_table_xv_subg_k2(int);
@@ -840,6 +842,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     const int ad = a.dil < 0 ? -a.dil : a.dil;
     a.xneg = a.dil < 0 ? (L.Ktaps - 1) * ad : 0;
     int xv_extra = 0;
+    bool duo_launch = false;          // ... in its two-tiles-per-workgroup form (nc_conv_kernel.hip.h "DUO")
     conv_kernel_fn xv_fn = nullptr;   // XV-only instance of this launch (nc_conv_kernel.hip.h "XVK"), when its staging form applies
     {   // XV (round 5): vectorised window staging of the two-tap sub-pixel instances (the kernel's XV note) -- plain input, rows and window
         // start on 16-byte boundaries (xneg is raised by up to 3 slots for that: the window still fits its 320-slot pitch), whole float4s
@@ -851,7 +854,13 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         constexpr bool xv_k7 = false;
 #endif
         const bool two_tap = L.sub_stride && L.n_phase == 1 && c.K == 2 && c.CB == 16 && !io.alpha_in && !io.fuse_k1;
-        const bool k7 = xv_k7 && !L.transposed && !L.sub_stride && c.K == 7 && c.CB == 8 && L.stride == 1 && !fused_wide;   // (the fused units included)
+#ifdef NC_EXPERIMENTS
+        static const bool duo_env = env_flag("NC_DUO");
+#else
+        constexpr bool duo_env = false;
+#endif
+        const bool duo7 = duo_env && !io.fuse_k1 && (c.TM == 2 || c.TM == 3);
+        const bool k7 = (xv_k7 || duo7) && !L.transposed && !L.sub_stride && c.K == 7 && c.CB == 8 && L.stride == 1 && !fused_wide;   // (the fused units included)
         const int vw = two_tap ? 4 : 2;   // floats per staged word
         if (!no_xv && !no_xr && (two_tap || k7) && c.TN == 2 && c.NW == 4 && c.TM >= 2 && c.TM <= 4 && !narrow && !flat && !dist_small_fn && !n_prod &&
             !light && !wide && !dist && !slim && !in_mode && !io.x2 && !io.gn_part && sx == 1 && L.Cin % c.CB == 0 && io.x_len % vw == 0 &&
@@ -859,7 +868,9 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
             xv_extra = (vw - (a.pad + a.xneg) % vw) % vw;
             if ((BN - 1) * sx + (L.Ktaps - 1) * ad + 1 + xv_extra <= 320) {
                 xv_fn = two_tap ? (L.sub_shift ? conv_kernel_table_xv_sub_k2(c.TM) : conv_kernel_table_xv_subg_k2(c.TM))
-                                : (io.fuse_k1 ? conv_kernel_table_xv_fused_k7(c.TM) : conv_kernel_table_xv_k7(c.TM));
+                                : duo7 ? conv_kernel_table_duo_k7(c.TM)
+                                       : (io.fuse_k1 ? conv_kernel_table_xv_fused_k7(c.TM) : conv_kernel_table_xv_k7(c.TM));
+                duo_launch = xv_fn && !two_tap && duo7;
             }
             if (xv_fn) { a.xneg += xv_extra; a.epi |= EPI_XVEC; }
             else xv_extra = 0;
@@ -973,6 +984,11 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         }
     }
 #endif
+    if (duo_launch) {   // two tiles per workgroup: 8 wavefronts, each sub-workgroup its own LDS half
+        const size_t lds_sub = sizeof(float) * (((size_t)a.ep_off + 6 * (size_t)BM + 3) & ~(size_t)3);
+        if (2 * lds_sub > 160 * 1024) fail(NC_EUNSUPPORTED, "DUO conv tile needs %zu B of LDS", 2 * lds_sub);
+        hipLaunchKernelGGL(fn, dim3((unsigned)((grid + 1) / 2)), dim3(512), 2 * lds_sub, stream, a);
+    } else
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64 * (c.NW + n_prod)), lds, stream, a);
     NC_HIP(hipGetLastError());
     if (prof && prof->on) prof->end(stream);

@@ -89,8 +89,15 @@ typedef __attribute__((address_space(3))) void* nc_lptr;
 // no GroupNorm epilogue.  This is the "scalar-register diet" of VERDICT r4: the legacy instances keep every run-time mode and pay for it
 // in spilled scalar registers whose reloads are vector instructions.
 template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0, bool DIST = false, int SUB = 0,
-          bool IN2 = false, bool XVK = false>
-__global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const ConvArgs p) {
+          bool IN2 = false, bool XVK = false, bool DUO = false>
+__global__ __launch_bounds__((DUO ? 2 : 1) * 64 * (NW + NP), DUO ? 1 : OCC) void conv_mfma_kernel(const ConvArgs p) {
+    // DUO (round 5): TWO tiles per workgroup.  A workgroup of 8 wavefronts is two "sub-workgroups" of 4 (one wavefront of each per SIMD),
+    // each with its own tile, its own half of the LDS and the XV-only loop -- but the second runs HALF A REDUCTION BLOCK behind the first,
+    // held there by the workgroup barrier, which both now pass twice per block (at the block's end and in its middle: one sub-workgroup's
+    // end is the other's middle).  Per half block one of them runs its staging run + two matrix-core segments, the other two segments:
+    // a staging run always has a partner inside a matrix-core segment on its SIMD.  With two independent workgroups per CU that
+    // anti-phase is left to chance (the phase trace: the pipe idles where both waves of a SIMD are outside their segments at once).
+    static_assert(!DUO || (XVK && !FUSE), "DUO belongs to the XV-only plain instances");
     constexpr bool SPEC = NP > 0;
     constexpr int NT = 64 * (NW + NP);             // threads per workgroup
     constexpr int SW = SPEC ? NP : NW;             // waves that stage
@@ -113,9 +120,11 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     static_assert(KB % 2 == 0, "reduction block must hold an even number of kk");
     static_assert(A_FLOATS % 4 == 0, "A tile must be 16-byte granular");
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    const int sub = DUO ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // sub-workgroup (DUO), wave-uniform
+    float* const smem = DUO ? smem_all + sub * ((p.ep_off + 6 * BM + 3) & ~3) : smem_all;    // its half of the LDS
 
-    const int tid = threadIdx.x;
+    const int tid = DUO ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
@@ -149,6 +158,13 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     {
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    bool duo_dead = false;   // DUO: the second sub-workgroup of the last workgroup of an odd tile count repeats the last tile without storing
+    if constexpr (DUO) {
+        const int n_tiles = p.n_phase * p.n_co_tiles * p.B * p.n_t_tiles;
+        lin = 2 * lin + sub;
+        duo_dead = lin >= n_tiles;
+        lin = min(lin, n_tiles - 1);
     }
     // (integer division runs on the vector ALU: hand the wave-uniform results back to scalar registers)
     // Polyphase (transposed) launches: the stride phases of one output tile are adjacent in the order, so they run together on
@@ -669,6 +685,9 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     if constexpr (XVCAND && XR == 1) {
         if (use_xv && n_cb > 1) xv_issue(1);      // (block 0 came through the prologue; see the rotating schedule below)
     }
+    if constexpr (DUO) {
+        if (sub == 1) __syncthreads();            // the second sub-workgroup starts half a block late ...
+    }
     for (int cb = 0; cb < n_cb; ++cb) {
         const int cur = cb & 1;
         const float* Ac = As0 + cur * A_FLOATS + hi * BM + nc_a_lane_off<TM>(l31);
@@ -708,13 +727,14 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
 #if NC_STAGE_PRIO
             if (more) __builtin_amdgcn_s_setprio(NC_STAGE_PRIO);   // (experiment: the staging run at raised issue priority)
 #endif
+            if constexpr (DUO && seg == NSEG / 2) __syncthreads();   // the partner's block boundary
             if (more) {
                 if constexpr (XVCAND && XR == 1) {   // (the XV-only instances)
                     // rotating schedule: ONE register set.  At the head of segment NC_XV_STORE_SEG the words of block cb + 1 (in flight
                     // since the same point of the block before: a whole block of latency cover) go to the idle LDS buffers, and the
                     // reads of block cb + 2 are issued straight behind them (that block's buffers are the ones being read now, but its
                     // words stay in registers until this block's closing barrier has passed).
-                    if constexpr (seg == NC_XV_STORE_SEG) xv_stage(cb, An, Xn);
+                    if constexpr (seg == (DUO ? 0 : NC_XV_STORE_SEG)) xv_stage(cb, An, Xn);   // (DUO: the run opens the block, beside the partner's segments 2-3)
                 } else {
                     if constexpr (seg >= 1) store_group_any(cb + 1, An, Xn, std::integral_constant<int, (seg >= 1 ? seg - 1 : 0)>{});
                     if constexpr (seg < NG) issue_group(cb + 1, seg_tag);
@@ -742,11 +762,14 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp % (FD + 1)][i], fb[kp % (FD + 1)][j], acc[i][j], 0, 0, 0);
             });
         });
-        if constexpr (XVCAND && XR == 1 && NC_XV_STORE_SEG >= NSEG) {   // (experiment: the words written behind the block's last matrix-core step)
+        if constexpr (XVCAND && XR == 1 && NC_XV_STORE_SEG >= NSEG && !DUO) {   // (experiment: the words written behind the block's last matrix-core step)
             if (more && use_xv) xv_stage(cb, An, Xn);
         }
         NC_STAMP(cb, 7);
         __syncthreads();
+    }
+    if constexpr (DUO) {
+        if (sub == 0) __syncthreads();            // ... and the first passes the barrier once more at the end: equal counts
     }
     };
     if constexpr (XVK) {
@@ -787,7 +810,7 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
     for (int j = 0; j < TN; ++j) {
         const int col = col0 + wave * BNW + j * 32 + l31 - sgc[j] * flat_pc;   // column within its clip b + sgc[j]
         const int t = col * p.y_tstride + p.y_toff + phase;
-        const bool clip_ok = (col < p.n_cols) & (b + sgc[j] < p.Bc);
+        const bool clip_ok = (col < p.n_cols) & (b + sgc[j] < p.Bc) & !duo_dead;
         const unsigned clip_off = (unsigned)min(sgc[j], p.Bc - 1 - b) * (unsigned)p.y_bstride;   // (clamped: masked reads stay inside the tensor)
         if constexpr (SUB != 0) {   // t = sample of sub-row r = 0; row R adds (R + 4*hi) & smask.  Time bounds are checked per row.
             okc[j] = clip_ok;
@@ -1197,9 +1220,9 @@ __global__ __launch_bounds__(64 * (NW + NP), OCC) void conv_mfma_kernel(const Co
 typedef void (*conv_kernel_fn)(const ConvArgs);
 
 template <int TM, int TN, int K, int CB, int NX, bool FUSE = false, int OCC = 2, int NW = 4, int NP = 0, bool DIST = false, int SUB = 0,
-          bool IN2 = false, bool XVK = false>
+          bool IN2 = false, bool XVK = false, bool DUO = false>
 inline conv_kernel_fn get_conv_kernel() {
-    return &conv_mfma_kernel<TM, TN, K, CB, NX, FUSE, OCC, NW, NP, DIST, SUB, IN2, XVK>;
+    return &conv_mfma_kernel<TM, TN, K, CB, NX, FUSE, OCC, NW, NP, DIST, SUB, IN2, XVK, DUO>;
 }
 
 }  // namespace nc
@@ -1425,6 +1448,18 @@ inline conv_kernel_fn get_conv_kernel() {
             case 2: return get_conv_kernel<2, 2, KVAL, CBVAL, NXVAL, FUSEV, 2, 4, 0, false, SUBV, false, true>(); \
             case 3: return get_conv_kernel<3, 2, KVAL, CBVAL, NXVAL, FUSEV, 2, 4, 0, false, SUBV, false, true>(); \
             case 4: return get_conv_kernel<4, 2, KVAL, CBVAL, NXVAL, FUSEV, 2, 4, 0, false, SUBV, false, true>(); \
+        }                                                                                                  \
+        return nullptr;                                                                                    \
+    }                                                                                                      \
+    }
+
+// DUO instances (see DUO above): two tiles per workgroup of 8 wavefronts, the second half a block behind the first.
+#define NC_INSTANTIATE_CONV_DUO(NAME, KVAL, CBVAL, NXVAL, SUBV)                                            \
+    namespace nc {                                                                                         \
+    conv_kernel_fn conv_kernel_table_##NAME(int TM) {                                                      \
+        switch (TM) {                                                                                      \
+            case 2: return get_conv_kernel<2, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, SUBV, false, true, true>(); \
+            case 3: return get_conv_kernel<3, 2, KVAL, CBVAL, NXVAL, false, 2, 4, 0, false, SUBV, false, true, true>(); \
         }                                                                                                  \
         return nullptr;                                                                                    \
     }                                                                                                      \

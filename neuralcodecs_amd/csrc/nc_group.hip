@@ -393,6 +393,85 @@ void local_encode_allgather_dev(nc_group* g, int kind, const float* const* pcm, 
     }
 }
 
+// Encodec (Models/Encodec.cs:259-285): a rank's Encode emits, per segment, codes [B, n_q, T'_f] (laid end to end in segment order: the
+// nc_encodec_encode_dev layout) and a scale [B] per segment.  Both gather rank by rank: codes_all = [world][per-rank code block], scales_all
+// = [world][n_frames][B] -- two collectives on the side stream (the scales are 4 * n_frames * B bytes: nothing to pack).
+int64_t encodec_codes_per_clip(EncodecModel& m, int64_t T, int* n_frames) {
+    const auto segs = m.segments(T);
+    int64_t fr = 0;
+    for (auto& sg : segs) fr += sg.frames;
+    if (n_frames) *n_frames = (int)segs.size();
+    return (int64_t)m.n_q * fr;
+}
+
+void rank_encodec_allgather(nc_group* g, const float* pcm, int B, int64_t T, int64_t* codes_all, float* scales_all) {
+    if (!g || g->rank < 0) fail(NC_EINVAL, "group was not created with nc_group_create_rank");
+    if (!pcm || !codes_all || B <= 0 || T <= 0) fail(NC_EINVAL, "bad arguments");
+    nc_group::Member& x = g->m[0];
+    if (x.h->kind != 2) fail(NC_EINVAL, "handle is not an Encodec codec");
+    EncodecModel& m = static_cast<EncodecModel&>(*x.h->impl);
+    m.use_device();
+    int nf = 0;
+    const int64_t per_clip = encodec_codes_per_clip(m, T, &nf), per_rank = (int64_t)B * per_clip;
+    if (m.cfg.normalize && !scales_all) fail(NC_EINVAL, "this model normalises frames: scales_all must be given");
+    float* my_scales = scales_all ? scales_all + (int64_t)g->rank * nf * B : nullptr;
+    m.encode_dev(pcm, B, T, codes_all + (int64_t)g->rank * per_rank, my_scales, nullptr);
+    NC_HIP(hipEventRecord(x.ev_enc, m.stream));
+    NC_HIP(hipStreamWaitEvent(x.side, x.ev_enc, 0));
+    // (the per-rank block is segment-major, not one row per clip: it travels as B "rows" of per_clip values only for the packed payload's
+    //  row arithmetic -- any split into equal rows packs the same value sequence)
+    gather_slots(g, x, g->rank, codes_all, B, per_clip);
+    unpack_slots(g, x, codes_all, B, per_clip);
+    if (my_scales && m.cfg.normalize)
+        NC_RCCL(rccl().AllGather(my_scales, scales_all, (size_t)nf * B, ncclFloat, x.comm, x.side));
+    NC_HIP(hipEventRecord(x.ev_gather, x.side));
+}
+
+void local_encodec_allgather_dev(nc_group* g, const float* const* pcm, const int32_t* B_local, int64_t T, int64_t* const* codes_all,
+                                 float* const* scales_all) {
+    if (!g || g->rank >= 0) fail(NC_EINVAL, "group was not created with nc_group_create_local");
+    if (!pcm || !B_local || !codes_all || T <= 0) fail(NC_EINVAL, "bad arguments");
+    const int W = g->world;
+    int B = 0;
+    for (int d = 0; d < W; ++d) {
+        if (g->m[(size_t)d].h->kind != 2) fail(NC_EINVAL, "handle is not an Encodec codec");
+        if (!pcm[d] || !codes_all[d] || B_local[d] <= 0 || (d && B_local[d] != B_local[0])) fail(NC_EINVAL, "Encodec groups take equal, non-empty blocks (block %d)", d);
+    }
+    B = B_local[0];
+    EncodecModel& m0 = static_cast<EncodecModel&>(*g->m[0].h->impl);
+    int nf = 0;
+    const int64_t per_clip = encodec_codes_per_clip(m0, T, &nf), per_rank = (int64_t)B * per_clip;
+    const bool sc = m0.cfg.normalize;
+    if (sc && !scales_all) fail(NC_EINVAL, "this model normalises frames: scales_all must be given");
+    for (int d = 0; d < W; ++d) {
+        nc_group::Member& x = g->m[(size_t)d];
+        EncodecModel& m = static_cast<EncodecModel&>(*x.h->impl);
+        m.use_device();
+        m.encode_dev(pcm[d], B, T, codes_all[d] + (int64_t)d * per_rank, sc ? scales_all[d] + (int64_t)d * nf * B : nullptr, nullptr);
+        NC_HIP(hipEventRecord(x.ev_enc, m.stream));
+        NC_HIP(hipStreamWaitEvent(x.side, x.ev_enc, 0));
+    }
+    std::vector<int64_t*> slots(codes_all, codes_all + W);
+    grouped_gather(g, slots, B, per_clip);
+    if (sc) {
+        NC_RCCL(rccl().GroupStart());
+        ncclResult_t bad = ncclSuccess;
+        for (int d = 0; d < W && bad == ncclSuccess; ++d) {
+            nc_group::Member& x = g->m[(size_t)d];
+            if (hipSetDevice(x.device) != hipSuccess) { bad = ncclUnhandledCudaError; break; }
+            bad = rccl().AllGather(scales_all[d] + (int64_t)d * nf * B, scales_all[d], (size_t)nf * B, ncclFloat, x.comm, x.side);
+        }
+        const ncclResult_t end = rccl().GroupEnd();
+        if (bad != ncclSuccess || end != ncclSuccess) fail(NC_EDEVICE, "ncclAllGather of the frame scales failed: %s", rccl().GetErrorString(bad != ncclSuccess ? bad : end));
+    }
+    for (int d = 0; d < W; ++d) {
+        nc_group::Member& x = g->m[(size_t)d];
+        NC_HIP(hipSetDevice(x.device));
+        unpack_slots(g, x, codes_all[d], B, per_clip);
+        NC_HIP(hipEventRecord(x.ev_gather, x.side));
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -492,6 +571,15 @@ nc_status nc_group_dac_encode_allgather(nc_group* g, const float* pcm, int32_t B
 
 nc_status nc_group_snac_encode_allgather(nc_group* g, const float* pcm, int32_t B_total, int64_t T, int64_t* codes) {
     return guard([&] { local_encode_allgather(g, 1, pcm, B_total, T, 0, 0, codes, nullptr); });
+}
+
+nc_status nc_group_encodec_encode_allgather_dev(nc_group* g, const float* pcm, int32_t B_local, int64_t T, int64_t* codes_all, float* scales_all) {
+    return guard([&] { rank_encodec_allgather(g, pcm, B_local, T, codes_all, scales_all); });
+}
+
+nc_status nc_group_encodec_encode_allgather_local_dev(nc_group* g, const float* const* pcm, const int32_t* B_local, int64_t T, int64_t* const* codes_all,
+                                                      float* const* scales_all) {
+    return guard([&] { local_encodec_allgather_dev(g, pcm, B_local, T, codes_all, scales_all); });
 }
 
 nc_status nc_group_dac_encode_allgather_local_dev(nc_group* g, const float* const* pcm, const int32_t* B_local, int64_t T, int32_t sample_rate,

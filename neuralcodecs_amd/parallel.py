@@ -202,6 +202,57 @@ class Group:
         _lib.check(_lib.lib().nc_group_snac_encode_allgather_dev(self._g, x.data_ptr(), B, T, codes_all.data_ptr()))
         return codes_all, widths
 
+    def encodec_encode_allgather(self, pcm, codes_all=None, scales_all=None):
+        """Encodec, rank mode: pcm [B_local, C, T] (torch, cuda) -> (codes_all [world, B_local * n_q * sum T'_f] int64, scales_all
+        [world, n_frames, B_local] float32 or None, frame_lens, n_q).  encodec_frames(codes_all[r], scales_all[r], ...) gives rank r's
+        List<EncodedFrame> (Models/Encodec.cs:259-285) as views; call wait() before reading on the codec's stream."""
+        import torch
+        from . import _lib
+        m = self._codecs[0]
+        B, _, T = pcm.shape
+        n_frames, nq, frame_lens, _ = m.query(T)
+        per_rank = B * nq * sum(frame_lens)
+        x = pcm.contiguous().to(torch.float32)
+        if codes_all is None:
+            codes_all = torch.empty((self.world, per_rank), dtype=torch.int64, device=x.device)
+        if scales_all is None and m.config.normalize:
+            scales_all = torch.empty((self.world, n_frames, B), dtype=torch.float32, device=x.device)
+        m._bind_torch_stream()
+        _lib.check(_lib.lib().nc_group_encodec_encode_allgather_dev(self._g, x.data_ptr(), B, T, codes_all.data_ptr(),
+                                                                    scales_all.data_ptr() if scales_all is not None else None))
+        return codes_all, scales_all, frame_lens, nq
+
+    def encodec_encode_allgather_local(self, pcm_blocks):
+        """Encodec, local mode, device-resident equal blocks: returns (codes_all[d] [ndev, per_rank], scales_all[d] [ndev, n_frames, B] or None,
+        frame_lens, n_q) with one copy of the gathered tensors per device."""
+        import ctypes as C
+        import torch
+        from . import _lib
+        xs, nb, ptrs, T, bmax = self._local_ptr_arrays(pcm_blocks)
+        m0 = self._codecs[0]
+        n_frames, nq, frame_lens, _ = m0.query(T)
+        per_rank = bmax * nq * sum(frame_lens)
+        devs = [torch.device("cuda", m.device_index) for m in self._codecs]
+        codes_all = [torch.empty((self.world, per_rank), dtype=torch.int64, device=dv) for dv in devs]
+        scales_all = [torch.empty((self.world, n_frames, bmax), dtype=torch.float32, device=dv) for dv in devs] if m0.config.normalize else None
+        for m in self._codecs:
+            m._bind_torch_stream()
+        _lib.check(_lib.lib().nc_group_encodec_encode_allgather_local_dev(
+            self._g, ptrs, nb, T, (C.c_void_p * self.world)(*[t.data_ptr() for t in codes_all]),
+            (C.c_void_p * self.world)(*[t.data_ptr() for t in scales_all]) if scales_all is not None else None))
+        self._keep = (xs,)
+        return codes_all, scales_all, frame_lens, nq
+
+    @staticmethod
+    def encodec_frames(codes_block, scales_block, B, n_q, frame_lens):
+        """One rank's block of the gathered tensors -> its frames [(codes [B, n_q, T'_f], scale [B, 1] or None), ...] as views."""
+        out, o = [], 0
+        for f, fl in enumerate(frame_lens):
+            n = B * n_q * fl
+            out.append((codes_block[o:o + n].view(B, n_q, fl), None if scales_block is None else scales_block[f].view(B, 1)))
+            o += n
+        return out
+
     def wait(self):
         from . import _lib
         _lib.check(_lib.lib().nc_group_wait(self._g))

