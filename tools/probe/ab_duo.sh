@@ -1,3 +1,7 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (round 5; needs NC_MI355X_LIB=<the EXPERIMENTS=1 library> since the DUO instances moved there): parity suites under
+# NC_DUO=1, then the headline class table and two k = 7 layers (tools/convbench.py), default against NC_DUO=1, three interleaved rounds.
+# Output: gpurun_out/ab_duo.txt (profiles/r05_ab_duo.txt is the run that rejected the form).
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/ab_duo.txt; : > $OUT
 echo "== parity NC_DUO=1" | tee -a $OUT

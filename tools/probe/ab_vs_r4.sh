@@ -1,3 +1,8 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (round 5): same-box A/B of this build against an OLDER build of the library (build_abl/lib_r4.so: check the old commit out
+# into a worktree, `make -C neuralcodecs_amd/csrc`, copy its libnc_mi355x.so there; the Python loader skips exports the old library lacks when
+# NC_MI355X_LIB is set) and against this build's own fallback switches: parity suites, then the headline class table and the other
+# configurations' step times, three interleaved rounds.  Output: gpurun_out/ab_xvk.txt (profiles/r05_ab_xvk_vs_r4.txt is one such run).
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/ab_xvk.txt; : > $OUT
 for setting in NC_DEFAULT=1 NC_XV_K7=1; do
