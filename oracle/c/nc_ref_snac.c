@@ -417,7 +417,7 @@ REF_API int ref_snac_decode(ref_snac* m, const float* zq, int64_t B, int64_t Tz,
     snprintf(nm, sizeof nm, "decoder.model.%d.alpha", n);
     x = snake_apply(m, nm, x, B, C, L, 1);
     snprintf(nm, sizeof nm, "decoder.model.%d", n + 1);
-    int64_t Lo; int Co;
+    int64_t Lo = 0; int Co = 0;   // (set by conv_apply)
     float* y = conv_apply(m, nm, x, B, C, L, 1, 3, 1, 1, NULL, &Lo, &Co, 1);
     ref_tanh(y, B * Lo, pcm);
     free(y);
