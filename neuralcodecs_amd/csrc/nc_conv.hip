@@ -331,7 +331,7 @@ struct TileChoice {
     const float* w;
     int64_t w_phase_stride;
 };
-static TileChoice choose_tile(const ConvLayer& L, int64_t blocks_per_rowtile, bool pointwise_fast) {
+static TileChoice choose_tile(const ConvLayer& L, int64_t blocks_per_rowtile, bool pointwise_fast, bool xv_cand = false) {
     auto cost = [&](const TileCfg& c) {
         const int n_co = (L.rows() + c.BM() - 1) / c.BM();
         const double blocks = (double)blocks_per_rowtile * n_co;
@@ -351,7 +351,7 @@ static TileChoice choose_tile(const ConvLayer& L, int64_t blocks_per_rowtile, bo
         // staging (tools/probe/tm_pick_up.sh, one box): 192 -> 96 at 32 x 22 272 columns 1079 us with 96-row tiles, 980 with 64-row tiles
         // (SNAC's at 8 x 110 592: 1318 / 1200); 384 -> 192: 1943 / 1834; from 768 input channels on the 96-row tiles win (2119 / 2215).
         static const bool xv_off = env_flag("NC_NO_XV") || env_flag("NC_NO_XR");   // (the legacy 64-row instance does not win: conv_up 5.94 -> 6.15 ms)
-        if (!xv_off && L.sub_stride && c.K == 2 && c.TM == 2 && L.Cin <= 384) inst = 0.88;
+        if (xv_cand && !xv_off && L.sub_stride && c.K == 2 && c.TM == 2 && L.Cin <= 384) inst = 0.88;   // (xv_cand: this launch takes the XV-only instance)
         return rounds * bpc * c.TM * pen[c.TM] * inst;
     };
     TileChoice best{L.cfg, L.w.as<float>(), L.w_phase_stride};
@@ -645,7 +645,10 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     if (launch_conv3_stream(L, io, B, stream, prof)) return;
     const int64_t n_cols_all = L.transposed ? io.Tin + L.Ktaps - 1 : Tout;
     TileChoice tsel{L.cfg, L.w.as<float>(), L.w_phase_stride};
-    if (!io.fuse_k1) tsel = choose_tile(L, (int64_t)L.n_phase * B * ((n_cols_all + 255) / 256), false);
+    // (launches that will take the XV-only two-tap instance: plain input, aligned rows -- the rest of its conditions are checked below)
+    const bool xv_cand = L.sub_stride && L.n_phase == 1 && !io.in_stats && !io.in_elu && io.in_L == 0 && !io.x2 && !io.alpha_in && !io.gn_part &&
+                         io.x_len % 4 == 0 && io.x_cstride % 4 == 0 && io.x_bstride % 4 == 0;
+    if (!io.fuse_k1) tsel = choose_tile(L, (int64_t)L.n_phase * B * ((n_cols_all + 255) / 256), false, xv_cand);
     else
         for (const auto& alt : L.alts)   // the fused residual unit needs the tile that spans all channels
             if (alt->cfg.BM() == L.Cout) tsel = TileChoice{alt->cfg, alt->w.as<float>(), alt->w_phase_stride};
