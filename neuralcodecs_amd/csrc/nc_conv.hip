@@ -55,13 +55,11 @@ static conv_kernel_fn conv_kernel_table_spec_k7(int, int) { return nullptr; }
 static conv_kernel_fn conv_kernel_table_dist_k7(int, int) { return nullptr; }
 static int experiment_mode(const char*) { return 0; }
 #endif
-#ifdef NC_EXPERIMENTS   // XV-only k = 7 instances: bit-exact, measured NEUTRAL against the legacy instances: EXPERIMENTS=1 builds
 conv_kernel_fn conv_kernel_table_xv_k7(int);
 conv_kernel_fn conv_kernel_table_xv_fused_k7(int);
-conv_kernel_fn conv_kernel_table_duo_k7(int);   // (their DUO form, NC_DUO=1: bit-exact, 6 % slower on the k = 7 class)
+#ifdef NC_EXPERIMENTS
+conv_kernel_fn conv_kernel_table_duo_k7(int);   // (the DUO form of the XV-only k = 7 instances, NC_DUO=1: bit-exact, 6 % slower on the k = 7 class)
 #else
-static conv_kernel_fn conv_kernel_table_xv_k7(int) { return nullptr; }
-static conv_kernel_fn conv_kernel_table_xv_fused_k7(int) { return nullptr; }
 static conv_kernel_fn conv_kernel_table_duo_k7(int) { return nullptr; }
 #endif
 conv_kernel_fn conv_kernel_table_xv_sub_k2(int);
@@ -851,11 +849,11 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         // start on 16-byte boundaries (xneg is raised by up to 3 slots for that: the window still fits its 320-slot pitch), whole float4s
         static const bool no_xv = env_flag("NC_NO_XV");
         static const bool no_xr = env_flag("NC_NO_XR");
-#ifdef NC_EXPERIMENTS
-        static const bool xv_k7 = env_flag("NC_XV_K7");
-#else
-        constexpr bool xv_k7 = false;
-#endif
+        // k = 7: the XV-only instances win on the LONG rows (per layer, profiles/r05_xvk7_per_layer.txt: C = 192 at 22 272 steps 2921 ->
+        // 2836 us, C = 384 at 5568 2884 -> 2818, the fused C = 64 / 96 / 128 units -2.4 / -1.2 / -0.5 %) and lose on the 696-step rows that keep
+        // one-clip tiles (two of a clip's three tiles are edge tiles: C = 768 d = 9 1622 -> 2015 us): taken from 2048 columns per clip on.
+        static const bool no_xv_k7 = env_flag("NC_NO_XV_K7");
+        const bool xv_k7 = !no_xv_k7 && n_cols_all >= 2048;
         const bool two_tap = L.sub_stride && L.n_phase == 1 && c.K == 2 && c.CB == 16 && !io.alpha_in && !io.fuse_k1;
 #ifdef NC_EXPERIMENTS
         static const bool duo_env = env_flag("NC_DUO");

@@ -108,14 +108,14 @@ FALLBACK_ROWS = [
     {"NC_NO_XR": "1"},                                                                 # generic fragment addressing in the conv template
     {"NC_PW_STREAM": "1"},                                                             # EXPERIMENTS=1 library: streaming pointwise kernel
     {"NC_NO_XV": "1"},                                                                 # legacy instances for the two-tap up-convolutions (item-form staging)
-    {"NC_XV_K7": "1"},                                                                 # EXPERIMENTS=1 library: XV-only k = 7 instances
+    {"NC_NO_XV_K7": "1"},                                                              # legacy instances for the k = 7 convolutions on the long rows
     {"NC_DUO": "1"},                                                                   # EXPERIMENTS=1 library: two tiles per 8-wavefront workgroup (k = 7)
 ]
 
 
 # Switches of measured-and-rejected kernels: compiled by `make -C neuralcodecs_amd/csrc EXPERIMENTS=1` only (libnc_mi355x_exp.so, round 5:
 # the shipped library carries shipped paths only).  Rows that name one run against that library when it has been built, and skip otherwise.
-EXPERIMENT_SWITCHES = {"NC_LSTM_FUSED", "NC_LSTM_SPLIT", "NC_PW_STREAM", "NC_RVQ_8WAVES", "NC_LIGHT", "NC_WIDE", "NC_SPEC", "NC_DIST", "NC_XV_K7", "NC_DUO"}
+EXPERIMENT_SWITCHES = {"NC_LSTM_FUSED", "NC_LSTM_SPLIT", "NC_PW_STREAM", "NC_RVQ_8WAVES", "NC_LIGHT", "NC_WIDE", "NC_SPEC", "NC_DIST", "NC_DUO"}
 EXP_LIB = os.path.join(ROOT, "neuralcodecs_amd", "libnc_mi355x_exp.so")
 
 

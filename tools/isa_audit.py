@@ -117,6 +117,9 @@ HOT = [
     ("nc_conv_xv2.o", r"conv_mfma_kernelILi3ELi2ELi2ELi16ELi20ELb0ELi2ELi4ELi0ELb0ELi1ELb0ELb1ELb0E", "XV-only two-tap up-convolution, 96 x 256 tiles (DAC 768 -> 384)"),
     ("nc_conv_xv2.o", r"conv_mfma_kernelILi4ELi2ELi2ELi16ELi20ELb0ELi2ELi4ELi0ELb0ELi1ELb0ELb1ELb0E", "XV-only two-tap up-convolution, 128 x 256 tiles (SNAC 1536 -> 768, 768 -> 384)"),
     ("nc_conv_xv2g.o", r"conv_mfma_kernelILi3ELi2ELi2ELi16ELi20ELb0ELi2ELi4ELi0ELb0ELi2ELb0ELb1ELb0E", "XV-only two-tap up-convolution, any stride (SNAC stride 3)"),
+    ("nc_conv_xv7.o", r"conv_mfma_kernelILi3ELi2ELi7ELi8ELi10ELb0ELi2ELi4ELi0ELb0ELi0ELb0ELb1ELb0E", "XV-only k = 7, 96 x 256 tiles (DAC C = 192 / 384 long rows)"),
+    ("nc_conv_xv7f.o", r"conv_mfma_kernelILi3ELi2ELi7ELi8ELi10ELb1ELi2ELi4ELi0ELb0ELi0ELb0ELb1ELb0E", "XV-only fused residual unit C = 96"),
+    ("nc_conv_xv7f.o", r"conv_mfma_kernelILi2ELi2ELi7ELi8ELi10ELb1ELi2ELi4ELi0ELb0ELi0ELb0ELb1ELb0E", "XV-only fused residual unit C = 64"),
     ("nc_conv_k4.o", r"conv_mfma_kernelILi4ELi2ELi4ELi8ELi18ELb0ELi2ELi4ELi0ELb0ELi0ELb0E", "k = 4 stride-2 down-convolution (DAC 64 -> 128)"),
     ("nc_conv_k8.o", r"conv_mfma_kernelILi4ELi2ELi8ELi4ELi18ELb0ELi2ELi4ELi0ELb0ELi0ELb0E", "k = 8 stride-4 down-convolution (DAC 128 -> 256)"),
     ("nc_conv_k16.o", r"conv_mfma_kernelILi4ELi2ELi16ELi2ELi18ELb0ELi2ELi4ELi0ELb0ELi0ELb0E", "k = 16 stride-8 down-convolution (SNAC 44 kHz, long rows)"),

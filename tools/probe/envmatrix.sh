@@ -42,9 +42,9 @@ run NC_SNAC_FUSE_MIN_COLS=0 NC_LN_TILE=16
 run NC_SYNC_ACQUIRE=1
 run NC_NO_XR=1
 run NC_NO_XV=1
+run NC_NO_XV_K7=1
 # round 5: the experiments library (measured-and-rejected kernels)
 expl NC_LSTM_FUSED=1 NC_RVQ_8WAVES=1
 expl NC_LSTM_SPLIT=1
 expl NC_PW_STREAM=1
-expl NC_XV_K7=1
 expl NC_DUO=1
