@@ -21,6 +21,9 @@
 #ifndef NC_STAGE_PRIO
 #define NC_STAGE_PRIO 0     // experiment: s_setprio of the staging runs of the segmented pipeline (0 = leave the priority alone)
 #endif
+#ifndef NC_XV_FD
+#define NC_XV_FD 1          // XV-only instances: fragment prefetch depth (experiment: 2)
+#endif
 #ifndef NC_XV_STORE_SEG
 #define NC_XV_STORE_SEG 3   // XV staging: the block's one staging run sits at the head of this matrix-core segment (0 .. 3; 4 = behind the last).
 #endif                      // Measured on one box (DAC conv_up class, ms per step): item form 6.54; XV at segment 1 / 2: 6.52 (no gain); at
@@ -541,7 +544,7 @@ __global__ __launch_bounds__((DUO ? 2 : 1) * 64 * (NW + NP), DUO ? 1 : OCC) void
         xt[k] = x_lane + (hi ? d : 0);
     }
 
-    constexpr int FD = 1;            // fragment reads run FD matrix-core steps ahead (FD + 1 register sets)
+    constexpr int FD = XVK ? NC_XV_FD : 1;   // fragment reads run FD matrix-core steps ahead (FD + 1 register sets)
     float fa[FD + 1][TM], fb[FD + 1][TN];
     // Ac = current weight buffer + hi*BM (the kk row of this lane half at step 0); xsc = scalar float index of the current window
     // Constant row pitch (XR, round 4): the k = 7 instances with 256-column tiles always stage 5 chunks of 64 slots per channel (a
@@ -754,6 +757,9 @@ __global__ __launch_bounds__((DUO ? 2 : 1) * 64 * (NW + NP), DUO ? 1 : OCC) void
             nc_static_for<kp_hi - kp_lo>([&](auto d) __attribute__((always_inline)) {
                 constexpr int kp = kp_lo + decltype(d)::value;
                 if constexpr (kp + FD < KP) load_frag_x(Ac, Xc, std::integral_constant<int, kp + FD>{}, xr_tag);
+#if defined(NC_XV_NOSB)
+                if constexpr (!XVK)
+#endif
                 __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of step kp+1 ahead of the MFMAs of step kp
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
