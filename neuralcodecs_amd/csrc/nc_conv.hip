@@ -849,11 +849,13 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         // start on 16-byte boundaries (xneg is raised by up to 3 slots for that: the window still fits its 320-slot pitch), whole float4s
         static const bool no_xv = env_flag("NC_NO_XV");
         static const bool no_xr = env_flag("NC_NO_XR");
-        // k = 7: the XV-only instances win on the LONG rows (per layer, profiles/r05_xvk7_per_layer.txt: C = 192 at 22 272 steps 2921 ->
-        // 2836 us, C = 384 at 5568 2884 -> 2818, the fused C = 64 / 96 / 128 units -2.4 / -1.2 / -0.5 %) and lose on the 696-step rows that keep
-        // one-clip tiles (two of a clip's three tiles are edge tiles: C = 768 d = 9 1622 -> 2015 us): taken from 2048 columns per clip on.
+        // k = 7: the XV-only instances are worth 1.4-2.9 % per layer wherever the rows start on 64-byte boundaries (row pitch a multiple of 16
+        // samples) and LOSE 25 % where they do not: C = 768 at 696 steps (2784-byte rows: every other channel row starts 32 bytes into a
+        // 64-byte sector) 1632 -> 2038 us, at 704 steps 1601 -> 1577, at 1024 2104 -> 2041, at 5568 11 254 -> 10 943
+        // (tools/probe/xvk7_rows.py, profiles/r05_xvk7_rows.txt): the 8-byte vector loads are that sensitive, the legacy dword loads are not.
         static const bool no_xv_k7 = env_flag("NC_NO_XV_K7");
-        const bool xv_k7 = !no_xv_k7 && n_cols_all >= 2048;
+        static const int64_t xv_k7_min = env_int("NC_XV_K7_MIN_COLS", 0);
+        const bool xv_k7 = !no_xv_k7 && n_cols_all >= xv_k7_min;
         const bool two_tap = L.sub_stride && L.n_phase == 1 && c.K == 2 && c.CB == 16 && !io.alpha_in && !io.fuse_k1;
 #ifdef NC_EXPERIMENTS
         static const bool duo_env = env_flag("NC_DUO");
@@ -865,7 +867,7 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
         const int vw = two_tap ? 4 : 2;   // floats per staged word
         if (!no_xv && !no_xr && (two_tap || k7) && c.TN == 2 && c.NW == 4 && c.TM >= 2 && c.TM <= 4 && !narrow && !flat && !dist_small_fn && !n_prod &&
             !light && !wide && !dist && !slim && !in_mode && !io.x2 && !io.gn_part && sx == 1 && L.Cin % c.CB == 0 && io.x_len % vw == 0 &&
-            io.x_cstride % vw == 0 && io.x_bstride % vw == 0 && (reinterpret_cast<uintptr_t>(io.x) & 15) == 0) {
+            io.x_cstride % 16 == 0 && io.x_bstride % 16 == 0 && (reinterpret_cast<uintptr_t>(io.x) & 63) == 0) {   // (rows on 64-byte boundaries: see above)
             xv_extra = (vw - (a.pad + a.xneg) % vw) % vw;
             if ((BN - 1) * sx + (L.Ktaps - 1) * ad + 1 + xv_extra <= 320) {
                 xv_fn = two_tap ? (L.sub_shift ? conv_kernel_table_xv_sub_k2(c.TM) : conv_kernel_table_xv_subg_k2(c.TM))

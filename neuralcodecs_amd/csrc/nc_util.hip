@@ -31,6 +31,7 @@ const EnvRow kEnv[] = {
     {"NC_NO_XR", 'b', "generic B-fragment addressing in the conv template (no constant-pitch immediate offsets)"},
     {"NC_NO_XV", 'b', "legacy instances with item-wise window staging everywhere (no XV-only instances)"},
     {"NC_DUO", 'b', "EXPERIMENTS=1 builds: k = 7 residual-unit convolutions as DUO instances (two tiles per 8-wavefront workgroup, the second half a block behind; measured slower)"},
+    {"NC_XV_K7_MIN_COLS", 'i', "columns per clip from which the k = 7 convolutions take the XV-only instances (0: wherever the rows are 64-byte aligned)"},
     {"NC_NO_XV_K7", 'b', "legacy instances for the k = 7 residual-unit convolutions (no XV-only instances on the long rows)"},
     {"NC_NO_NARROW", 'b', "no 3-wave narrow variants"},
     {"NC_NO_SLIM", 'b', "no half-size reduction blocks for narrow long rows"},
