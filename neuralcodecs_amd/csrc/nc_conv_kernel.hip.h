@@ -21,6 +21,9 @@
 #ifndef NC_STAGE_PRIO
 #define NC_STAGE_PRIO 0     // experiment: s_setprio of the staging runs of the segmented pipeline (0 = leave the priority alone)
 #endif
+#ifndef NC_XV_SNAKE_ON   // 0 = timing probe only (WRONG results): what the staging Snake costs in total
+#define NC_XV_SNAKE_ON 1
+#endif
 #ifndef NC_XV_FD
 #define NC_XV_FD 1          // XV-only instances: fragment prefetch depth (experiment: 2)
 #endif
@@ -324,11 +327,11 @@ __global__ __launch_bounds__((DUO ? 2 : 1) * 64 * (NW + NP), DUO ? 1 : OCC) void
                 xv_t v = rxv[n];
                 if constexpr (!decltype(allok_tag)::value)
                     if (!((xvok >> n) & 1u)) v = xv_t(0.0f);
-                if constexpr (K == 7 && decltype(snake_tag)::value) {   // Snake of the consumed tensor (snake(0) == 0: the zero padding survives it)
+                if constexpr (K == 7 && NC_XV_SNAKE_ON && decltype(snake_tag)::value) {   // Snake of the consumed tensor (snake(0) == 0: the zero padding survives it)
                     const float2 al = Al[cbn * CB + xvc[n]];
-                    float v0 = v[0], v1 = v[1];
-                    nc_snake_pair(v0, v1, al.x, al.y, al.x, al.y);
-                    v[0] = v0; v[1] = v1;
+                    // the sine up to its sign ((-s)^2 == s^2 exactly: bit-identical, 8 of the ~25 instructions of a pair fewer; nc_math.h)
+                    const nc_f2 sm = nc_snakef2_m(nc_f2{v[0], v[1]}, nc_f2{al.x, al.x}, nc_f2{al.y, al.y});
+                    v[0] = sm[0]; v[1] = sm[1];
                 }
                 if ((XVN % NT == 0) || tid + NT * n < XVN) reinterpret_cast<xv_t*>(Xd)[tid + NT * n] = v;
             }
@@ -921,7 +924,10 @@ __global__ __launch_bounds__((DUO ? 2 : 1) * 64 * (NW + NP), DUO ? 1 : OCC) void
                     const int R = ib * 32 + rr + 8 * rq + 4 * hi;
                     const float a0 = ao_t[R], i0 = ao_t[BM + R], a1 = ao_t[R + 1], i1 = ao_t[BM + R + 1];
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) nc_snake_pair(vq[rr][j], vq[rr + 1][j], a0, i0, a1, i1);
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (XVK) nc_snake_pair_m(vq[rr][j], vq[rr + 1][j], a0, i0, a1, i1);   // (sign-free sine: nc_math.h)
+                        else nc_snake_pair(vq[rr][j], vq[rr + 1][j], a0, i0, a1, i1);
+                    }
                 }
             }
 #pragma unroll
@@ -1097,7 +1103,8 @@ __global__ __launch_bounds__((DUO ? 2 : 1) * 64 * (NW + NP), DUO ? 1 : OCC) void
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     float x0 = acc[i][j][r] + b0, x1 = acc[i][j][r + 1] + b1;
-                    nc_snake_pair(x0, x1, a0, i0, a1, i1);
+                    if constexpr (XVK) nc_snake_pair_m(x0, x1, a0, i0, a1, i1);
+                    else nc_snake_pair(x0, x1, a0, i0, a1, i1);
                     acc[i][j][r] = x0;
                     acc[i][j][r + 1] = x1;
                 }

@@ -115,8 +115,9 @@ __device__ __forceinline__ nc_f2 nc_snakef2(nc_f2 x, nc_f2 alpha, nc_f2 inv) {
 }
 // The same Snake with the sine taken up to its sign: (-s) * (-s) == s * s exactly in IEEE-754, so the parity select of nc_sinf2 (two
 // conversions, masks, compares and selects: 8 of the ~30 vector instructions of a pair) is dead weight under the square -- bit-identical
-// to nc_snakef2.  Used by the vector-ALU-bound SNAC kernels (depthwise convolution, fused residual unit); the conv template keeps
-// nc_snakef2: there the shorter form measured 0.3 ms SLOWER on the DAC step.
+// to nc_snakef2.  Used by the vector-ALU-bound SNAC kernels (depthwise convolution, fused residual unit) and, from round 5, by the
+// XV-only instances of the conv template (staging and epilogue: -0.35 ms on the DAC step); the legacy instances keep nc_snakef2: there the
+// shorter form measured 0.3 ms SLOWER, and in the pointwise kernel it is neutral (round 5).
 __device__ __forceinline__ nc_f2 nc_snakef2_m(nc_f2 x, nc_f2 alpha, nc_f2 inv) {
     const nc_f2 ax = alpha * x;
     const nc_f2 n = __builtin_elementwise_rint(ax * 0x1.45f306p-2f);
@@ -133,6 +134,11 @@ __device__ __forceinline__ nc_f2 nc_snakef2_m(nc_f2 x, nc_f2 alpha, nc_f2 inv) {
     return x + (s * s) * inv;
 }
 // in-place on two scalars
+__device__ __forceinline__ void nc_snake_pair_m(float& x0, float& x1, float a0, float i0, float a1, float i1) {
+    const nc_f2 r = nc_snakef2_m(nc_f2{x0, x1}, nc_f2{a0, a1}, nc_f2{i0, i1});
+    x0 = r[0];
+    x1 = r[1];
+}
 __device__ __forceinline__ void nc_snake_pair(float& x0, float& x1, float a0, float i0, float a1, float i1) {
     const nc_f2 r = nc_snakef2(nc_f2{x0, x1}, nc_f2{a0, a1}, nc_f2{i0, i1});
     x0 = r[0];
