@@ -21,6 +21,9 @@
 #ifndef NC_STAGE_PRIO
 #define NC_STAGE_PRIO 0     // experiment: s_setprio of the staging runs of the segmented pipeline (0 = leave the priority alone)
 #endif
+#ifndef NC_XV_SNAKE_ILV  // 1 = the Snake chains of a staging run step by step side by side (0: word by word, the round-5 first form)
+#define NC_XV_SNAKE_ILV 1
+#endif
 #ifndef NC_XV_SNAKE_ON   // 0 = timing probe only (WRONG results): what the staging Snake costs in total
 #define NC_XV_SNAKE_ON 1
 #endif
@@ -322,18 +325,37 @@ __global__ __launch_bounds__((DUO ? 2 : 1) * 64 * (NW + NP), DUO ? 1 : OCC) void
 #pragma unroll
             for (int n = 0; n < NA; ++n)
                 if ((A_VEC % SNT == 0) || stid + SNT * n < A_VEC) reinterpret_cast<f32x4*>(Ad)[stid + SNT * n] = rav[n];
+            if constexpr (K == 7 && NC_XV_SNAKE_ON && NC_XV_SNAKE_ILV && decltype(snake_tag)::value) {
+                // Snake of the consumed tensor (snake(0) == 0: the zero padding survives it), the sine up to its sign ((-s)^2 == s^2 exactly:
+                // bit-identical, 8 of the ~25 instructions of a pair fewer; nc_math.h), and the NV words' chains STEP BY STEP side by side:
+                // read -> chain -> store word by word made every packed instruction wait on the one before it (an `s_nop` between each
+                // pair: 75 in a staging run) because the LDS store of one word orders the alpha read of the next behind it
+                nc_f2 xv[NV], a[NV], iv[NV];
+#pragma unroll
+                for (int n = 0; n < NV; ++n) {
+                    const float2 al = Al[cbn * CB + xvc[n]];
+                    a[n] = nc_f2{al.x, al.x}; iv[n] = nc_f2{al.y, al.y};
+                    xv[n] = nc_f2{rxv[n][0], rxv[n][1]};
+                    if constexpr (!decltype(allok_tag)::value)
+                        if (!((xvok >> n) & 1u)) xv[n] = nc_f2{0.0f, 0.0f};
+                }
+                nc_snakef2_m_rows<NV>(xv, a, iv);
+#pragma unroll
+                for (int n = 0; n < NV; ++n)
+                    if ((XVN % NT == 0) || tid + NT * n < XVN) reinterpret_cast<xv_t*>(Xd)[tid + NT * n] = xv_t{xv[n][0], xv[n][1]};
+            } else {
 #pragma unroll
             for (int n = 0; n < NV; ++n) {
                 xv_t v = rxv[n];
                 if constexpr (!decltype(allok_tag)::value)
                     if (!((xvok >> n) & 1u)) v = xv_t(0.0f);
-                if constexpr (K == 7 && NC_XV_SNAKE_ON && decltype(snake_tag)::value) {   // Snake of the consumed tensor (snake(0) == 0: the zero padding survives it)
+                if constexpr (K == 7 && NC_XV_SNAKE_ON && decltype(snake_tag)::value) {
                     const float2 al = Al[cbn * CB + xvc[n]];
-                    // the sine up to its sign ((-s)^2 == s^2 exactly: bit-identical, 8 of the ~25 instructions of a pair fewer; nc_math.h)
                     const nc_f2 sm = nc_snakef2_m(nc_f2{v[0], v[1]}, nc_f2{al.x, al.x}, nc_f2{al.y, al.y});
                     v[0] = sm[0]; v[1] = sm[1];
                 }
                 if ((XVN % NT == 0) || tid + NT * n < XVN) reinterpret_cast<xv_t*>(Xd)[tid + NT * n] = v;
+            }
             }
         }
     };

@@ -133,6 +133,37 @@ __device__ __forceinline__ nc_f2 nc_snakef2_m(nc_f2 x, nc_f2 alpha, nc_f2 inv) {
     const nc_f2 s = nc_fma2(r * u, p, r);
     return x + (s * s) * inv;
 }
+// N independent pairs, the chain written step by step ACROSS the pairs: every packed instruction is followed by N - 1 independent ones, so
+// none waits on its predecessor (pair by pair the compiler puts an `s_nop` between each two instructions of a chain).  Same operations
+// per element in the same order as nc_snakef2_m: bit-identical.
+template <int N>
+__device__ __forceinline__ void nc_snakef2_m_rows(nc_f2 (&x)[N], const nc_f2 (&alpha)[N], const nc_f2 (&inv)[N]) {
+    nc_f2 ax[N], n[N], r[N], u[N], p[N], s[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) ax[i] = alpha[i] * x[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) n[i] = __builtin_elementwise_rint(ax[i] * 0x1.45f306p-2f);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = nc_fma2(n[i], (nc_f2)(-3.140625f), ax[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = nc_fma2(n[i], (nc_f2)(-9.67502593994140625e-4f), r[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = nc_fma2(n[i], (nc_f2)(-1.509957990978376432e-7f), r[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) u[i] = r[i] * r[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = nc_fma2((nc_f2)(-0x1.9d5778p-26f), u[i], (nc_f2)(0x1.71936ap-19f));
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = nc_fma2(p[i], u[i], (nc_f2)(-0x1.a018f4p-13f));
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = nc_fma2(p[i], u[i], (nc_f2)(0x1.111110p-7f));
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = nc_fma2(p[i], u[i], (nc_f2)(-0x1.555556p-3f));
+#pragma unroll
+    for (int i = 0; i < N; ++i) s[i] = nc_fma2(r[i] * u[i], p[i], r[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = x[i] + (s[i] * s[i]) * inv[i];
+}
 // in-place on two scalars
 __device__ __forceinline__ void nc_snake_pair_m(float& x0, float& x1, float a0, float i0, float a1, float i1) {
     const nc_f2 r = nc_snakef2_m(nc_f2{x0, x1}, nc_f2{a0, a1}, nc_f2{i0, i1});
