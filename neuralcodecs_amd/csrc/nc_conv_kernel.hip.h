@@ -940,6 +940,23 @@ __global__ __launch_bounds__((DUO ? 2 : 1) * 64 * (NW + NP), DUO ? 1 : OCC) void
             for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) vq[rr][j] = v[j][4 * rq + rr];
+            if constexpr (XVK && NC_XV_SNAKE_ILV) {   // (XV-only instances: sign-free sine, the 2 x TN chains step by step side by side)
+                if (snake) {
+                    nc_f2 xs[2 * TN], as[2 * TN], is[2 * TN];
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int R = ib * 32 + 2 * h2 + 8 * rq + 4 * hi;
+                        const nc_f2 a = {ao_t[R], ao_t[R + 1]}, iv = {ao_t[BM + R], ao_t[BM + R + 1]};
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) { xs[h2 * TN + j] = nc_f2{vq[2 * h2][j], vq[2 * h2 + 1][j]}; as[h2 * TN + j] = a; is[h2 * TN + j] = iv; }
+                    }
+                    nc_snakef2_m_rows<2 * TN>(xs, as, is);
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) { vq[2 * h2][j] = xs[h2 * TN + j][0]; vq[2 * h2 + 1][j] = xs[h2 * TN + j][1]; }
+                }
+            } else
             if (snake) {   // Snake of the consuming layer, two rows per packed instruction (nc_math.h)
 #pragma unroll
                 for (int rr = 0; rr < 4; rr += 2) {
@@ -1115,6 +1132,34 @@ __global__ __launch_bounds__((DUO ? 2 : 1) * 64 * (NW + NP), DUO ? 1 : OCC) void
         //      D registers holding rows (2m, 2m+1) of one lane half into the B operands of k-steps m and m+2.
         static_assert(!FUSE || K == 7, "the fused tail belongs to the k=7 residual-unit convolution");
         // 1) h = snake(h_pre + b7, a2), in place
+        if constexpr (XVK && NC_XV_SNAKE_ILV) {   // (XV-only instances: sign-free sine, eight chains step by step side by side -- pair by
+                                                  //  pair the compiler serialises them with an `s_nop` between every two instructions)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int rg = 0; rg < 16; rg += 8) {
+                    nc_f2 xs[4 * TN], as[4 * TN], is[4 * TN];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = rg + 2 * q;
+                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const nc_f2 b = {Ep[row], Ep[row + 1]}, a = {Ep[BM + row], Ep[BM + row + 1]}, iv = {Ep[2 * BM + row], Ep[2 * BM + row + 1]};
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            xs[q * TN + j] = nc_f2{acc[i][j][r], acc[i][j][r + 1]} + b;
+                            as[q * TN + j] = a; is[q * TN + j] = iv;
+                        }
+                    }
+                    nc_snakef2_m_rows<4 * TN>(xs, as, is);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            acc[i][j][rg + 2 * q] = xs[q * TN + j][0];
+                            acc[i][j][rg + 2 * q + 1] = xs[q * TN + j][1];
+                        }
+                }
+        } else
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
