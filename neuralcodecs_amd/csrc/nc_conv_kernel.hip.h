@@ -21,6 +21,9 @@
 #ifndef NC_STAGE_PRIO
 #define NC_STAGE_PRIO 0     // experiment: s_setprio of the staging runs of the segmented pipeline (0 = leave the priority alone)
 #endif
+#ifndef NC_LEGACY_ROWS   // staging Snake of the legacy instances: 2 = sign-free chains side by side (shipped), 1 = side by side with the parity select, 0 = pair by pair
+#define NC_LEGACY_ROWS 2
+#endif
 #ifndef NC_XV_SNAKE_ILV  // 1 = the Snake chains of a staging run step by step side by side (0: word by word, the round-5 first form)
 #define NC_XV_SNAKE_ILV 1
 #endif
@@ -453,6 +456,18 @@ __global__ __launch_bounds__((DUO ? 2 : 1) * 64 * (NW + NP), DUO ? 1 : OCC) void
             }
         });
         if constexpr (SNAKE) {   // Snake of the consumed tensor, two window values per packed instruction (nc_math.h; items past NX: unused)
+            // groups of >= 2 pairs: the sine up to its sign and the pairs' chains step by step side by side (nc_math.h; round 5: in the k = 7
+            // instances 57 -> 37 `s_nop` and 40 vector instructions fewer per loop, conv_k7 -0.17 ms, bit-identical; NC_LEGACY_ROWS=0
+            // at compile time keeps the pair-by-pair form with the parity select)
+            if constexpr (GX >= 4 && NC_LEGACY_ROWS != 0) {
+                constexpr int NPR = GX / 2;
+                nc_f2 xs[NPR], as[NPR], is[NPR];
+#pragma unroll
+                for (int q = 0; q < NPR; ++q) { xs[q] = nc_f2{v[2 * q], v[2 * q + 1]}; as[q] = nc_f2{al[2 * q].x, al[2 * q + 1].x}; is[q] = nc_f2{al[2 * q].y, al[2 * q + 1].y}; }
+                nc_snakef2_m_rows<NPR, NC_LEGACY_ROWS == 1>(xs, as, is);
+#pragma unroll
+                for (int q = 0; q < NPR; ++q) { v[2 * q] = xs[q][0]; v[2 * q + 1] = xs[q][1]; }
+            } else
 #pragma unroll
             for (int u = 0; u + 1 < GX; u += 2) nc_snake_pair(v[u], v[u + 1], al[u].x, al[u].y, al[u + 1].x, al[u + 1].y);
             if constexpr (GX & 1) v[GX - 1] = nc_snakef(v[GX - 1], al[GX - 1].x, al[GX - 1].y);

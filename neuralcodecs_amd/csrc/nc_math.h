@@ -116,8 +116,8 @@ __device__ __forceinline__ nc_f2 nc_snakef2(nc_f2 x, nc_f2 alpha, nc_f2 inv) {
 // The same Snake with the sine taken up to its sign: (-s) * (-s) == s * s exactly in IEEE-754, so the parity select of nc_sinf2 (two
 // conversions, masks, compares and selects: 8 of the ~30 vector instructions of a pair) is dead weight under the square -- bit-identical
 // to nc_snakef2.  Used by the vector-ALU-bound SNAC kernels (depthwise convolution, fused residual unit) and, from round 5, by the
-// XV-only instances of the conv template (staging and epilogue: -0.35 ms on the DAC step); the legacy instances keep nc_snakef2: there the
-// shorter form measured 0.3 ms SLOWER, and in the pointwise kernel it is neutral (round 5).
+// conv template (XV-only instances: staging and epilogue, -0.35 ms on the DAC step; legacy instances: the in-loop staging, as
+// nc_snakef2_m_rows); in the pointwise kernel's epilogue it is neutral (round 5) and nc_snakef2 stays.
 __device__ __forceinline__ nc_f2 nc_snakef2_m(nc_f2 x, nc_f2 alpha, nc_f2 inv) {
     const nc_f2 ax = alpha * x;
     const nc_f2 n = __builtin_elementwise_rint(ax * 0x1.45f306p-2f);
@@ -136,7 +136,7 @@ __device__ __forceinline__ nc_f2 nc_snakef2_m(nc_f2 x, nc_f2 alpha, nc_f2 inv) {
 // N independent pairs, the chain written step by step ACROSS the pairs: every packed instruction is followed by N - 1 independent ones, so
 // none waits on its predecessor (pair by pair the compiler puts an `s_nop` between each two instructions of a chain).  Same operations
 // per element in the same order as nc_snakef2_m: bit-identical.
-template <int N>
+template <int N, bool SIGNED = false>
 __device__ __forceinline__ void nc_snakef2_m_rows(nc_f2 (&x)[N], const nc_f2 (&alpha)[N], const nc_f2 (&inv)[N]) {
     nc_f2 ax[N], n[N], r[N], u[N], p[N], s[N];
 #pragma unroll
@@ -161,6 +161,14 @@ __device__ __forceinline__ void nc_snakef2_m_rows(nc_f2 (&x)[N], const nc_f2 (&a
     for (int i = 0; i < N; ++i) p[i] = nc_fma2(p[i], u[i], (nc_f2)(-0x1.555556p-3f));
 #pragma unroll
     for (int i = 0; i < N; ++i) s[i] = nc_fma2(r[i] * u[i], p[i], r[i]);
+    if constexpr (SIGNED) {   // (the canonical sine's parity select, kept for A/B runs: dead under the square)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int n0 = (int)n[i][0], n1 = (int)n[i][1];
+            s[i][0] = (n0 & 1) ? -s[i][0] : s[i][0];
+            s[i][1] = (n1 & 1) ? -s[i][1] : s[i][1];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i) x[i] = x[i] + (s[i] * s[i]) * inv[i];
 }
