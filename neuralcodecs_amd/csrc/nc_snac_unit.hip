@@ -22,10 +22,6 @@
 
 #include <utility>
 
-#ifndef NC_SU_PAIRED   // 1 = the B fragments of two steps built side by side (round 5), 0 = one step at a time
-#define NC_SU_PAIRED 1
-#endif
-
 namespace nc {
 
 namespace {
@@ -103,10 +99,9 @@ __global__ __launch_bounds__(256, 2) void snac_unit_kernel(const UnitArgs p) {
             su_f32x4 r = st[u];
             if (wq < 0 || wq >= xw4) r = su_f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // (T % 4 == 0: a word is all in or all out)
             const float ai = Tb[(cb * CB + item_ch(u)) * 12 + 10], ai_inv = Tb[(cb * CB + item_ch(u)) * 12 + 11];
-            nc_f2 v2[2] = {nc_f2{r[0], r[1]}, nc_f2{r[2], r[3]}};             // the word's two chains step by step side by side (nc_math.h)
-            const nc_f2 a2[2] = {nc_f2{ai, ai}, nc_f2{ai, ai}}, i2[2] = {nc_f2{ai_inv, ai_inv}, nc_f2{ai_inv, ai_inv}};
-            nc_snakef2_m_rows<2>(v2, a2, i2);
-            if (tid + 256 * u < NITEM) reinterpret_cast<su_f32x4*>(Xs)[item_ch(u) * XWORDS + item_wq(u)] = su_f32x4{v2[0][0], v2[0][1], v2[1][0], v2[1][1]};
+            const nc_f2 lo = nc_snakef2_m(nc_f2{r[0], r[1]}, nc_f2{ai, ai}, nc_f2{ai_inv, ai_inv});
+            const nc_f2 hi2 = nc_snakef2_m(nc_f2{r[2], r[3]}, nc_f2{ai, ai}, nc_f2{ai_inv, ai_inv});
+            if (tid + 256 * u < NITEM) reinterpret_cast<su_f32x4*>(Xs)[item_ch(u) * XWORDS + item_wq(u)] = su_f32x4{lo[0], lo[1], hi2[0], hi2[1]};
             __builtin_amdgcn_sched_barrier(0);   // one item at a time: interleaved, the Snake temporaries of all items are live at once
         }
     };
@@ -138,7 +133,6 @@ __global__ __launch_bounds__(256, 2) void snac_unit_kernel(const UnitArgs p) {
             // B fragments of step u + 1 are built while the matrix cores work on step u: a two-stage software pipeline inside the wave.
             // (One stage -- window reads, 7 packed fmas, Snake, then the step's 2 TM matrix-core instructions -- left the pipe idle
             // while a wave computed and the vector ALU idle while it issued: 0.56 us per step against 0.16 us of matrix-core time.)
-#if !NC_SU_PAIRED
             auto build_h = [&](int u) __attribute__((always_inline)) -> nc_f2 {
                 const int chl = 2 * u + hi, ch = cb * CB + chl;
                 const su_f32x4 t0 = *reinterpret_cast<const su_f32x4*>(Tb + ch * 12), t1 = *reinterpret_cast<const su_f32x4*>(Tb + ch * 12 + 4);
@@ -150,65 +144,6 @@ __global__ __launch_bounds__(256, 2) void snac_unit_kernel(const UnitArgs p) {
                 for (int k = 0; k < K; ++k) a2 = nc_fma2(nc_f2{wk[k], wk[k]}, nc_f2{row[k * DIL], row[32 + k * DIL]}, a2);
                 return nc_snakef2_m(a2 + nc_f2{bv, bv}, nc_f2{ao, ao}, nc_f2{ao_inv, ao_inv});
             };
-#endif
-#if NC_SU_PAIRED
-            // Two steps' B fragments are built TOGETHER, their chains (7 packed fmas + the Snake's 17) step by step side by side: one chain
-            // alone left every packed instruction waiting on its predecessor -- at two waves per SIMD the kernel was bound by that latency,
-            // not by the vector ALU, the matrix cores or HBM (round 5).
-            auto build_h2 = [&](int u, nc_f2 (&h2)[2]) __attribute__((always_inline)) {
-                nc_f2 x2[2], ao2[2], iv2[2];
-                float wk[2][K], bv[2];
-                const float* row[2];
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const int chl = 2 * (u + s2) + hi, ch = cb * CB + chl;
-                    const su_f32x4 t0 = *reinterpret_cast<const su_f32x4*>(Tb + ch * 12), t1 = *reinterpret_cast<const su_f32x4*>(Tb + ch * 12 + 4);
-                    bv[s2] = t1[3];
-                    ao2[s2] = nc_f2{Tb[ch * 12 + 8], Tb[ch * 12 + 8]};
-                    iv2[s2] = nc_f2{Tb[ch * 12 + 9], Tb[ch * 12 + 9]};
-                    wk[s2][0] = t0[0]; wk[s2][1] = t0[1]; wk[s2][2] = t0[2]; wk[s2][3] = t0[3]; wk[s2][4] = t1[0]; wk[s2][5] = t1[1]; wk[s2][6] = t1[2];
-                    row[s2] = Xs + chl * XP + c0;
-                    x2[s2] = nc_f2{0.0f, 0.0f};
-                }
-#pragma unroll
-                for (int k = 0; k < K; ++k)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) x2[s2] = nc_fma2(nc_f2{wk[s2][k], wk[s2][k]}, nc_f2{row[s2][k * DIL], row[s2][32 + k * DIL]}, x2[s2]);
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) x2[s2] = x2[s2] + nc_f2{bv[s2], bv[s2]};
-                nc_snakef2_m_rows<2>(x2, ao2, iv2);
-                h2[0] = x2[0]; h2[1] = x2[1];
-            };
-            static_assert((CB / 2) % 2 == 0, "paired steps");
-            nc_f2 h2[2];
-            build_h2(0, h2);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < CB / 2; u += 2) {
-                nc_f2 hn[2] = {h2[0], h2[1]};
-                if (u + 2 < CB / 2) build_h2(u + 2, hn);
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    float a[TM];
-                    nc_load_a_frag<TM>(Ab + 2 * (cb * (CB / 2) + u + s2) * C, l31, a);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], h2[s2][0], acc[i][0], 0, 0, 0);
-                        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], h2[s2][1], acc[i][1], 0, 0, 0);
-                    }
-                }
-                if (u + 2 < CB / 2) {                                        // deal the next two steps' reads and arithmetic into the matrix-core slots
-#pragma unroll
-                    for (int g = 0; g < 4 * TM; ++g) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one matrix-core instruction
-                        __builtin_amdgcn_sched_group_barrier(0x100, (36 + 4 * TM - 1) / (4 * TM), 0);   // LDS reads
-                        __builtin_amdgcn_sched_group_barrier(0x002, (96 + 4 * TM - 1) / (4 * TM), 0);   // vector ALU
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                h2[0] = hn[0]; h2[1] = hn[1];
-            }
-#else
             nc_f2 h = build_h(0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -233,7 +168,6 @@ __global__ __launch_bounds__(256, 2) void snac_unit_kernel(const UnitArgs p) {
                 __builtin_amdgcn_sched_barrier(0);                           // (one step of look-ahead: hoisted further, the reads cost 100+ registers)
                 h = hn;
             }
-#endif
             if (tr) tr[3] = __builtin_amdgcn_s_memrealtime();
         }
         // ---- epilogue: row R = 32 i + (r & 3) + 8 (r >> 2) + 4 hi, column t0 + 64 wave + 32 j + l31.  Phase A folds bias and the skip
