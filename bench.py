@@ -24,8 +24,11 @@ The JSON line carries
     as a sequence of ATen CPU operators (tools/aten_proxy.py, the closest stand-in for the reference's TorchSharp-CPU path):
     one warm-up + 3 timed passes over 8 clips, median;
   * `extra_configs` (N=1 only): BASELINE configs C3 (Encodec 48 kHz stereo, 16 x 2 s), C5's per-GPU share and C1
-    (SNAC 24 kHz, 1 x 1 s) on the same GPU: ms, x real-time, per-class HIP-event times, dominant kernel class with its
-    roofline fraction, algorithmic vs PMC bytes, and a GPU == oracle check on one clip.
+    (SNAC 24 kHz, 1 x 1 s) on the same GPU: ms, x real-time, compact per-class HIP-event table, dominant kernel class with its
+    roofline fraction and a GPU == oracle check on one clip; their step times also as flat top-level keys (c3_... / c5_share_... / c1_...).
+  The line is kept small (< 4 KB); the full per-class tables are written to gpurun_out/bench_detail.json (NC_BENCH_DETAIL=<path>).
+  `roofline.traffic` comes from profiles/traffic.json only when the loaded library's SHA-256 equals the one recorded there
+  (else null + "traffic_stale": true).
 """
 import argparse
 import json
@@ -84,13 +87,42 @@ def dominant(classes):
             "frac": round(c["algo_GBps"] / HBM_PEAK_GBS, 4), "ms_per_step": c["ms_per_step"]}
 
 
+_TRAFFIC_STALE = {}
+
+
 def load_traffic(key):
     """HBM bytes from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per
-    MI355X_MICROARCH.md), committed under profiles/traffic.json by tools/pmc_classes.py: a measured constant of the build."""
+    MI355X_MICROARCH.md), committed under profiles/traffic.json by tools/pmc_classes.py together with the SHA-256 of the engine library
+    they were measured on.  Counters of ANOTHER build are not this build's traffic: when the loaded library's hash differs the entry is
+    withheld (None) and traffic_stale(key) says so -- re-run tools/profile_round.sh after a kernel change."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(p):
         return None
-    return json.load(open(p)).get(key)
+    t = json.load(open(p)).get(key)
+    if not t:
+        return None
+    from neuralcodecs_amd import _lib
+    if t.get("_lib_sha256") != _lib.lib_sha256():
+        _TRAFFIC_STALE[key] = True
+        return None
+    _TRAFFIC_STALE[key] = False
+    return t
+
+
+def traffic_stale(key):
+    return bool(_TRAFFIC_STALE.get(key, False))
+
+
+def compact_classes(classes):
+    """name -> [ms per step, launches per step, achieved (TFLOP/s for the matrix-core classes, algorithmic GB/s otherwise), fraction of
+    the bound's peak]: the bench line stays small; the full tables go to the detail file."""
+    out = {}
+    for n, c in classes.items():
+        if n in MFMA_CLASSES:
+            out[n] = [round(c["ms_per_step"], 3), c["launches_per_step"], c["tflops"], round(c["tflops"] / FP32_MFMA_PEAK_TFLOPS, 3)]
+        else:
+            out[n] = [round(c["ms_per_step"], 3), c["launches_per_step"], c["algo_GBps"], round(c["algo_GBps"] / HBM_PEAK_GBS, 3)]
+    return out
 
 
 def timed(fn, steps, warmup, sync):
@@ -128,7 +160,8 @@ def extra_configs(dev, steps, warmup, check):
         e = {"workload": name, "B": B, "clip_seconds": secs, "ms_per_step": round(dt * 1e3, 3), "x_realtime": round(B * secs / dt, 1),
              "whole_step_tflops": round(fl * B * secs / dt / 1e12, 3), "whole_step_algo_GBps": round(by * B * secs / dt / 1e9, 1),
              "kernel_ms_per_step": round(sum(c["ms_per_step"] for c in classes.values()), 3),
-             "dominant": dominant(classes), "classes": classes, "pmc_traffic": load_traffic(algo_key)}
+             "dominant": dominant(classes), "classes": classes,
+             "pmc_traffic_ref": "profiles/traffic.json#" + algo_key, "traffic_stale": traffic_stale(algo_key)}
         if check:
             deferred.append((e, oracle_check))
         out[algo_key if algo_key != "snac44k" else "snac44k_c5_share"] = e
@@ -591,8 +624,9 @@ def main():
                 "bound": "mfma", "achieved": round(ach_tflops, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": round(tk7["hbm_bytes_per_launch"]) if tk7 else None,
+                "traffic_stale": traffic_stale("dac44k"),
                 "traffic_unit": "HBM bytes per launch of this class (PMC FETCH_SIZE x2 + WRITE_SIZE over exactly the launches the class counts)",
-                "traffic_source": "profiles/traffic.json: separate rocprofv3 --pmc passes of this bench command on this build (tools/profile_round.sh); a committed constant, NOT measured in this run (counters need the profiler)",
+                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes of this command, tools/profile_round.sh); reported only when the loaded library's SHA-256 equals the one recorded there",
                 "traffic_over_algorithmic": round(tk7["hbm_bytes_per_launch"] / algo_b, 3) if tk7 and algo_b else None,
                 "mfma_busy": tk7.get("mfma_busy"),
                 "algorithmic_bytes_per_launch": round(algo_b),
@@ -675,6 +709,34 @@ def main():
                        "collective": coll if use_dist else "none"},
             "roofline": roofline, "cpu_baseline": cpu, "extra_configs": extras,
         }
+        # The ONE line must be readable in a log tail: the full per-class tables go to a detail file, the line keeps a
+        # compact form of them; the other BASELINE configs' step times are flat top-level keys as well.
+        detail = json.loads(json.dumps(out))
+        out["roofline"]["all_classes"] = compact_classes(roofline["all_classes"])
+        out["roofline"]["all_classes_columns"] = ["ms_per_step", "launches_per_step", "TFLOP/s (matrix-core classes) or algorithmic GB/s", "frac_of_peak"]
+        for k in ("traffic_unit", "traffic_source"):
+            out["roofline"].pop(k, None)
+        if isinstance(extras, dict) and "error" not in extras:
+            slim = {}
+            for k, e in extras.items():
+                slim[k] = {kk: e[kk] for kk in ("workload", "B", "clip_seconds", "ms_per_step", "x_realtime", "whole_step_tflops", "kernel_ms_per_step",
+                                                "dominant", "traffic_stale", "gpu_equals_oracle") if kk in e}
+                slim[k]["classes"] = compact_classes(e["classes"])
+                slim[k]["launches_per_step"] = round(sum(c["launches_per_step"] for c in e["classes"].values()), 1)
+            out["extra_configs"] = slim
+            for k, flat in (("encodec48k", "c3_encodec48k_16x2s_ms_per_step"), ("snac44k_c5_share", "c5_share_snac44k_8x5s_ms_per_step"),
+                            ("snac24k", "c1_snac24k_1x1s_ms_per_step")):
+                if k in extras:
+                    out[flat] = extras[k]["ms_per_step"]
+        if cpu and isinstance(cpu.get("aten_proxy"), dict):
+            out["cpu_baseline"] = dict(cpu, aten_proxy={k: v for k, v in cpu["aten_proxy"].items() if not isinstance(v, (list, dict))})
+        try:
+            dpath = os.environ.get("NC_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+            os.makedirs(os.path.dirname(dpath), exist_ok=True)
+            json.dump(detail, open(dpath, "w"), indent=1)
+            out["detail_file"] = os.path.relpath(dpath, ROOT)
+        except OSError:
+            pass
     gathered_ok = None
     if use_dist and not args.no_check:
         # the gathered codes of the N-GPU run must equal the 1-GPU run on the same inputs -- EVERY slot, on every rank:

@@ -320,6 +320,12 @@ typedef struct nc_group nc_group;
 NC_API nc_status nc_group_unique_id(void* uid /* [NC_GROUP_UID_BYTES] */);
 NC_API nc_status nc_group_create_rank(int32_t world, int32_t rank, const void* uid, nc_codec* local, nc_group** out);
 NC_API nc_status nc_group_create_local(int32_t ndev, nc_codec* const* handles, nc_group** out);
+/* local mode with options.  NC_GROUP_PEER_COPY: the all-gather is moved by peer copies (hipMemcpyPeerAsync on the members' side streams:
+ * member e pulls slot d from member d's buffer behind d's "slot final" event) instead of RCCL -- same slots, same results, no librccl; the
+ * members may then SHARE a device (an RCCL communicator cannot hold two ranks of one GPU), e.g. eight handles on one GPU split a batch
+ * eight ways exactly as eight GPUs would.  flags = 0 is nc_group_create_local. */
+#define NC_GROUP_PEER_COPY 1u
+NC_API nc_status nc_group_create_local_ex(int32_t ndev, nc_codec* const* handles, uint32_t flags, nc_group** out);
 NC_API nc_status nc_group_destroy(nc_group* g);
 NC_API nc_status nc_group_info(const nc_group* g, int32_t* world, int32_t* rank /* -1 in local mode */);
 /* Payload of the code all-gather: bits = 0 (default) moves the int64 codes as they are; 1..24 moves them bit-packed in the wire layout of
@@ -423,6 +429,11 @@ NC_API nc_status nc_op_res_unit(int device_index, int32_t B, int32_t C, int64_t 
 /* one VQ stage on projected latents z_e [B,D,T] against codebook [N,D] -> idx [B,T], st [B,D,T] */
 NC_API nc_status nc_op_vq_argmin(int device_index, const float* z_e, int32_t B, int32_t D, int64_t T, const float* codebook,
                                  int32_t N, int64_t* idx, float* st);
+/* the Encodec Euclidean RVQ (Modules/Encodec/ResidualVectorQuantizer.cs:133-157 over EuclideanCodebook.cs:155-182) on residual [B,D,T]
+ * with codebooks [n_q,N,D] -> codes [B,n_q,T], residual_out [B,D,T] (nullable; the residual after the last stage in form 0, the input in form 1, whose residual never
+ * leaves LDS).  form 0: one launch per stage; form 1: the all-stages matrix-core kernel (D == 128 and N % 512 == 0, else NC_EUNSUPPORTED). */
+NC_API nc_status nc_op_euclid_rvq(int device_index, const float* residual, int32_t B, int32_t D, int64_t T, const float* codebooks,
+                                  int32_t n_q, int32_t N, int32_t form, int64_t* codes, float* residual_out);
 /* weight-norm fold w = v/(||v||+1e-7)*g over dim-0 slices (host-side, what load_weights does) */
 NC_API nc_status nc_op_fold_weight_norm(const float* v, const float* g, int64_t d0, int64_t inner, float* w);
 

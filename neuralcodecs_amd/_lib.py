@@ -127,6 +127,7 @@ SYMBOLS = [
     ("nc_group_unique_id", C.c_int, [_P]),
     ("nc_group_create_rank", C.c_int, [C.c_int32, C.c_int32, _P, _P, C.POINTER(_P)]),
     ("nc_group_create_local", C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P)]),
+    ("nc_group_create_local_ex", C.c_int, [C.c_int32, C.POINTER(_P), C.c_uint32, C.POINTER(_P)]),
     ("nc_group_destroy", C.c_int, [_P]),
     ("nc_group_info", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("nc_group_set_code_bits", C.c_int, [_P, C.c_int32]),
@@ -148,6 +149,7 @@ SYMBOLS = [
     ("nc_op_res_unit", C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P,
                                  C.c_int32, C.POINTER(C.c_double)]),
     ("nc_op_vq_argmin", C.c_int, [C.c_int, _P, C.c_int32, C.c_int32, C.c_int64, _P, C.c_int32, _P, _P]),
+    ("nc_op_euclid_rvq", C.c_int, [C.c_int, _P, C.c_int32, C.c_int32, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("nc_op_fold_weight_norm", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
 ]
 
@@ -172,13 +174,29 @@ def lib():
         try:
             fn = getattr(L, name)
         except AttributeError:
-            if os.environ.get("NC_MI355X_LIB"):      # (A/B against an OLDER build of the library: it may predate an export)
+            # A/B against an OLDER build of the library (NC_MI355X_LIB=<path>): only the exports named in NC_ALLOW_MISSING_EXPORTS (comma
+            # separated) may be absent -- a symbol dropped by accident from any build must fail here, not as an AttributeError later
+            if os.environ.get("NC_MI355X_LIB") and name in [x.strip() for x in os.environ.get("NC_ALLOW_MISSING_EXPORTS", "").split(",")]:
                 continue
             raise
         fn.restype = res
         fn.argtypes = args
     _lib = L
     return L
+
+
+def lib_path() -> str:
+    return os.environ.get("NC_MI355X_LIB") or LIB_PATH
+
+
+def lib_sha256() -> str:
+    """SHA-256 of the engine library file this process loads: profiles/traffic.json records the one its counters were measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(lib_path(), "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
 
 
 def check(status: int) -> None:

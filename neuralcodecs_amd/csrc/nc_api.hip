@@ -798,4 +798,13 @@ nc_status nc_op_vq_argmin(int device_index, const float* z_e, int32_t B, int32_t
     });
 }
 
+nc_status nc_op_euclid_rvq(int device_index, const float* residual, int32_t B, int32_t D, int64_t T, const float* codebooks, int32_t n_q, int32_t N,
+                           int32_t form, int64_t* codes, float* residual_out) {
+    return guard([&] {
+        if (!residual || !codebooks || !codes || B <= 0 || D <= 0 || T <= 0 || N <= 0 || n_q <= 0 || form < 0 || form > 1) fail(NC_EINVAL, "bad arguments");
+        op_set_device(device_index);
+        op_euclid_rvq(residual, B, D, T, codebooks, n_q, N, form, codes, residual_out);
+    });
+}
+
 }  // extern "C"

@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void euclid_vq_kernel(float* __restrict__ resi
 #pragma unroll
                 for (int f = 0; f < EQ_F; ++f) {
                     const float dist = (e2s[f] + cc) - 2.0f * cr[u][f];
-                    if (dist < best[f]) { best[f] = dist; besti[f] = n; }
+                    if (nc_argmin_scan(dist, best[f])) { best[f] = dist; besti[f] = n; }
                 }
             }
         }
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void euclid_vq_kernel(float* __restrict__ resi
         for (int off = 32; off >= 1; off >>= 1) {
             const float od = __shfl_xor(d0, off, 64);
             const int oi = __shfl_xor(i0, off, 64);
-            if (od < d0 || (od == d0 && oi < i0)) { d0 = od; i0 = oi; }
+            if (nc_argmin_before(od, oi, d0, i0)) { d0 = od; i0 = oi; }
         }
         if (lane == 0) { bd[f][wave] = d0; bi[f][wave] = i0; }
     }
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void euclid_vq_kernel(float* __restrict__ resi
         float d0 = bd[tid][0];
         int i0 = bi[tid][0];
         for (int w = 1; w < 4; ++w)
-            if (bd[tid][w] < d0 || (bd[tid][w] == d0 && bi[tid][w] < i0)) { d0 = bd[tid][w]; i0 = bi[tid][w]; }
+            if (nc_argmin_before(bd[tid][w], bi[tid][w], d0, i0)) { d0 = bd[tid][w]; i0 = bi[tid][w]; }
         if (i0 == 0x7fffffff) i0 = 0;
         win[tid] = i0;
         const int64_t fr = f0 + tid;
@@ -604,14 +604,14 @@ __global__ __launch_bounds__(64 * NWV) void euclid_rvq_mfma_kernel(const float* 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float dist = (e2 + cc[i]) - 2.0f * acc[i][r];
-                    if (dist < best || (dist == best && nb + i < besti)) { best = dist; besti = nb + i; }
+                    if (nc_argmin_before(dist, nb + i, best, besti)) { best = dist; besti = nb + i; }
                 }
             }
         }
         {   // the two lane halves hold the same frame; then the four waves meet in LDS
             const float od = __shfl_xor(best, 32, 64);
             const int oi = __shfl_xor(besti, 32, 64);
-            if (od < best || (od == best && oi < besti)) { best = od; besti = oi; }
+            if (nc_argmin_before(od, oi, best, besti)) { best = od; besti = oi; }
             if (hi == 0) { bd[wave][l31] = best; bi[wave][l31] = besti; }
         }
         __syncthreads();
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(64 * NWV) void euclid_rvq_mfma_kernel(const float* 
             float d0 = bd[0][tid];
             int i0 = bi[0][tid];
             for (int w = 1; w < NWV; ++w)
-                if (bd[w][tid] < d0 || (bd[w][tid] == d0 && bi[w][tid] < i0)) { d0 = bd[w][tid]; i0 = bi[w][tid]; }
+                if (nc_argmin_before(bd[w][tid], bi[w][tid], d0, i0)) { d0 = bd[w][tid]; i0 = bi[w][tid]; }
             if (i0 == 0x7fffffff) i0 = 0;
             win[tid] = i0;
             const int64_t fr = f0 + tid;
@@ -1724,6 +1724,41 @@ void EncodecModel::decode_dev(const int64_t* codes, const float* scales, int B, 
     hipLaunchKernelGGL(overlap_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dfp, dfl, nfr, L0, dw, dsw, (int64_t)B * C, stride,
                        total, pcm);
     NC_HIP(hipGetLastError());
+}
+
+
+void op_euclid_rvq(const float* residual_in, int B, int D, int64_t T, const float* books_host, int n_q, int N, int form, int64_t* codes_host,
+                   float* residual_out) {
+    std::vector<Codebook> books((size_t)n_q);
+    std::vector<const float*> pT, pR, p2;
+    for (int q = 0; q < n_q; ++q) {
+        books[(size_t)q].build(books_host + (int64_t)q * N * D, N, D);
+        pT.push_back(books[(size_t)q].cbT.as<float>()); pR.push_back(books[(size_t)q].cb.as<float>()); p2.push_back(books[(size_t)q].c2.as<float>());
+    }
+    DevBuf res, codes, dT, dR, d2;
+    const size_t nb = (size_t)B * D * T * 4;
+    res.reserve(nb); codes.reserve((size_t)B * n_q * T * 8);
+    dT.reserve(pT.size() * sizeof(float*)); dR.reserve(pT.size() * sizeof(float*)); d2.reserve(pT.size() * sizeof(float*));
+    NC_HIP(hipMemcpy(res.p, residual_in, nb, hipMemcpyHostToDevice));
+    NC_HIP(hipMemcpy(dT.p, pT.data(), pT.size() * sizeof(float*), hipMemcpyHostToDevice));
+    NC_HIP(hipMemcpy(dR.p, pR.data(), pR.size() * sizeof(float*), hipMemcpyHostToDevice));
+    NC_HIP(hipMemcpy(d2.p, p2.data(), p2.size() * sizeof(float*), hipMemcpyHostToDevice));
+    const int64_t total = (int64_t)B * T;
+    if (form == 1) {
+        if (D != 128 || N % 512 != 0) fail(NC_EUNSUPPORTED, "the matrix-core Euclidean RVQ takes D == 128 and N %% 512 == 0");
+        hipLaunchKernelGGL(euclid_rvq_mfma_kernel<128>, dim3((unsigned)((total + EM_F - 1) / EM_F)), dim3(256), 0, nullptr, res.as<float>(),
+                           dT.as<const float*>(), dR.as<const float*>(), d2.as<const float*>(), n_q, N, B, T, codes.as<int64_t>(), (int64_t)n_q * T);
+    } else {
+        for (int q = 0; q < n_q; ++q)
+            hipLaunchKernelGGL(euclid_vq_kernel, dim3((unsigned)((total + EQ_F - 1) / EQ_F)), dim3(256), 0, nullptr, res.as<float>(), pT[(size_t)q],
+                               pR[(size_t)q], p2[(size_t)q], N, D, B, T, codes.as<int64_t>() + (int64_t)q * T, (int64_t)n_q * T);
+    }
+    NC_HIP(hipGetLastError());
+    NC_HIP(hipDeviceSynchronize());
+    NC_HIP(hipMemcpy(codes_host, codes.p, (size_t)B * n_q * T * 8, hipMemcpyDeviceToHost));
+    if (residual_out) NC_HIP(hipMemcpy(residual_out, res.p, nb, hipMemcpyDeviceToHost));
+    res.release(); codes.release(); dT.release(); dR.release(); d2.release();
+    for (auto& b : books) { b.cbT.release(); b.cb.release(); b.c2.release(); }
 }
 
 }  // namespace nc

@@ -115,12 +115,14 @@ struct PinBuf {
 struct nc_group {
     int world = 1, rank = -1;        // rank == -1: local mode (this process drives all `world` devices)
     int code_bits = 0;               // > 0: the all-gather moves bit-packed codes (nc_group_set_code_bits)
+    bool peer_copy = false;          // local mode, NC_GROUP_PEER_COPY: the gather pulls the slots with peer copies instead of RCCL
     struct Member {
         nc_codec* h = nullptr;       // borrowed: the codec must outlive the group (nc_group_destroy before nc_codec_destroy)
         int device = 0;              // (kept here so that the destructor never reads through the borrowed handle)
         ncclComm_t comm = nullptr;
         hipStream_t side = nullptr;
         hipEvent_t ev_enc = nullptr, ev_gather = nullptr;
+        hipEvent_t ev_slot = nullptr, ev_pulled = nullptr;   // peer-copy transport: "my slot is final" / "I hold every slot"
         DevBuf pcm, codes_all, z;    // local mode staging
         DevBuf packed_all;           // [world][slot bytes]: the packed payload of the collective (code_bits > 0)
         PinBuf pin_in, pin_out, pin_z;
@@ -133,6 +135,8 @@ struct nc_group {
             if (x.side) (void)hipStreamDestroy(x.side);
             if (x.ev_enc) (void)hipEventDestroy(x.ev_enc);
             if (x.ev_gather) (void)hipEventDestroy(x.ev_gather);
+            if (x.ev_slot) (void)hipEventDestroy(x.ev_slot);
+            if (x.ev_pulled) (void)hipEventDestroy(x.ev_pulled);
             x.pcm.release(); x.codes_all.release(); x.z.release(); x.packed_all.release();
             x.pin_in.release(); x.pin_out.release(); x.pin_z.release();
         }
@@ -149,6 +153,8 @@ void init_member(nc_group::Member& x, nc_codec* h) {
     NC_HIP(hipStreamCreateWithFlags(&x.side, hipStreamNonBlocking));
     NC_HIP(hipEventCreateWithFlags(&x.ev_enc, hipEventDisableTiming));
     NC_HIP(hipEventCreateWithFlags(&x.ev_gather, hipEventDisableTiming));
+    NC_HIP(hipEventCreateWithFlags(&x.ev_slot, hipEventDisableTiming));
+    NC_HIP(hipEventCreateWithFlags(&x.ev_pulled, hipEventDisableTiming));
 }
 
 // codes of this member -> its slot of codes_all; returns elements per rank.  The encode writes straight into the slot, so the
@@ -201,6 +207,39 @@ void gather_slots(nc_group* g, nc_group::Member& x, int slot, int64_t* codes_all
     prepare_slot(g, x, slot, codes_all, rows, per_clip);
     NC_RCCL(issue_gather(g, x, slot, codes_all, rows, per_clip));
 }
+// Peer-copy transport (local mode created with NC_GROUP_PEER_COPY): the same in-place all-gather -- slot d of member d's buffer ends up in
+// slot d of EVERY member's buffer -- moved by hipMemcpyPeerAsync on the members' side streams instead of RCCL: member e waits for the
+// "slot final" event of member d and pulls slot d.  No librccl, and members may share a device (RCCL refuses a communicator with two ranks
+// on one GPU): a W-way group over fewer GPUs, which is how a one-GPU box runs BASELINE configs C4 / C5 through all eight slots.
+// bufs[d] = member d's buffer of W slots of slot_bytes each; everything queued on a side stream so far belongs to the slot.
+void copy_allgather(nc_group* g, const std::vector<uint8_t*>& bufs, int64_t slot_bytes) {
+    const int W = g->world;
+    for (int d = 0; d < W; ++d) {
+        nc_group::Member& x = g->m[(size_t)d];
+        NC_HIP(hipSetDevice(x.device));
+        NC_HIP(hipEventRecord(x.ev_slot, x.side));
+    }
+    for (int e = 0; e < W; ++e) {
+        nc_group::Member& x = g->m[(size_t)e];
+        NC_HIP(hipSetDevice(x.device));
+        for (int k = 1; k < W; ++k) {                     // (staggered: at any moment the members read from W different sources)
+            const int d = (e + k) % W;
+            nc_group::Member& src = g->m[(size_t)d];
+            NC_HIP(hipStreamWaitEvent(x.side, src.ev_slot, 0));
+            NC_HIP(hipMemcpyPeerAsync(bufs[(size_t)e] + (int64_t)d * slot_bytes, x.device, bufs[(size_t)d] + (int64_t)d * slot_bytes, src.device,
+                                      (size_t)slot_bytes, x.side));
+        }
+        NC_HIP(hipEventRecord(x.ev_pulled, x.side));
+    }
+    // a member's buffer may be rewritten (its next encode) only when every reader is done with it: each side stream meets all pulls
+    for (int d = 0; d < W; ++d) {
+        nc_group::Member& x = g->m[(size_t)d];
+        NC_HIP(hipSetDevice(x.device));
+        for (int e = 0; e < W; ++e)
+            if (e != d) NC_HIP(hipStreamWaitEvent(x.side, g->m[(size_t)e].ev_pulled, 0));
+    }
+}
+
 // local mode: every member's collective inside ONE RCCL group; the group is closed on the error path too
 void grouped_gather(nc_group* g, const std::vector<int64_t*>& codes_all, int rows, int64_t per_clip) {
     const int W = g->world;
@@ -208,6 +247,14 @@ void grouped_gather(nc_group* g, const std::vector<int64_t*>& codes_all, int row
         nc_group::Member& x = g->m[(size_t)d];
         NC_HIP(hipSetDevice(x.device));
         prepare_slot(g, x, d, codes_all[(size_t)d], rows, per_clip);
+    }
+    if (g->peer_copy) {
+        std::vector<uint8_t*> bufs((size_t)W);
+        const bool packed = g->code_bits > 0;
+        for (int d = 0; d < W; ++d)
+            bufs[(size_t)d] = packed ? g->m[(size_t)d].packed_all.as<uint8_t>() : reinterpret_cast<uint8_t*>(codes_all[(size_t)d]);
+        copy_allgather(g, bufs, packed ? (int64_t)rows * nc_packed_bytes(per_clip, g->code_bits) : (int64_t)rows * per_clip * 8);
+        return;
     }
     NC_RCCL(rccl().GroupStart());
     ncclResult_t bad = ncclSuccess;
@@ -273,6 +320,7 @@ void local_encode_allgather(nc_group* g, int kind, const float* pcm, int B_total
             Codec& c = *x.h->impl;
             c.use_device();
             const int B = n_of(d);
+            if (g->peer_copy) NC_HIP(hipStreamSynchronize(x.side));   // (host mode: before a grow-only buffer may move)
             x.codes_all.reserve((size_t)per_rank * W * 8);
             if (B > 0) {
                 const size_t in_bytes = (size_t)B * channels * T * 4;
@@ -372,6 +420,7 @@ void local_encode_allgather_dev(nc_group* g, int kind, const float* const* pcm, 
         nc_group::Member& x = g->m[(size_t)d];
         Codec& c = *x.h->impl;
         c.use_device();
+        if (g->peer_copy) NC_HIP(hipStreamWaitEvent(c.stream, x.ev_gather, 0));   // (the previous gather's readers of this member's buffer)
         const int B = B_local[d];
         int64_t* slot = codes_all[d] + (int64_t)d * per_rank;
         if (B > 0) {
@@ -447,13 +496,18 @@ void local_encodec_allgather_dev(nc_group* g, const float* const* pcm, const int
         nc_group::Member& x = g->m[(size_t)d];
         EncodecModel& m = static_cast<EncodecModel&>(*x.h->impl);
         m.use_device();
+        if (g->peer_copy) NC_HIP(hipStreamWaitEvent(m.stream, x.ev_gather, 0));
         m.encode_dev(pcm[d], B, T, codes_all[d] + (int64_t)d * per_rank, sc ? scales_all[d] + (int64_t)d * nf * B : nullptr, nullptr);
         NC_HIP(hipEventRecord(x.ev_enc, m.stream));
         NC_HIP(hipStreamWaitEvent(x.side, x.ev_enc, 0));
     }
     std::vector<int64_t*> slots(codes_all, codes_all + W);
     grouped_gather(g, slots, B, per_clip);
-    if (sc) {
+    if (sc && g->peer_copy) {
+        std::vector<uint8_t*> bufs((size_t)W);
+        for (int d = 0; d < W; ++d) bufs[(size_t)d] = reinterpret_cast<uint8_t*>(scales_all[d]);
+        copy_allgather(g, bufs, (int64_t)nf * B * 4);
+    } else if (sc) {
         NC_RCCL(rccl().GroupStart());
         ncclResult_t bad = ncclSuccess;
         for (int d = 0; d < W && bad == ncclSuccess; ++d) {
@@ -502,27 +556,53 @@ nc_status nc_group_create_rank(int32_t world, int32_t rank, const void* uid, nc_
     });
 }
 
-nc_status nc_group_create_local(int32_t ndev, nc_codec* const* handles, nc_group** out) {
-    return guard([&] {
-        if (!out || !handles) fail(NC_EINVAL, "handles and out must not be null");
-        *out = nullptr;
-        if (ndev <= 0 || ndev > 64) fail(NC_EINVAL, "bad device count %d", ndev);
-        std::unique_ptr<nc_group> g(new nc_group());
-        g->world = ndev; g->rank = -1;
-        g->m.resize((size_t)ndev);
-        std::vector<int> devs((size_t)ndev);
-        for (int d = 0; d < ndev; ++d) {
-            init_member(g->m[(size_t)d], handles[d]);
-            devs[(size_t)d] = handles[d]->impl->device;
+namespace {
+void create_local(int32_t ndev, nc_codec* const* handles, uint32_t flags, nc_group** out) {
+    if (!out || !handles) fail(NC_EINVAL, "handles and out must not be null");
+    *out = nullptr;
+    if (ndev <= 0 || ndev > 64) fail(NC_EINVAL, "bad device count %d", ndev);
+    if (flags & ~(uint32_t)NC_GROUP_PEER_COPY) fail(NC_EINVAL, "unknown group flags 0x%x", flags);
+    std::unique_ptr<nc_group> g(new nc_group());
+    g->world = ndev; g->rank = -1;
+    g->peer_copy = (flags & NC_GROUP_PEER_COPY) != 0;
+    g->m.resize((size_t)ndev);
+    std::vector<int> devs((size_t)ndev);
+    for (int d = 0; d < ndev; ++d) {
+        if (!handles[d]) fail(NC_EINVAL, "null codec handle");
+        for (int e = 0; e < d; ++e)
+            if (handles[e] == handles[d]) fail(NC_EINVAL, "handle %d is handle %d again: one codec (one stream, one workspace) per member", d, e);
+        init_member(g->m[(size_t)d], handles[d]);
+        devs[(size_t)d] = handles[d]->impl->device;
+        if (!g->peer_copy)   // (an RCCL communicator cannot hold two ranks of one GPU; the peer-copy transport can)
             for (int e = 0; e < d; ++e)
                 if (devs[(size_t)e] == devs[(size_t)d]) fail(NC_EINVAL, "handles %d and %d live on the same device %d", e, d, devs[(size_t)d]);
-            if (handles[d]->kind != handles[0]->kind) fail(NC_EINVAL, "the handles of a group must be of one codec kind");
-        }
+        if (handles[d]->kind != handles[0]->kind) fail(NC_EINVAL, "the handles of a group must be of one codec kind");
+    }
+    if (g->peer_copy) {
+        for (int d = 0; d < ndev; ++d)      // direct peer access where the hardware offers it (otherwise the runtime stages the copies)
+            for (int e = 0; e < ndev; ++e) {
+                int can = 0;
+                if (devs[(size_t)d] == devs[(size_t)e] || hipDeviceCanAccessPeer(&can, devs[(size_t)d], devs[(size_t)e]) != hipSuccess || !can) continue;
+                NC_HIP(hipSetDevice(devs[(size_t)d]));
+                const hipError_t pe = hipDeviceEnablePeerAccess(devs[(size_t)e], 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) NC_HIP(pe);
+                (void)hipGetLastError();
+            }
+    } else {
         std::vector<ncclComm_t> comms((size_t)ndev);
         NC_RCCL(rccl().CommInitAll(comms.data(), ndev, devs.data()));
         for (int d = 0; d < ndev; ++d) g->m[(size_t)d].comm = comms[(size_t)d];
-        *out = g.release();
-    });
+    }
+    *out = g.release();
+}
+}  // namespace
+
+nc_status nc_group_create_local(int32_t ndev, nc_codec* const* handles, nc_group** out) {
+    return guard([&] { create_local(ndev, handles, 0, out); });
+}
+
+nc_status nc_group_create_local_ex(int32_t ndev, nc_codec* const* handles, uint32_t flags, nc_group** out) {
+    return guard([&] { create_local(ndev, handles, flags, out); });
 }
 
 nc_status nc_group_destroy(nc_group* g) {

@@ -17,6 +17,17 @@
 
 NC_HD float nc_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// The order of ATen's argmin, which the reference's quantizers call on the distance matrix (Modules/DAC/VectorQuantizer.cs:121,
+// Modules/SNAC/VectorQuantizer.cs:137, Modules/Encodec/EuclideanCodebook.cs:181): a NaN distance beats every number, and among equal
+// distances (and among NaNs) the LOWER index wins -- so a partly-NaN row yields its first NaN, an all-equal row index 0.
+// nc_argmin_before: (d, i) precedes (bd, bi) in that order (any visiting order).  nc_argmin_scan: the same test for a scan that visits
+// indices in ASCENDING order, where an equal distance never replaces the incumbent.
+NC_HD bool nc_argmin_before(float d, int i, float bd, int bi) {
+    const bool dn = d != d, bn = bd != bd;
+    return (dn || bn) ? (dn && (!bn || i < bi)) : (d < bd || (d == bd && i < bi));
+}
+NC_HD bool nc_argmin_scan(float d, float bd) { return !(d >= bd) && bd == bd; }
+
 NC_HD float nc_sinf(float x) {
     float n = __builtin_rintf(x * 0x1.45f306p-2f);  // x * fl(1/pi)
     float r = nc_fma(n, -3.140625f, x);             // Cody-Waite, pi = A + B + C

@@ -40,6 +40,10 @@ bool launch_dac_rvq_fused(const RvqStage* stages_dev, int n_q, int L, int D, int
 void launch_vq_argmin(const Codebook& cb, const float* z_e, int64_t ze_bstride, int B, int64_t T, int64_t* codes,
                       int64_t codes_bstride, float* st, hipStream_t s, Profiler* prof);
 // codes -> out [B,D,T] = cb[codes]  (Embedding + transpose, VectorQuantizer.cs:135-142)
+// Test hook (nc_op_euclid_rvq): the Encodec Euclidean RVQ (ResidualVectorQuantizer.cs:133-157) on residual [B,D,T] (updated in place) with n_q
+// codebooks [n_q][N][D] (host): form 0 = the per-stage kernel, 1 = the all-stages matrix-core kernel (D == 128, N % 512 == 0)
+void op_euclid_rvq(const float* residual_in, int B, int D, int64_t T, const float* books_host, int n_q, int N, int form, int64_t* codes_host,
+                   float* residual_out);
 void launch_vq_gather(const Codebook& cb, const int64_t* codes, int64_t codes_bstride, int B, int64_t T, float* out, hipStream_t s,
                       Profiler* prof);
 

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict_
             for (int d = 0; d < MAXD; ++d)
                 if (d < D) cr = nc_fma(e[fi][d], s_cb[d * N + n], cr);
             const float dist = (e2 + s_c2[n]) - 2.0f * cr;
-            if (dist < best) {
+            if (nc_argmin_scan(dist, best)) {
                 best = dist;
                 bi = n;
             }
@@ -90,12 +90,12 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict_
         for (int off = 32; off >= 1; off >>= 1) {
             const float od = __shfl_xor(best, off, 64);
             const int oi = __shfl_xor(bi, off, 64);
-            if (od < best || (od == best && oi < bi)) {
+            if (nc_argmin_before(od, oi, best, bi)) {
                 best = od;
                 bi = oi;
             }
         }
-        if (bi == 0x7fffffff) bi = 0;  // all-NaN row: ATen returns an index as well; pick 0
+        if (bi == 0x7fffffff) bi = 0;  // a row of +inf only: every distance equal, ATen returns index 0
         win[fi] = bi;
     }
     // epilogue: codes and the straight-through values, restated literally (VectorQuantizer.cs:81): e + (q - e)
@@ -282,13 +282,13 @@ __global__ __launch_bounds__(256) void dac_rvq_fused_kernel(const RvqFusedArgs a
 #pragma unroll
                 for (int d = 0; d < RD; ++d) cr = nc_fma(e[d], s_cb[d * N + n], cr);
                 const float dist = (e2 + s_c2[n]) - 2.0f * cr;
-                if (dist < best) { best = dist; bi = n; }
+                if (nc_argmin_scan(dist, best)) { best = dist; bi = n; }
             }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) {
                 const float od = __shfl_xor(best, off, 64);
                 const int oi = __shfl_xor(bi, off, 64);
-                if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
+                if (nc_argmin_before(od, oi, best, bi)) { best = od; bi = oi; }
             }
             if (bi == 0x7fffffff) bi = 0;
             const int b = s_bt[2 * f], t = s_bt[2 * f + 1];

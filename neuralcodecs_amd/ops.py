@@ -55,6 +55,16 @@ def vq_argmin(z_e, codebook, device_index=0):
     return idx, st
 
 
+def euclid_rvq(residual, codebooks, form=1, device_index=0):
+    """Encodec RVQ encode on residual [B,D,T] with codebooks [n_q,N,D] -> (codes [B,n_q,T], residual after the last stage)."""
+    r = np.ascontiguousarray(residual, np.float32); cb = np.ascontiguousarray(codebooks, np.float32)
+    B, D, T = r.shape
+    nq, N, _ = cb.shape
+    codes = np.empty((B, nq, T), np.int64); out = np.empty_like(r)
+    _lib.check(_lib.lib().nc_op_euclid_rvq(device_index, r.ctypes.data, B, D, T, cb.ctypes.data, nq, N, int(form), codes.ctypes.data, out.ctypes.data))
+    return codes, out
+
+
 def fold_weight_norm(v, g):
     v = np.ascontiguousarray(v, np.float32); g = np.ascontiguousarray(g, np.float32).reshape(-1)
     w = np.empty_like(v)

@@ -143,12 +143,14 @@ class Group:
         return cls(g, world, rank, [codec])
 
     @classmethod
-    def local(cls, codecs: Sequence) -> "Group":
+    def local(cls, codecs: Sequence, peer_copy: bool = False) -> "Group":
+        """peer_copy=True (NC_GROUP_PEER_COPY): the gather is moved by peer copies instead of RCCL; the codecs may then share a device (W
+        handles on one GPU split a batch W ways exactly as W GPUs would)."""
         import ctypes as C
         from . import _lib
         arr = (C.c_void_p * len(codecs))(*[c._h for c in codecs])
         g = C.c_void_p()
-        _lib.check(_lib.lib().nc_group_create_local(len(codecs), arr, C.byref(g)))
+        _lib.check(_lib.lib().nc_group_create_local_ex(len(codecs), arr, 1 if peer_copy else 0, C.byref(g)))
         return cls(g, len(codecs), -1, list(codecs))
 
     def set_code_bits(self, bits: int) -> None:
@@ -269,8 +271,12 @@ class Group:
                 raise ValueError(f"block {d} must live on device {m.device_index}")
         nb = (C.c_int32 * self.world)(*[0 if x is None else int(x.shape[0]) for x in xs])
         ptrs = (C.c_void_p * self.world)(*[None if x is None or x.shape[0] == 0 else x.data_ptr() for x in xs])
-        T = next(int(x.shape[-1]) for x in xs if x is not None and x.shape[0] > 0)
-        return xs, nb, ptrs, T, max(nb)
+        full = [x for x in xs if x is not None and x.shape[0] > 0]
+        if not full:
+            raise ValueError("no clips: every block is empty")
+        if any(x.dim() != 3 or tuple(x.shape[1:]) != tuple(full[0].shape[1:]) for x in full):
+            raise ValueError("every block must be [B_d, C, T] with the same C and T")
+        return xs, nb, ptrs, int(full[0].shape[-1]), max(nb)
 
     def dac_encode_allgather_local(self, pcm_blocks, n_quantizers: int = 0, codes_all=None):
         """pcm_blocks[d]: [B_d,1,T] on device d (None / empty for a device without clips).  Returns (z[d], codes_all[d], latents[d]) lists:

@@ -184,7 +184,7 @@ REF_API void ref_conv_transpose1d(const float* x, int64_t B, int Cin, int64_t Ti
 }
 
 /* One VQ stage on projected latents z_e [B,D,T]: squared-Euclidean argmin over the codebook [N,D]
- * (VectorQuantizer.cs:99-125, D1) -> idx [B,T] (first index on ties, like ATen argmin), and the
+ * (VectorQuantizer.cs:99-125, D1) -> idx [B,T] (ATen argmin: first index on ties, the first NaN of a row that holds one), and the
  * straight-through value st = z_e + (cb[idx] - z_e) [B,D,T] (VectorQuantizer.cs:81). */
 REF_API void ref_vq_argmin(const float* z_e, int64_t B, int D, int64_t T, const float* cb, int N, int64_t* idx, float* st,
                            float* best_dist /*nullable [B,T]*/) {
@@ -206,7 +206,9 @@ REF_API void ref_vq_argmin(const float* z_e, int64_t B, int D, int64_t T, const 
                 float cr = 0.0f;
                 for (int d = 0; d < D; d++) cr = fmaf(e[d], cb[n * D + d], cr);
                 float dist = (e2 + c2[n]) - 2.0f * cr;
-                if (dist < best) { best = dist; bi = n; }
+                /* ATen argmin order (VectorQuantizer.cs:121 dist.argmin(1)): a NaN beats every number, the first one wins; equal
+                 * distances keep the lower index (ascending scan) */
+                if (!(dist >= best) && best == best) { best = dist; bi = n; }
             }
             idx[b * T + t] = bi;
             if (best_dist) best_dist[b * T + t] = best;

@@ -155,3 +155,142 @@ def test_encodec_large_batch_lstm_tile_groups_batch_invariance():
         assert all(np.array_equal(a.codes, b.codes[lo:lo + 4]) and np.array_equal(a.scale, b.scale[lo:lo + 4]) for a, b in zip(f4, frames))
         assert np.array_equal(m.decode(f4, T), audio[lo:lo + 4])
     m.dispose()
+
+
+# ---- BASELINE configs C4 / C5 at their GLOBAL batch size on one GPU ---------------------------------------------------
+# No multi-GPU node exists for this build, so the 8-way form is exercised as far as one GPU allows: (a) the whole batch in ONE call (B*C*T
+# beyond 2^31 bytes per activation), (b) every one of the eight parallel.shard_bounds(., 8, r) blocks encoded alone == its rows of the
+# whole-batch result, sampled clips == the C oracle, (c) the blocks pushed through one-member groups into their rows of the gathered tensor,
+# (d) an EIGHT-member group on this one device (NC_GROUP_PEER_COPY: eight codec handles, eight streams, every member ends with all eight
+# slots -- the slot arithmetic of csrc/nc_group.hip for W = 8, int64 and bit-packed, equal and ragged blocks).  What stays unmeasured: the
+# RCCL collective itself across GPUs.
+
+def _eight_blocks(n):
+    from neuralcodecs_amd.parallel import shard_bounds
+    return [shard_bounds(n, 8, r) for r in range(8)]
+
+
+def test_c4_dac44k_global_batch256_eight_way_on_one_gpu():
+    import torch
+    from neuralcodecs_amd import parallel
+    g = load_golden("dac44k_b1")
+    cfg = dac_cfg_from_meta(g["meta"])
+    blob = save_blob(dac_synthetic_state_dict(cfg, seed=42))
+    m = DAC(cfg)
+    m.load_blob(blob)
+    B, T = 256, 44100
+    pcm = synthetic_pcm(B, 1, T, cfg.sample_rate, seed=1234)
+    x = torch.from_numpy(pcm).cuda()
+    z, codes, lat, _, _ = m.encode(x)                                     # (a) ONE call over the global batch, device resident
+    audio = m.decode(z)
+    torch.cuda.synchronize()
+    assert codes.shape == (B, 9, 87) and audio.shape == (B, 1, 44544)
+    codes_h, z_h, audio_h = codes.cpu().numpy(), z.cpu().numpy(), audio.cpu().numpy()
+    ref = c_oracle.RefDAC(cfg, blob)
+    pick = [0, 100, 255]                                                  # (first / middle / last shard)
+    rz, rcodes, rlat, _ = ref.encode(pcm[pick])
+    assert np.array_equal(codes_h[pick], rcodes) and np.array_equal(z_h[pick], rz) and np.array_equal(lat.cpu().numpy()[pick], rlat)
+    assert np.array_equal(audio_h[pick], ref.decode(rz))
+    gathered = torch.full((B, 9, 87), -1, dtype=torch.int64, device="cuda")
+    one = parallel.Group.local([m])
+    for lo, hi in _eight_blocks(B):                                       # (b) + (c)
+        assert hi - lo == 32
+        zs, cs, _, _, _ = m.encode(x[lo:hi])
+        assert torch.equal(cs, codes[lo:hi]) and torch.equal(zs, z[lo:hi])
+        assert torch.equal(m.decode(zs), audio[lo:hi])
+        one.dac_encode_allgather_local([x[lo:hi]], codes_all=[gathered[lo:hi]])
+        one.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(gathered, codes)
+    one.dispose()
+    # (d) eight members on this device
+    ms = [m] + [DAC(cfg) for _ in range(7)]
+    for k in ms[1:]:
+        k.load_blob(blob)
+    grp = parallel.Group.local(ms, peer_copy=True)
+    blocks = [x[lo:hi] for lo, hi in _eight_blocks(B)]
+    for bits in (0, 10):
+        grp.set_code_bits(bits)
+        zs, call, _ = grp.dac_encode_allgather_local(blocks)
+        dec = [k.decode(zz) for k, zz in zip(ms, zs)]                      # the local decode, queued before the gather is awaited
+        grp.wait()
+        torch.cuda.synchronize()
+        for d in range(8):
+            assert torch.equal(call[d], codes), (bits, d)
+            assert torch.equal(dec[d], audio[32 * d: 32 * d + 32])
+    grp.set_code_bits(0)
+    # ragged: 250 clips -> blocks of 32,32,31,... (slots sized for 32, zero padded), device form and host form
+    rb = _eight_blocks(250)
+    zs, call, _ = grp.dac_encode_allgather_local([x[lo:hi] for lo, hi in rb])
+    grp.wait()
+    torch.cuda.synchronize()
+    for d in range(8):
+        for r, (lo, hi) in enumerate(rb):
+            assert torch.equal(call[d][32 * r: 32 * r + (hi - lo)], codes[lo:hi])
+            assert int(call[d][32 * r + (hi - lo): 32 * r + 32].abs().sum()) == 0
+    hc, hz = grp.dac_encode_allgather_host(pcm[:250], return_z=True)
+    assert np.array_equal(hc, codes_h[:250]) and np.array_equal(hz, z_h[:250])
+    grp.set_code_bits(10)
+    assert np.array_equal(grp.dac_encode_allgather_host(pcm), codes_h)
+    grp.dispose()
+    for k in ms:
+        k.dispose()
+
+
+def test_c5_snac44k_global_batch64x5s_eight_way_on_one_gpu():
+    import torch
+    from neuralcodecs_amd import parallel
+    g = load_golden("snac44k_short")
+    cfg = snac_cfg_from_meta(g["meta"])
+    blob = save_blob(snac_synthetic_state_dict(cfg, seed=42))
+    m = SNAC(cfg)
+    m.load_blob(blob)
+    B, T = 64, 220500
+    pcm = synthetic_pcm(B, 1, T, cfg.sampling_rate, seed=1234)
+    nz = snac_noise(cfg, B, 576, seed=3)
+    x = torch.from_numpy(pcm).cuda()
+    nzd = [torch.from_numpy(n).cuda() for n in nz]
+    codes = m.encode(x)                                                    # (a) ONE call over the global batch
+    audio = m.decode(codes, nzd)
+    torch.cuda.synchronize()
+    assert [tuple(c.shape) for c in codes] == [(B, 72), (B, 144), (B, 288), (B, 576)] and tuple(audio.shape) == (B, 1, 221184)
+    flat, widths = parallel.concat_levels(codes)
+    assert widths == [72, 144, 288, 576]
+    ref = c_oracle.RefSNAC(cfg, blob)
+    pick = [63]
+    _, _, rcodes = ref.encode(pcm[pick])
+    for a, b in zip(codes, rcodes):
+        assert np.array_equal(a.cpu().numpy()[pick], b)
+    assert np.array_equal(audio.cpu().numpy()[pick], ref.decode(rcodes, [n[pick] for n in nz]))
+    gathered = torch.full((B, 1080), -1, dtype=torch.int64, device="cuda")
+    one = parallel.Group.local([m])
+    for lo, hi in _eight_blocks(B):                                        # (b) + (c)
+        assert hi - lo == 8
+        cs = m.encode(x[lo:hi])
+        assert all(torch.equal(a, b[lo:hi]) for a, b in zip(cs, codes))
+        assert torch.equal(m.decode(cs, [n[lo:hi] for n in nzd]), audio[lo:hi])
+        one.snac_encode_allgather_local([x[lo:hi]], codes_all=[gathered[lo:hi]])
+        one.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(gathered, flat)
+    one.dispose()
+    ms = [m] + [SNAC(cfg) for _ in range(7)]                               # (d) eight members on this device
+    for k in ms[1:]:
+        k.load_blob(blob)
+    grp = parallel.Group.local(ms, peer_copy=True)
+    blocks = [x[lo:hi] for lo, hi in _eight_blocks(B)]
+    for bits in (0, 12):                                                   # 4096-entry codebooks: 12 bits
+        grp.set_code_bits(bits)
+        call, w = grp.snac_encode_allgather_local(blocks)
+        grp.wait()
+        torch.cuda.synchronize()
+        assert w == widths
+        for d in range(8):
+            assert torch.equal(call[d], flat), (bits, d)
+    grp.set_code_bits(12)
+    host = grp.snac_encode_allgather_host(pcm[:61])                        # ragged: 8,8,8,8,8,7,7,7
+    for a, b in zip(host, codes):
+        assert np.array_equal(a, b.cpu().numpy()[:61])
+    grp.dispose()
+    for k in ms:
+        k.dispose()

@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HDR = os.path.join(ROOT, "include", "nc_mi355x.h")
 OUT = os.path.join(ROOT, "bindings", "csharp")
 
-SCALARS = {"int": "int", "int32_t": "int", "int64_t": "long", "uint64_t": "ulong", "size_t": "nuint", "float": "float", "double": "double",
+SCALARS = {"int": "int", "int32_t": "int", "int64_t": "long", "uint64_t": "ulong", "uint32_t": "uint", "size_t": "nuint", "float": "float", "double": "double",
            "int16_t": "short", "uint8_t": "byte", "nc_status": "NcStatus"}
 OPAQUE = {"nc_codec", "nc_group"}
 

@@ -121,12 +121,108 @@ def encodec_case(name, cfg_kw, B, T, wseed, pseed, full):
     print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k != "meta"})
 
 
+
+def nonfinite_pcm(B, C, T, sr, seed):
+    """Clips with one non-finite sample each: clip 0 a +inf, clip 1 a NaN, clip 2 a -inf next to a NaN; further clips stay
+    finite.  The positions sit inside the clip so that frames before / after the poisoned receptive field stay finite."""
+    pcm = synthetic_pcm(B, C, T, sr, seed=seed)
+    pcm[0, 0, T // 3] = np.inf
+    if B > 1:
+        pcm[1, C - 1, T // 2] = np.nan
+    if B > 2:
+        pcm[2, 0, T // 4] = -np.inf
+        pcm[2, 0, T // 4 + 1] = np.nan
+    return pcm
+
+
+def nonfinite_cases():
+    """Goldens for non-finite inputs: what ATen does with them is the reference's behaviour (argmin returns the first NaN of a row:
+    Modules/DAC/VectorQuantizer.cs:121, Modules/SNAC/VectorQuantizer.cs:137, Modules/Encodec/EuclideanCodebook.cs:181)."""
+    # (1) one quantizer stage on rows that are PARTLY NaN: a latent with +-inf components makes dist = |e|^2 + |c|^2 - 2 e.c NaN exactly for the
+    # codes whose cross term is +inf (inf - inf) and +inf for the others; ATen returns the first NaN index, an all-inf row gives 0.
+    g = np.random.default_rng(606)
+    out = {}
+    for name, N, D in (("dac", 1024, 8), ("snac", 4096, 8), ("encodec", 1024, 128)):
+        T = 96
+        ze = g.standard_normal((2, D, T)).astype(np.float32)
+        cb = g.standard_normal((N, D)).astype(np.float32)
+        for t in range(0, T, 3):
+            ze[0, (t // 3) % D, t] = np.inf if (t // 3) % 2 == 0 else -np.inf          # partly-NaN rows
+        for t in range(1, T, 12):
+            ze[1, :, t] = np.nan                                                        # all-NaN rows -> 0
+        ze[1, 0, 2] = np.inf; ze[1, 1, 2] = np.inf                                      # two infinities: more NaNs (inf - inf inside e.c)
+        cb[:5, :] = np.abs(cb[:5, :]) * np.sign(cb[5, :])[None, :]                      # a block of codes sharing every sign: runs of equal class
+        enc = torch.from_numpy(ze).transpose(1, 2).reshape(-1, D).contiguous()
+        c = torch.from_numpy(cb)
+        if name == "encodec":    # EuclideanCodebook.cs:155-182
+            dist = enc.pow(2).sum(1, keepdim=True).add(c.pow(2).sum(1, keepdim=True).t()).add(-2 * enc.matmul(c.t()))
+            idx = dist.argmin(dim=-1)
+        else:                    # DAC / SNAC VectorQuantizer.DecodeLatents
+            dist = enc.pow(2).sum(1, keepdim=True) + c.pow(2).sum(1, keepdim=True).t() - torch.einsum("bd,nd->bn", enc, c).mul_(2.0)
+            idx = dist.argmin(1)
+        nan_rows = torch.isnan(dist).any(1)
+        part = nan_rows & ~torch.isnan(dist).all(1)
+        assert int(part.sum()) >= 20, name
+        first_nan = torch.isnan(dist).float().argmax(1)
+        assert bool((idx[nan_rows] == first_nan[nan_rows]).all())                       # ATen: the FIRST NaN of the row
+        out[f"{name}_ze"] = ze
+        out[f"{name}_cb"] = cb
+        out[f"{name}_idx"] = idx.reshape(2, T).numpy().astype(np.int32)
+        out[f"{name}_partly_nan_rows"] = np.int32(int(part.sum()))
+    np.savez_compressed(os.path.join(OUT, "vq_nonfinite.npz"), meta=json.dumps(dict(seed=606)), **out)
+    print("vq_nonfinite", {k: (v.shape if hasattr(v, "shape") and v.shape else v) for k, v in out.items()})
+
+    # (2) whole codecs, reduced width, on clips with one inf / NaN sample
+    cfg = DACConfig(**SMALL)
+    m = TorchDAC(cfg, dac_synthetic_state_dict(cfg, seed=7))
+    pcm = nonfinite_pcm(4, 1, 16000, cfg.sample_rate, seed=21)
+    zq, codes, lat = m.encode(pcm)
+    audio = m.decode(zq)
+    meta = dict(cfg=SMALL, B=4, T=16000, weight_seed=7, pcm_seed=21)
+    np.savez_compressed(os.path.join(OUT, "dac_small_nonfinite.npz"), meta=json.dumps(meta), pcm=pcm, codes=codes.numpy().astype(np.int16),
+                        zq=zq.numpy(), audio=audio.numpy())
+    print("dac_small_nonfinite: NaN frames per clip", torch.isnan(zq).any(1).sum(1).tolist(), "of", zq.shape[-1],
+          "| NaN samples per clip", torch.isnan(audio).any(1).sum(1).tolist(), "of", audio.shape[-1])
+
+    cfg = SNACConfig(**SNAC_SMALL)
+    m = TorchSNAC(cfg, snac_synthetic_state_dict(cfg, seed=5))
+    pcm = nonfinite_pcm(4, 1, 12000, cfg.sampling_rate, seed=22)
+    z, zq, codes = m.encode(pcm)[:3]
+    noises = snac_noise(cfg, 4, z.shape[-1], seed=98)
+    audio = m.decode(codes, noises)
+    meta = dict(cfg=SNAC_SMALL, B=4, T=12000, weight_seed=5, pcm_seed=22, noise_seed=98)
+    out = dict(meta=json.dumps(meta), pcm=pcm, audio=audio.numpy())
+    for i, c in enumerate(codes):
+        out[f"codes{i}"] = c.numpy().astype(np.int16)
+    np.savez_compressed(os.path.join(OUT, "snac_small_nonfinite.npz"), **out)
+    print("snac_small_nonfinite: NaN frames per clip", torch.isnan(z).any(1).sum(1).tolist(), "of", z.shape[-1],
+          "| NaN samples per clip", torch.isnan(audio).any(1).sum(1).tolist(), "of", audio.shape[-1])
+
+    for name, kw, T in (("encodec_small48_nonfinite", ENC_SMALL48, 12100), ("encodec_small24_nonfinite", ENC_SMALL24, 12001)):
+        cfg = EncodecConfig(**kw)
+        m = TorchEncodec(cfg, encodec_synthetic_state_dict(cfg, seed=7))
+        pcm = nonfinite_pcm(4, cfg.channels, T, cfg.sampling_rate, seed=23)
+        frames = m.encode(pcm)
+        audio = m.decode(frames)
+        meta = dict(cfg=kw, B=4, T=T, weight_seed=7, pcm_seed=23, n_frames=len(frames), n_q=m.n_q())
+        out = dict(meta=json.dumps(meta), pcm=pcm, audio=audio.numpy())
+        for i, fr in enumerate(frames):
+            out[f"codes{i}"] = fr[0].numpy().astype(np.int16)
+            if fr[1] is not None:
+                out[f"scale{i}"] = fr[1].numpy()
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        print(name, "frames", len(frames), "| NaN samples per clip", torch.isnan(audio).any(1).sum(1).tolist(), "of", audio.shape[-1])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "--round2":   # fixtures added in round 2 (the round-1 files stay byte-identical)
         # SNAC.Encode(Tensor) as written (D7): 24 kHz model on an un-padded, non-multiple length (22628 samples -> 44 frames, not 48)
         snac_case("snac24k_tensor_b1", dict(), 1, 22628, 42, 1234, 77, True, tensor_overload=True)
         snac_case("snac_small_tensor", SNAC_SMALL, 2, 3100, 5, 3, 99, False, tensor_overload=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "--round6":   # non-finite inputs (VERDICT r5 item 5; the older files stay byte-identical)
+        nonfinite_cases()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "--round5":   # fixtures added in round 5 (VERDICT r4 item 6; the older files stay byte-identical)
         # full-size DAC 24 kHz (Config/DAC/DACConfig.cs:115-124: 32 codebooks, rates 2-4-5-8 -- stride 5 at full width), one 1 s clip

@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--key", required=True)
     ap.add_argument("--out", required=True)
     ap.add_argument("--skip-frac", type=float, default=0.0, help="drop this leading fraction of every class's launches (warm-up)")
+    ap.add_argument("--lib", default=None, help="the engine library the passes ran on: its SHA-256 is stored beside the counters (bench.py "
+                    "reports traffic only when the library it loads has the same hash)")
     ap.add_argument("passes", nargs="+")
     a = ap.parse_args()
     acc = defaultdict(lambda: defaultdict(float))
@@ -98,6 +100,9 @@ def main():
         res[cls] = e
     res["_method"] = ("rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES, kernel trace only) of the bench "
                       "command; classes by kernel name + engine launch log (tools/pmc_classes.py); FETCH doubled per MI355X_MICROARCH.md")
+    if a.lib:
+        import hashlib
+        res["_lib_sha256"] = hashlib.sha256(open(a.lib, "rb").read()).hexdigest()
     allj = {}
     if os.path.exists(a.out):
         allj = json.load(open(a.out))
