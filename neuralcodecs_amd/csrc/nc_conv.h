@@ -201,6 +201,22 @@ struct ThinInmArgs {
 };
 bool launch_conv_thin_inm(const ThinInmArgs& a, int B, int Cout, hipStream_t s);
 
+// arguments of the fused first pass of a SEANetResnetBlock (nc_resa.hip res_a_kernel): shortcut 1x1 + k = 3 branch from one read of x
+struct ResAArgs {
+    const float* x;              // block input [B][Cin][T] view (row stride x_cstride) with its pending GroupNorm
+    int64_t x_bstride, x_cstride;
+    int Cin, T;
+    const float* in_stats;       // nullable [B][2] (mean, rstd): GroupNorm(1,C) of x still pending
+    const float* in_gamma; const float* in_beta;
+    const float* w_s; const float* bias_s; float* ys; int64_t ys_bstride, ys_cstride; int Cs;   // shortcut: packed 1x1 image (one row tile), Cs = Cin rows
+    const float* w_b; const float* bias_b; float* yb; int64_t yb_bstride, yb_cstride; int Cb;   // branch: packed k = 3 image (one row tile), Cb = Cin/2 rows
+    int B, n_t_tiles, n_cb;
+    // GroupNorm block sums of the two outputs (all null = off) with the in-launch finish on each output's own counters
+    double* gn_part_s; double* gn_part_b; int gn_nrb_s, gn_nrb_b, gn_ncb;
+    unsigned* gn_count_s; unsigned* gn_count_b; float* gn_stats_s; float* gn_stats_b; double gn_n_s, gn_n_b;
+};
+bool launch_res_a(const ResAArgs& a, int TMS, bool aligned, hipStream_t s);
+
 // short-row strided convolution on v_mfma_f32_16x16x4_f32 (nc_conv_small.hip): plain input, bias-only epilogue
 bool conv_small_eligible(int Cin, int Cout, int K, int stride, int dil, bool transposed);
 void pack_conv_small(const float* dense_w, int Cin, int Cout, int K, std::vector<float>& out);

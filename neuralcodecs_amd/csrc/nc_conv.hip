@@ -643,9 +643,10 @@ void launch_conv(const ConvLayer& L, const ConvIO& io, int B, hipStream_t stream
     if (launch_conv3_stream(L, io, B, stream, prof)) return;
     const int64_t n_cols_all = L.transposed ? io.Tin + L.Ktaps - 1 : Tout;
     TileChoice tsel{L.cfg, L.w.as<float>(), L.w_phase_stride};
-    // (launches that will take the XV-only two-tap instance: plain input, aligned rows -- the rest of its conditions are checked below)
+    // (launches that will take the XV-only two-tap instance: plain input, rows on 64-byte boundaries -- the same alignment test the grant
+    //  below applies; its remaining conditions depend on the tile and are checked there)
     const bool xv_cand = L.sub_stride && L.n_phase == 1 && !io.in_stats && !io.in_elu && io.in_L == 0 && !io.x2 && !io.alpha_in && !io.gn_part &&
-                         io.x_len % 4 == 0 && io.x_cstride % 4 == 0 && io.x_bstride % 4 == 0;
+                         !io.fuse_k1 && io.x_len % 4 == 0 && io.x_cstride % 16 == 0 && io.x_bstride % 16 == 0 && (reinterpret_cast<uintptr_t>(io.x) & 63) == 0;
     if (!io.fuse_k1) tsel = choose_tile(L, (int64_t)L.n_phase * B * ((n_cols_all + 255) / 256), false, xv_cand);
     else
         for (const auto& alt : L.alts)   // the fused residual unit needs the tile that spans all channels

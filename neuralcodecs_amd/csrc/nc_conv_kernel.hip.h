@@ -282,7 +282,7 @@ __global__ __launch_bounds__((DUO ? 2 : 1) * 64 * (NW + NP), DUO ? 1 : OCC) void
     // after them -2.7 ... -4.4 % per layer; the latency cover is what these short-reduction classes were missing.  The host
     // (launch_conv: EPI_XVEC) grants it for plain inputs with 16-byte aligned rows, a window start that is a multiple of 4 samples (xneg
     // is raised for that) and row lengths that are multiples of 4, so that a float4 is inside the row or outside it as a whole.
-    // K = 7 (launches of >= 2048 columns per clip; NC_NO_XV_K7=1 keeps the legacy instances): the same for the dilated residual-unit convolutions with 8-byte words -- [8][320] floats = 5
+    // K = 7 (every launch whose rows start on 64-byte boundaries -- NC_XV_K7_MIN_COLS=<n> raises a column floor; NC_NO_XV_K7=1 keeps the legacy instances): the same for the dilated residual-unit convolutions with 8-byte words -- [8][320] floats = 5
     // float2 per thread, so the Snake work per thread stays exactly the item form's 10 elements, as packed pairs of one channel.
     constexpr bool XVCAND = XVK;
     static_assert(!XVK || (TN == 2 && NW == 4 && !IN2 && !SPEC && !DIST && ((K == 2 && SUB != 0 && !FUSE) || (K == 7 && SUB == 0))),

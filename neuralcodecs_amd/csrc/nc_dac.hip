@@ -214,13 +214,25 @@ int64_t DacModel::decoded_len(int64_t fr) const {
 }
 
 // x + conv1(snake(conv7(snake(x))));  buffers rotate through act[0..2]
+// Row pitch of an activation [B][C][L] in the arena.  NC_DAC_PITCH=1: rows of 256 samples or more start on 64-byte boundaries (pitch = L
+// rounded up to 16 samples), which puts DAC 44.1 kHz's 696-step layers (C = 512 / 768) on the XV-only instances of the convolution template
+// (they need 64-byte aligned rows; every other shipped preset has L % 16 == 0 there already).  Built and measured in round 6 on VERDICT r5's
+// request and NOT the default: on the C2 step the k = 7 class went 40.45 -> 41.20 ms with it (one box, alternating runs,
+// profiles/r06_ab_dac_pitch.txt) -- the legacy instances at pitch 696 beat the XV-only ones at pitch 704 on these 3-column-tile layers.
+// The pad columns are never read as data: every kernel bounds its reads by x_len.
+static int64_t row_pitch(int64_t L) {
+    static const bool on = env_flag("NC_DAC_PITCH");
+    return (on && L >= 256) ? ((L + 15) & ~(int64_t)15) : L;
+}
+
 float* DacModel::run_res_unit(ResUnit& ru, int dil, float* cur, int C, int64_t L, int B, int& cur_idx, const float* alpha_next) {
     (void)dil;
+    const int64_t P = row_pitch(L);
     const int h_idx = (cur_idx + 1) % 3, o_idx = (cur_idx + 2) % 3;
     float* h = act[h_idx].as<float>();
     float* o = act[o_idx].as<float>();
     ConvIO io{};
-    io.x = cur; io.x_bstride = (int64_t)C * L; io.x_cstride = L; io.x_len = (int32_t)L; io.Tin = L;
+    io.x = cur; io.x_bstride = (int64_t)C * P; io.x_cstride = P; io.x_len = (int32_t)L; io.Tin = L;
     io.alpha_in = ru.a1.as<float>(); io.alpha_out = ru.a2.as<float>();
     // Which units run as one launch: C <= 128 (the 1x1 weights stay in LDS) and C = 256 (whole-channel 128-column tile, W1 streamed:
     // 1.79 ms against 1.88 ms in two launches).  At C = 192 the fused form only breaks even (2.00 against 2.02 ms per unit: the
@@ -230,17 +242,17 @@ float* DacModel::run_res_unit(ResUnit& ru, int dil, float* cur, int C, int64_t L
     if (fuse_res_units && can_fuse_res_unit(ru.c7, ru.c1) && (C != 192 || wide_192)) {
         // one launch: y = x + W1.snake(conv7(snake(x)) + b7) + b1 ; h never reaches HBM
         io.res = cur; io.fuse_k1 = &ru.c1; io.alpha_out2 = alpha_next;
-        io.y = o; io.y_bstride = (int64_t)C * L; io.y_cstride = L;
+        io.y = o; io.y_bstride = (int64_t)C * P; io.y_cstride = P;
         launch_conv(ru.c7, io, B, stream, &prof);
         cur_idx = o_idx;
         return o;
     }
-    io.y = h; io.y_bstride = (int64_t)C * L; io.y_cstride = L;
+    io.y = h; io.y_bstride = (int64_t)C * P; io.y_cstride = P;
     launch_conv(ru.c7, io, B, stream, &prof);
     ConvIO i2{};
-    i2.x = h; i2.x_bstride = (int64_t)C * L; i2.x_cstride = L; i2.x_len = (int32_t)L; i2.Tin = L;
+    i2.x = h; i2.x_bstride = (int64_t)C * P; i2.x_cstride = P; i2.x_len = (int32_t)L; i2.Tin = L;
     i2.res = cur; i2.alpha_out = alpha_next;
-    i2.y = o; i2.y_bstride = (int64_t)C * L; i2.y_cstride = L;
+    i2.y = o; i2.y_bstride = (int64_t)C * P; i2.y_cstride = P;
     launch_conv(ru.c1, i2, B, stream, &prof);
     cur_idx = o_idx;
     return o;
@@ -261,11 +273,11 @@ void DacModel::encode_dev(const float* pcm, int B, int64_t T, int sample_rate, i
     {
         int c = cfg.encoder_dim;
         int64_t L = Tp;
-        maxel = (int64_t)c * L;
+        maxel = (int64_t)c * row_pitch(L);
         for (int i = 0; i < cfg.n_encoder_rates; ++i) {
             c *= 2;
             L /= cfg.encoder_rates[i];
-            if ((int64_t)c * L > maxel) maxel = (int64_t)c * L;
+            if ((int64_t)c * row_pitch(L) > maxel) maxel = (int64_t)c * row_pitch(L);
         }
     }
     for (auto& a : act) a.reserve((size_t)B * maxel * sizeof(float));
@@ -282,7 +294,7 @@ void DacModel::encode_dev(const float* pcm, int B, int64_t T, int sample_rate, i
     {  // stem; DAC.Preprocess right zero-pad is the x_len < Tin bound
         ConvIO io{};
         io.x = pcm; io.x_bstride = T; io.x_cstride = T; io.x_len = (int32_t)T; io.Tin = Tp;
-        io.y = cur; io.y_bstride = (int64_t)C * L; io.y_cstride = L;
+        io.y = cur; io.y_bstride = (int64_t)C * row_pitch(L); io.y_cstride = row_pitch(L);
         launch_conv(enc_stem, io, B, stream, &prof);
     }
     for (int bi = 0; bi < cfg.n_encoder_rates; ++bi) {
@@ -294,9 +306,9 @@ void DacModel::encode_dev(const float* pcm, int B, int64_t T, int sample_rate, i
         const int o_idx = (cur_idx + 1) % 3;
         float* o = act[o_idx].as<float>();
         ConvIO io{};
-        io.x = cur; io.x_bstride = (int64_t)C * L; io.x_cstride = L; io.x_len = (int32_t)L; io.Tin = L;
+        io.x = cur; io.x_bstride = (int64_t)C * row_pitch(L); io.x_cstride = row_pitch(L); io.x_len = (int32_t)L; io.Tin = L;
         if (bi + 1 == cfg.n_encoder_rates) io.alpha_out = enc_alpha_out.as<float>();   // Encoder.cs:44 Snake, consumed by the k3 conv only
-        io.y = o; io.y_bstride = (int64_t)2 * C * Lo; io.y_cstride = Lo;
+        io.y = o; io.y_bstride = (int64_t)2 * C * row_pitch(Lo); io.y_cstride = row_pitch(Lo);
         launch_conv(enc[bi].down, io, B, stream, &prof);
         (void)s;
         cur = o; cur_idx = o_idx; C *= 2; L = Lo;
@@ -305,7 +317,7 @@ void DacModel::encode_dev(const float* pcm, int B, int64_t T, int sample_rate, i
     float* residual = resid.as<float>();
     {  // Snake -> conv k3 -> z, written straight into the RVQ residual buffer (residual = z.clone())
         ConvIO io{};
-        io.x = cur; io.x_bstride = (int64_t)C * L; io.x_cstride = L; io.x_len = (int32_t)L; io.Tin = L;
+        io.x = cur; io.x_bstride = (int64_t)C * row_pitch(L); io.x_cstride = row_pitch(L); io.x_len = (int32_t)L; io.Tin = L;
         io.y = residual; io.y_bstride = (int64_t)latent * Tz; io.y_cstride = Tz;
         launch_conv(enc_out, io, B, stream, &prof);
     }
@@ -389,13 +401,13 @@ void DacModel::decode_dev(const float* z, int B, int64_t Tz, float* pcm) {
     if (!z || !pcm) fail(NC_EINVAL, "z and pcm must not be null");
     if (B <= 0 || Tz <= 0) fail(NC_EINVAL, "B and frames must be positive");
     use_device();
-    int64_t maxel = (int64_t)cfg.decoder_dim * Tz;
+    int64_t maxel = (int64_t)cfg.decoder_dim * row_pitch(Tz);
     {
         int64_t L = Tz;
         for (int i = 0; i < cfg.n_decoder_rates; ++i) {
             L = dec[i].up.out_len(L);
             const int64_t c = cfg.decoder_dim >> (i + 1);
-            if (c * L > maxel) maxel = c * L;
+            if (c * row_pitch(L) > maxel) maxel = c * row_pitch(L);
         }
     }
     for (auto& a : act) a.reserve((size_t)B * maxel * sizeof(float));
@@ -407,7 +419,7 @@ void DacModel::decode_dev(const float* z, int B, int64_t Tz, float* pcm) {
         ConvIO io{};
         io.x = z; io.x_bstride = (int64_t)latent * Tz; io.x_cstride = Tz; io.x_len = (int32_t)Tz; io.Tin = Tz;
         io.alpha_out = dec[0].a_up.as<float>();   // consumed only through the first DecoderBlock's Snake (DecoderBlock.cs:24)
-        io.y = cur; io.y_bstride = (int64_t)C * L; io.y_cstride = L;
+        io.y = cur; io.y_bstride = (int64_t)C * row_pitch(L); io.y_cstride = row_pitch(L);
         launch_conv(dec_in, io, B, stream, &prof);
     }
     for (int bi = 0; bi < cfg.n_decoder_rates; ++bi) {
@@ -416,8 +428,8 @@ void DacModel::decode_dev(const float* z, int B, int64_t Tz, float* pcm) {
         const int o_idx = (cur_idx + 1) % 3;
         float* o = act[o_idx].as<float>();
         ConvIO io{};
-        io.x = cur; io.x_bstride = (int64_t)C * L; io.x_cstride = L; io.x_len = (int32_t)L; io.Tin = L;
-        io.y = o; io.y_bstride = (int64_t)Co * Lo; io.y_cstride = Lo;
+        io.x = cur; io.x_bstride = (int64_t)C * row_pitch(L); io.x_cstride = row_pitch(L); io.x_len = (int32_t)L; io.Tin = L;
+        io.y = o; io.y_bstride = (int64_t)Co * row_pitch(Lo); io.y_cstride = row_pitch(Lo);
         launch_conv(dec[bi].up, io, B, stream, &prof);
         cur = o; cur_idx = o_idx; C = Co; L = Lo;
         const float* a_next = bi + 1 < cfg.n_decoder_rates ? dec[bi + 1].a_up.as<float>() : dec_alpha_out.as<float>();
@@ -425,7 +437,7 @@ void DacModel::decode_dev(const float* z, int B, int64_t Tz, float* pcm) {
     }
     {
         ConvIO io{};
-        io.x = cur; io.x_bstride = (int64_t)C * L; io.x_cstride = L; io.x_len = (int32_t)L; io.Tin = L;
+        io.x = cur; io.x_bstride = (int64_t)C * row_pitch(L); io.x_cstride = row_pitch(L); io.x_len = (int32_t)L; io.Tin = L;
         io.y = pcm; io.y_bstride = L; io.y_cstride = L;
         io.epi = EPI_TANH;
         launch_conv(dec_out, io, B, stream, &prof);

@@ -170,6 +170,71 @@ __global__ void rms_final_kernel(const double* __restrict__ part, float* __restr
     for (int k = 0; k < nchunk; ++k) s += part[(int64_t)b * nchunk + k];
     scale[b] = sqrtf((float)(s / (double)L)) + 1e-8f;
 }
+// The same scale in ONE launch (the default; NC_RMS_TWO_PASS=1 runs the two kernels above): a workgroup stages RMS_G chunks of a clip through
+// LDS -- coalesced reads, fl32(mono^2) per sample computed in parallel -- and thread g adds chunk g's 256 values in ascending order in
+// binary64 (the canonical chunk sum); the LAST workgroup of a clip to arrive (self-resetting counter, the hand-off of nc_gn.h: write-through
+// partials, drain, barrier, one relaxed agent-scope fetch-add, agent-scope loads) adds the clip's chunk sums in ascending order and writes
+// the scale.  Bit-identical to rms_partial_kernel + rms_final_kernel: 44 + 24 us -> one short launch on C3 (16 x 2 s).
+constexpr int RMS_G = 16;
+__global__ __launch_bounds__(256) void rms_scale_kernel(const float* __restrict__ x, double* __restrict__ part, unsigned* __restrict__ counter,
+                                                        float* __restrict__ scale, int C, int64_t L, int nchunk, int nblk) {
+    __shared__ float sq[RMS_G][GN_CHUNK + 1];
+    __shared__ double fin[256];
+    __shared__ int last;
+    const int b = blockIdx.x / nblk, blk = blockIdx.x - b * nblk, tid = threadIdx.x;
+    const int64_t t_base = (int64_t)blk * RMS_G * GN_CHUNK;
+    const float* xb = x + (int64_t)b * C * L;
+    const float invC = (float)C;
+    for (int g0 = 0; g0 < RMS_G; g0 += 4) {                       // four chunk rows per pass: the reads of a pass are in flight together
+        float a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t t = t_base + (int64_t)(g0 + u) * GN_CHUNK + tid;
+            a[u] = t < L ? xb[t] : 0.0f;
+        }
+        for (int c = 1; c < C; ++c) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t t = t_base + (int64_t)(g0 + u) * GN_CHUNK + tid;
+                const float v = t < L ? xb[(int64_t)c * L + t] : 0.0f;
+                a[u] = a[u] + v;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float m = a[u] / invC;
+            sq[g0 + u][tid] = m * m;
+        }
+    }
+    __syncthreads();
+    const int ch = blk * RMS_G + tid;
+    if (tid < RMS_G && ch < nchunk) {
+        const int64_t t0 = (int64_t)ch * GN_CHUNK;
+        const int n = (int)((t0 + GN_CHUNK < L ? t0 + GN_CHUNK : L) - t0);
+        double acc = 0.0;
+        for (int i = 0; i < n; ++i) acc += (double)sq[tid][i];
+        __hip_atomic_store(part + (int64_t)b * nchunk + ch, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) last = __hip_atomic_fetch_add(counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == (unsigned)nblk;
+    __syncthreads();
+    if (!last) return;
+    double tot = 0.0;                                               // (ascending chunk order, one accumulator: rms_final_kernel's sum)
+    for (int k0 = 0; k0 < nchunk; k0 += 256) {
+        if (k0 + tid < nchunk) fin[tid] = __hip_atomic_load(part + (int64_t)b * nchunk + k0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (tid == 0) {
+            const int n = nchunk - k0 < 256 ? nchunk - k0 : 256;
+            for (int i = 0; i < n; ++i) tot += fin[i];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        scale[b] = sqrtf((float)(tot / (double)L)) + 1e-8f;
+        __hip_atomic_store(counter + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 // y = x / scale[b]  (mode 0)   |   y = GN(x) * scale[b] (mode 1, scale nullable -> plain GN materialisation)
 __global__ void scale_kernel(ActView a, const float* __restrict__ scale, int mode, float* __restrict__ y, int B, int C, int64_t L) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -885,8 +950,8 @@ void EncodecModel::load(const Blob& b) {
     }
     snprintf(nm, sizeof nm, "decoder.layers.%d", n + 1);
     load_sconv(b, nm, dec_out, nf, cfg.channels, cfg.last_kernel_size, 1, false);
-    gn_counters.reserve((size_t)3 * GN_MAX_SAMPLES * sizeof(unsigned));
-    NC_HIP(hipMemset(gn_counters.p, 0, (size_t)3 * GN_MAX_SAMPLES * sizeof(unsigned)));
+    gn_counters.reserve((size_t)3 * 2 * GN_MAX_SAMPLES * sizeof(unsigned));
+    NC_HIP(hipMemset(gn_counters.p, 0, (size_t)3 * 2 * GN_MAX_SAMPLES * sizeof(unsigned)));
     if (!lstm_tmo_host) {
         void* hp = nullptr;
         NC_HIP(hipHostMalloc(&hp, 64, hipHostMallocMapped));
@@ -1033,7 +1098,7 @@ EncodecModel::GnJob EncodecModel::gn_begin(const ConvLayer& conv, ConvIO& io, in
         // sample; the segment groups of a call run concurrently, so each has its own set.
         static const bool no_finish = env_flag("NC_NO_GN_FINISH");
         if (!no_finish && N <= GN_MAX_SAMPLES) {
-            io.gn_count = gn_counters.as<unsigned>() + (size_t)cur_group * GN_MAX_SAMPLES;
+            io.gn_count = gn_counters.as<unsigned>() + (size_t)cur_group * 2 * GN_MAX_SAMPLES;
             io.gn_stats = j.stats;
             io.gn_n = gn_count_arg((double)C * (double)L);
             j.finished = true;
@@ -1136,10 +1201,60 @@ EncodecModel::Act EncodecModel::sconvT(SConv& L, const Act& a, const Act* b2, bo
     return o;
 }
 
+// The first pass of a residual block as ONE launch (nc_resa.hip): s = shortcut(x) and h = conv3(elu(x)) from a single read of x -- the
+// thin outer stages of the 48 kHz model (C = 32 / 64: HBM-bound; the block input was read twice, the k = 3 launch alone ran at 2.1 TB/s).
+// Same arithmetic as the two launches (NC_NO_RES_A=1 runs those).
+bool EncodecModel::resblock_first_pass(ResBlock& r, const Act& x, int N, Act& s, Act& h) {
+    static const bool off = env_flag("NC_NO_RES_A") || env_flag("NC_ENCODEC_NO_FUSE");
+    const int C = x.C;
+    const int64_t T = x.L;
+    if (off || cfg.causal || (C != 32 && C != 64) || r.sc.K != 1 || r.c1.K != 3 || r.sc.Cin != C || r.sc.Cout != C || r.c1.Cin != C || r.c1.Cout != C / 2) return false;
+    if (r.sc.conv.cfg.TM != C / 32 || r.sc.conv.cfg.CB != 16 || r.c1.conv.cfg.TM != 1 || r.c1.conv.cfg.CB != 16) return false;   // one row tile each
+    if (T < 4 || (T & 1) || T >= ((int64_t)1 << 30) || (int64_t)(C + 1) * x.rs + T >= ((int64_t)1 << 32)) return false;
+    const Plan pl = plan_sconv(T, 3, 1, 1);
+    if (pl.left != 1 || pl.Lz != T || pl.Lp != T + 2 || pl.Lout != T) return false;   // (the non-causal reflect pad 1 + 1 the kernel folds into its lanes)
+    const bool gn = cfg.time_group_norm;
+    if (gn && (N > GN_MAX_SAMPLES || env_flag("NC_NO_GN_FINISH"))) return false;
+    float* ys = alloc((size_t)N * C * T);
+    float* yb = alloc((size_t)N * (C / 2) * T);
+    ResAArgs a{};
+    a.x = x.p + x.off; a.x_bstride = (int64_t)x.C * x.rs; a.x_cstride = x.rs; a.Cin = C; a.T = (int)T;
+    a.in_stats = x.stats; a.in_gamma = x.stats ? x.gamma : nullptr; a.in_beta = x.stats ? x.beta : nullptr;
+    a.w_s = r.sc.conv.w.as<float>(); a.bias_s = r.sc.conv.has_bias ? r.sc.conv.bias.as<float>() : nullptr;
+    a.ys = ys; a.ys_bstride = (int64_t)C * T; a.ys_cstride = T; a.Cs = C;
+    a.w_b = r.c1.conv.w.as<float>(); a.bias_b = r.c1.conv.has_bias ? r.c1.conv.bias.as<float>() : nullptr;
+    a.yb = yb; a.yb_bstride = (int64_t)(C / 2) * T; a.yb_cstride = T; a.Cb = C / 2;
+    a.B = N; a.n_t_tiles = (int)((T + 255) / 256); a.n_cb = C / 16;
+    float* st_s = nullptr; float* st_b = nullptr;
+    if (gn) {
+        a.gn_nrb_s = C / 32; a.gn_nrb_b = 1; a.gn_ncb = (int)((T + 31) / 32);
+        a.gn_part_s = reinterpret_cast<double*>(alloc((size_t)N * a.gn_nrb_s * a.gn_ncb * 4));
+        a.gn_part_b = reinterpret_cast<double*>(alloc((size_t)N * a.gn_nrb_b * a.gn_ncb * 4));
+        st_s = alloc((size_t)N * 2); st_b = alloc((size_t)N * 2);
+        a.gn_stats_s = st_s; a.gn_stats_b = st_b;
+        a.gn_count_s = gn_counters.as<unsigned>() + (size_t)cur_group * 2 * GN_MAX_SAMPLES;
+        a.gn_count_b = a.gn_count_s + GN_MAX_SAMPLES;
+        a.gn_n_s = gn_count_arg((double)C * (double)T); a.gn_n_b = gn_count_arg((double)(C / 2) * (double)T);
+    }
+    auto al8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; };
+    const bool aligned = al8(a.x) && !(a.x_cstride & 1) && !(a.x_bstride & 1);
+    {
+        // (one class for the launch: the pointwise one -- 2/5 of its flops, all of its input bytes)
+        ProfScope ps(&prof, stream, NC_KC_CONV_K1, 2.0 * C * (C + 1.5 * C) * (double)T * N, 4.0 * N * (double)T * (C + C + C / 2));
+        if (!launch_res_a(a, C / 32, aligned, stream)) fail(NC_ESTATE, "internal: no first-pass kernel for C = %d", C);
+    }
+    s.p = ys; s.C = C; s.L = T; s.rs = T; s.off = 0; s.stats = st_s; s.gamma = st_s ? r.sc.gamma.as<float>() : nullptr; s.beta = st_s ? r.sc.beta.as<float>() : nullptr;
+    h.p = yb; h.C = C / 2; h.L = T; h.rs = T; h.off = 0; h.stats = st_b; h.gamma = st_b ? r.c1.gamma.as<float>() : nullptr; h.beta = st_b ? r.c1.beta.as<float>() : nullptr;
+    return true;
+}
+
 // SEANetResnetBlock.forward (:72-85): shortcut(x) + conv1(elu(conv3(elu(x)))) -> the two pending views (s, y)
 void EncodecModel::resblock(ResBlock& r, const Act& x, int N, Act& s, Act& y) {
-    s = sconv(r.sc, x, nullptr, false, N);
-    Act h = sconv(r.c1, x, nullptr, true, N);
+    Act h;
+    if (!resblock_first_pass(r, x, N, s, h)) {
+        s = sconv(r.sc, x, nullptr, false, N);
+        h = sconv(r.c1, x, nullptr, true, N);
+    }
     y = sconv(r.c2, h, nullptr, true, N);
     // A row shorter than the k=3 pad takes SConv1d's small-input path (zero-extend, never trimmed: D9), so the block branch comes
     // out LONGER than the 1x1 shortcut and the reference's add() would broadcast.  Such degenerate segments are rejected.
@@ -1481,8 +1596,16 @@ void EncodecModel::encode_batch(const float* x, int N, int64_t L, int64_t Tz, in
         const int nchunk = (int)((L + GN_CHUNK - 1) / GN_CHUNK);
         double* part = reinterpret_cast<double*>(alloc((size_t)N * nchunk * 2));
         float* sc = scale_out ? scale_out : alloc((size_t)N);
-        hipLaunchKernelGGL(rms_partial_kernel, dim3((unsigned)(((int64_t)N * nchunk + 63) / 64)), dim3(64), 0, stream, x, part, N, cfg.channels, L, nchunk);
-        hipLaunchKernelGGL(rms_final_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, stream, part, sc, N, L, nchunk);
+        static const bool two_pass = env_flag("NC_RMS_TWO_PASS");
+        if (!two_pass && N <= GN_MAX_SAMPLES) {
+            const int nblk = (nchunk + RMS_G - 1) / RMS_G;
+            ProfScope ps(&prof, stream, NC_KC_ELEM, 3.0 * N * cfg.channels * (double)L, 4.0 * N * cfg.channels * (double)L);
+            hipLaunchKernelGGL(rms_scale_kernel, dim3((unsigned)((int64_t)N * nblk)), dim3(256), 0, stream, x, part,
+                               gn_counters.as<unsigned>() + (size_t)cur_group * 2 * GN_MAX_SAMPLES, sc, cfg.channels, L, nchunk, nblk);
+        } else {
+            hipLaunchKernelGGL(rms_partial_kernel, dim3((unsigned)(((int64_t)N * nchunk + 63) / 64)), dim3(64), 0, stream, x, part, N, cfg.channels, L, nchunk);
+            hipLaunchKernelGGL(rms_final_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, stream, part, sc, N, L, nchunk);
+        }
         cur.p = materialize(cur, N, sc, 0);
     }
     cur = sconv(enc_in, cur, nullptr, false, N);

@@ -276,13 +276,15 @@ struct EncodecModel : Codec {
     float* pad_act(const Act& a, const Act* b2, bool elu, int N, const Plan& pl);
     struct GnJob { bool on = false, fused = false, finished = false; int sub = 1, nrb = 0, ncb = 0; double* part = nullptr; float* stats = nullptr; };
     static constexpr int GN_MAX_SAMPLES = 4096;   // rows of a segment group (encode_dev caps a group at 4096)
-    DevBuf gn_counters;                           // [3 groups][GN_MAX_SAMPLES] arrival counters of the in-launch GroupNorm finish (zero between launches)
+    DevBuf gn_counters;                           // [3 groups][2][GN_MAX_SAMPLES] arrival counters of the in-launch GroupNorm finish (zero between launches; the second set: the
+                                                  // branch output of the fused first pass of a residual block, two outputs finishing in one launch)
     int cur_group = 0;
     GnJob gn_begin(const ConvLayer& conv, ConvIO& io, int N, int C, int64_t L, int sub);
     const float* gn_end(const GnJob& j, const float* raw, int N, int C, int64_t L);
     Act sconv(SConv& L, const Act& a, const Act* b2, bool elu, int N);
     Act sconvT(SConv& L, const Act& a, const Act* b2, bool elu, int N);
     void resblock(ResBlock& r, const Act& x, int N, Act& s, Act& y);
+    bool resblock_first_pass(ResBlock& r, const Act& x, int N, Act& s, Act& h);   // shortcut + k = 3 branch in one launch (nc_resa.hip); false: not this shape
     float* materialize(const Act& a, int N, const float* scale, int mode);
     float* run_lstm(Lstm& l, const float* x, int N, int64_t T, bool elu_out);
     void encode_batch(const float* x, int N, int64_t L, int64_t Tz, int64_t* codes, float* scale_out, float* emb_out);
