@@ -217,6 +217,20 @@ struct ResAArgs {
 };
 bool launch_res_a(const ResAArgs& a, int TMS, bool aligned, hipStream_t s);
 
+// arguments of the streaming two-input k = 4, stride-2 down-convolution of the Encodec encoder (nc_down2.hip down2_kernel)
+struct Down2Args {
+    const float* xa; const float* xb;   // the two pending operands [B][Cin][T] (same strides): shortcut and branch of the residual block
+    int64_t x_bstride, x_cstride;
+    int Cin, T, Tout;
+    const float* stats_a; const float* gamma_a; const float* beta_a;   // nullable together with the b set: GroupNorm(1,C) still pending
+    const float* stats_b; const float* gamma_b; const float* beta_b;
+    const float* w; const float* bias;  // packed image of the layer (K = 4, CB = 8, one row tile)
+    float* y; int64_t y_bstride, y_cstride; int Cout;
+    int B, n_t_tiles, n_cb;
+    double* gn_part; int gn_nrb, gn_ncb; unsigned* gn_count; float* gn_stats; double gn_n;
+};
+bool launch_down2(const Down2Args& a, int TM, bool aligned, hipStream_t s);
+
 // short-row strided convolution on v_mfma_f32_16x16x4_f32 (nc_conv_small.hip): plain input, bias-only epilogue
 bool conv_small_eligible(int Cin, int Cout, int K, int stride, int dil, bool transposed);
 void pack_conv_small(const float* dense_w, int Cin, int Cout, int K, std::vector<float>& out);

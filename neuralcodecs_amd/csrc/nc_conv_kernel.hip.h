@@ -18,26 +18,31 @@
 #define NC_TRACE_CB0 8
 #define NC_TRACE_NCB 8
 #endif
-#ifndef NC_STAGE_PRIO
-#define NC_STAGE_PRIO 0     // experiment: s_setprio of the staging runs of the segmented pipeline (0 = leave the priority alone)
+// ---- compile-time knobs of the template.  The SHIPPED build fixes every one of them to its shipped value: the A/B experiments of DESIGN 8
+// (rounds 4-5; results under profiles/r05_ab_*.txt) can only be compiled with -DNC_EXPERIMENTS (`make EXPERIMENTS=1` + tools/probe/mk_abl.sh),
+// and a -D override without it is an error -- one of them, NC_XV_SNAKE_ON=0, is a timing probe that computes WRONG results on purpose.
+#if !defined(NC_EXPERIMENTS) && (defined(NC_STAGE_PRIO) || defined(NC_LEGACY_ROWS) || defined(NC_XV_SNAKE_ILV) || defined(NC_XV_SNAKE_ON) || \
+                                 defined(NC_XV_FD) || defined(NC_XV_STORE_SEG))
+#error "NC_STAGE_PRIO / NC_LEGACY_ROWS / NC_XV_SNAKE_ILV / NC_XV_SNAKE_ON / NC_XV_FD / NC_XV_STORE_SEG are experiment knobs: build with -DNC_EXPERIMENTS"
 #endif
-#ifndef NC_LEGACY_ROWS   // staging Snake of the legacy instances: 2 = sign-free chains side by side (shipped), 1 = side by side with the parity select, 0 = pair by pair
+#ifndef NC_STAGE_PRIO
+#define NC_STAGE_PRIO 0     // s_setprio of the staging runs of the segmented pipeline (0 = leave the priority alone; measured: no gain)
+#endif
+#ifndef NC_LEGACY_ROWS      // staging Snake of the legacy instances: 2 = sign-free chains side by side (shipped), 1 = side by side with the parity select, 0 = pair by pair
 #define NC_LEGACY_ROWS 2
 #endif
-#ifndef NC_XV_SNAKE_ILV  // 1 = the Snake chains of a staging run step by step side by side (0: word by word, the round-5 first form)
+#ifndef NC_XV_SNAKE_ILV     // 1 = the Snake chains of a staging run step by step side by side (shipped); 0: word by word, the round-5 first form
 #define NC_XV_SNAKE_ILV 1
 #endif
-#ifndef NC_XV_SNAKE_ON   // 0 = timing probe only (WRONG results): what the staging Snake costs in total
+#ifndef NC_XV_SNAKE_ON      // 1 (shipped); 0 = timing probe only (WRONG results): what the staging Snake costs in total
 #define NC_XV_SNAKE_ON 1
 #endif
 #ifndef NC_XV_FD
-#define NC_XV_FD 1          // XV-only instances: fragment prefetch depth (experiment: 2)
+#define NC_XV_FD 1          // XV-only instances: fragment prefetch depth (2 measured: no gain)
 #endif
 #ifndef NC_XV_STORE_SEG
-#define NC_XV_STORE_SEG 3   // XV staging: the block's one staging run sits at the head of this matrix-core segment (0 .. 3; 4 = behind the last).
-#endif                      // Measured on one box (DAC conv_up class, ms per step): item form 6.54; XV at segment 1 / 2: 6.52 (no gain); at
-                            // segment 0: 6.25, 3: 6.21, 4: 6.27 -- ONE staging run per block next to the barrier, not the vector loads and not
-                            // the latency cover (the rotating schedule gives every position a whole block of it), is what pays: see DESIGN 8 r5.
+#define NC_XV_STORE_SEG 3   // XV staging: the block's one staging run sits at the head of this matrix-core segment (0 .. 3; 4 = behind the last):
+#endif                      // segment 3 measured best (profiles/r05_ab_xv_store_segment.txt)
 
 namespace nc {
 

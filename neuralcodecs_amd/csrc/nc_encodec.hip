@@ -985,26 +985,43 @@ struct LstmTicket {
     std::mutex mu;
     hipEvent_t ev = nullptr;   // behind the last persistent section enqueued on this device
     int live = 0;              // handles on this device that have run a persistent section
+    const void* last_owner = nullptr;   // the handle that recorded `ev`
 };
 static LstmTicket& lstm_ticket_of(int device) {
-    static std::mutex m;
-    static std::map<int, std::unique_ptr<LstmTicket>> t;
-    std::lock_guard<std::mutex> lk(m);
-    auto& p = t[device];
-    if (!p) p.reset(new LstmTicket());
+    // (leaked on purpose: handles destroyed during static destruction still find their ticket -- ADVICE r5)
+    static std::mutex* m = new std::mutex();
+    static std::map<int, LstmTicket*>* t = new std::map<int, LstmTicket*>();
+    std::lock_guard<std::mutex> lk(*m);
+    LstmTicket*& p = (*t)[device];
+    if (!p) p = new LstmTicket();
     return *p;
 }
 namespace {
 struct LstmSection {
     LstmTicket& t;
+    EncodecModel& m;
     hipStream_t s;
     std::unique_lock<std::mutex> lk;
-    LstmSection(EncodecModel& m, hipStream_t stream) : t(m.lstm_ticket ? *m.lstm_ticket : lstm_ticket_of(m.device)), s(stream), lk(t.mu) {
+    int unwinding_at_entry;
+    LstmSection(EncodecModel& model, hipStream_t stream)
+        : t(model.lstm_ticket ? *model.lstm_ticket : lstm_ticket_of(model.device)), m(model), s(stream), lk(t.mu), unwinding_at_entry(std::uncaught_exceptions()) {
         if (!m.lstm_ticket) { m.lstm_ticket = &t; ++t.live; }
         if (!t.ev) NC_HIP(hipEventCreateWithFlags(&t.ev, hipEventDisableTiming));
+        // (with more than one live handle EVERY section waits for the one before it, a handle's own included: the event is re-recorded by
+        //  each section, so the chain main group -> side group -> next handle is what keeps a third party behind all of them)
         else if (t.live > 1) NC_HIP(hipStreamWaitEvent(s, t.ev, 0));
     }
-    ~LstmSection() { if (t.ev) (void)hipEventRecord(t.ev, s); }
+    ~LstmSection() {
+        if (!t.ev) return;
+        if (std::uncaught_exceptions() > unwinding_at_entry) {
+            // error path: the layer-pipelined form may have left persistent launches on the second stream that were never joined into `s`;
+            // the ticket must not be handed on before they are done
+            if (m.lstm_stream) (void)hipStreamSynchronize(m.lstm_stream);
+            (void)hipStreamSynchronize(s);
+        }
+        (void)hipEventRecord(t.ev, s);
+        t.last_owner = &m;
+    }
 };
 }  // namespace
 
@@ -1023,6 +1040,11 @@ EncodecModel::~EncodecModel() {
     if (lstm_ticket) {
         std::lock_guard<std::mutex> lk(lstm_ticket->mu);
         --lstm_ticket->live;
+        if (lstm_ticket->last_owner == this) lstm_ticket->last_owner = nullptr;
+        if (lstm_ticket->live == 0 && lstm_ticket->ev) {   // (the last handle of the device: the event goes with it; the next first section makes a new one)
+            (void)hipEventDestroy(lstm_ticket->ev);
+            lstm_ticket->ev = nullptr;
+        }
     }
 }
 
@@ -1144,6 +1166,43 @@ static void second_input(ConvIO& io, const EncodecModel::Act& b2) {
 EncodecModel::Act EncodecModel::sconv(SConv& L, const Act& a, const Act* b2, bool elu, int N) {
     const Plan pl = plan_sconv(a.L, L.K, L.stride, 1);
     static const bool no_fuse = env_flag("NC_ENCODEC_NO_FUSE");
+    {   // the stride-2 down-convolution behind the first residual block: streaming two-input kernel (nc_down2.hip)
+        static const bool no_down2 = env_flag("NC_NO_DOWN2");
+        const int64_t T = a.L;
+        if (!no_down2 && !no_fuse && b2 && elu && !cfg.causal && !L.transposed && L.K == 4 && L.stride == 2 && L.conv.cfg.TM == 2 && L.conv.cfg.CB == 8 &&
+            L.Cout == 64 && !(L.Cin & 1) && L.Cin <= 128 && b2->C == a.C && b2->L == a.L && b2->rs == a.rs && (a.stats != nullptr) == (b2->stats != nullptr) &&
+            T >= 4 && !(T & 1) && pl.left == 1 && pl.right == 1 && pl.Lz == T && pl.Lout == T / 2 && (int64_t)(a.C + 1) * a.rs + T < ((int64_t)1 << 32) &&
+            (!cfg.time_group_norm || (N <= GN_MAX_SAMPLES && !env_flag("NC_NO_GN_FINISH")))) {
+            Down2Args d{};
+            d.xa = a.p + a.off; d.xb = b2->p + b2->off; d.x_bstride = (int64_t)a.C * a.rs; d.x_cstride = a.rs;
+            d.Cin = a.C; d.T = (int)T; d.Tout = (int)pl.Lout;
+            d.stats_a = a.stats; d.gamma_a = a.stats ? a.gamma : nullptr; d.beta_a = a.stats ? a.beta : nullptr;
+            d.stats_b = b2->stats; d.gamma_b = b2->stats ? b2->gamma : nullptr; d.beta_b = b2->stats ? b2->beta : nullptr;
+            d.w = L.conv.w.as<float>(); d.bias = L.conv.has_bias ? L.conv.bias.as<float>() : nullptr;
+            float* y = alloc((size_t)N * L.Cout * pl.Lout);
+            d.y = y; d.y_bstride = (int64_t)L.Cout * pl.Lout; d.y_cstride = pl.Lout; d.Cout = L.Cout;
+            d.B = N; d.n_t_tiles = (int)((pl.Lout + 127) / 128); d.n_cb = (L.Cin + 7) / 8;
+            float* st = nullptr;
+            if (cfg.time_group_norm) {
+                d.gn_nrb = L.Cout / 32; d.gn_ncb = (int)((pl.Lout + 31) / 32);
+                d.gn_part = reinterpret_cast<double*>(alloc((size_t)N * d.gn_nrb * d.gn_ncb * 4));
+                st = alloc((size_t)N * 2);
+                d.gn_stats = st;
+                d.gn_count = gn_counters.as<unsigned>() + (size_t)cur_group * 2 * GN_MAX_SAMPLES;
+                d.gn_n = gn_count_arg((double)L.Cout * (double)pl.Lout);
+            }
+            auto al8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; };
+            const bool aligned = al8(d.xa) && al8(d.xb) && !(d.x_cstride & 1) && !(d.x_bstride & 1);
+            {
+                ProfScope ps(&prof, stream, L.conv.kclass, L.conv.flops(N, pl.Lp), 4.0 * N * (2.0 * a.C * (double)T + (double)L.Cout * pl.Lout));
+                if (!launch_down2(d, 2, aligned, stream)) fail(NC_ESTATE, "internal: no streaming down-convolution instance");
+            }
+            Act o;
+            o.p = y; o.C = L.Cout; o.L = pl.Lout; o.rs = pl.Lout; o.off = 0;
+            o.stats = st; o.gamma = st ? L.gamma.as<float>() : nullptr; o.beta = st ? L.beta.as<float>() : nullptr;
+            return o;
+        }
+    }
     float* y = nullptr;
     ConvIO io{};
     const bool two_in = b2 && !no_fuse && conv_in2_available(L.conv) && b2->C == a.C && b2->L == a.L && b2->rs == a.rs &&

@@ -120,6 +120,37 @@ __device__ __forceinline__ nc_f2 nc_sinf2(nc_f2 x) {
     s[1] = (n1 & 1) ? -s[1] : s[1];
     return s;
 }
+// exp / ELU of a pair: nc_expf's operation sequence per component (clamps, range reduction, polynomial, scale by 2^n), the multiplies /
+// fmas / adds packed.  Bit-identical to nc_expf / nc_eluf per element, NaNs included (the clamps and the final choice are compare +
+// select per component, exactly as in the scalar form).  The Encodec input mode applies an ELU to every element a convolution stages;
+// next to a matrix-core stream those vector instructions are issue time the matrix pipe does not get back (DESIGN 8 rounds 4-6).
+__device__ __forceinline__ nc_f2 nc_expf2(nc_f2 x) {
+    x[0] = x[0] > 88.0f ? 88.0f : x[0];
+    x[1] = x[1] > 88.0f ? 88.0f : x[1];
+    x[0] = x[0] < -87.0f ? -87.0f : x[0];
+    x[1] = x[1] < -87.0f ? -87.0f : x[1];
+    const nc_f2 n = __builtin_elementwise_rint(x * 0x1.715476p+0f);
+    nc_f2 r = nc_fma2(n, (nc_f2)(-0x1.62e400p-1f), x);
+    r = nc_fma2(n, (nc_f2)(-0x1.7f7d1cp-20f), r);
+    nc_f2 q = (nc_f2)(0x1.6d5accp-10f);
+    q = nc_fma2(q, r, (nc_f2)(0x1.121f36p-7f));
+    q = nc_fma2(q, r, (nc_f2)(0x1.5554d8p-5f));
+    q = nc_fma2(q, r, (nc_f2)(0x1.5554cap-3f));
+    q = nc_fma2(q, r, (nc_f2)(0x1.000000p-1f));
+    const nc_f2 e = nc_fma2(r * r, q, r) + 1.0f;
+    const int32_t n0 = (int32_t)n[0], n1 = (int32_t)n[1];
+    nc_f2 sc;
+    sc[0] = __builtin_bit_cast(float, (uint32_t)(n0 + 127) << 23);
+    sc[1] = __builtin_bit_cast(float, (uint32_t)(n1 + 127) << 23);
+    return e * sc;
+}
+__device__ __forceinline__ nc_f2 nc_eluf2(nc_f2 x) {
+    const nc_f2 e = nc_expf2(x) - 1.0f;
+    nc_f2 y;
+    y[0] = x[0] > 0.0f ? x[0] : e[0];
+    y[1] = x[1] > 0.0f ? x[1] : e[1];
+    return y;
+}
 __device__ __forceinline__ nc_f2 nc_snakef2(nc_f2 x, nc_f2 alpha, nc_f2 inv) {
     const nc_f2 s = nc_sinf2(alpha * x);
     return x + (s * s) * inv;

@@ -62,6 +62,21 @@ def audit_object(obj, grep="", min_mfma=64):
         subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
                                "--input=" + fat, "--output=" + co])
         dis = subprocess.run([llvm + "/llvm-objdump", "-d", "--symbolize-operands", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+        notes = subprocess.run([llvm + "/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+    # the code object's kernel metadata (round 6): registers, spills and scratch -- a spill the loop audit cannot see (scratch traffic sits
+    # outside the counted mnemonics) shows up here as private_segment_fixed_size / vgpr_spill_count
+    res, cur = {}, {}
+    for l in notes.splitlines():
+        m = re.match(r"\s*-?\s*\.(name|private_segment_fixed_size|sgpr_count|sgpr_spill_count|vgpr_count|vgpr_spill_count|agpr_count|group_segment_fixed_size):\s+(\S+)", l)
+        if not m:
+            continue
+        k, v = m.group(1), m.group(2)
+        if k == "name":
+            if v.startswith("_Z") and not v.endswith(".kd"):
+                cur = res.setdefault(v, {})
+            continue
+        if cur is not None:
+            cur[k] = int(v)
     name, lines = None, []
 
     def flush():
@@ -81,7 +96,9 @@ def audit_object(obj, grep="", min_mfma=64):
                                   "v_readlane": c["v_readlane_b32"], "ds_read": sum(v for k, v in c.items() if k.startswith("ds_read")),
                                   "waits": c["s_waitcnt"]})
         if loops:
-            out[name] = {"loops": loops}
+            r = res.get(name, {})
+            out[name] = {"loops": loops, "scratch_bytes": r.get("private_segment_fixed_size"), "vgpr": r.get("vgpr_count"), "agpr": r.get("agpr_count"),
+                         "vgpr_spill": r.get("vgpr_spill_count"), "sgpr": r.get("sgpr_count"), "sgpr_spill": r.get("sgpr_spill_count")}
     for l in dis.splitlines():
         m = re.match(r"^[0-9a-f]+ <(_Z\w+)>:$", l)
         if m:
@@ -124,7 +141,21 @@ HOT = [
     ("nc_conv_k8.o", r"conv_mfma_kernelILi4ELi2ELi8ELi4ELi18ELb0ELi2ELi4ELi0ELb0ELi0ELb0E", "k = 8 stride-4 down-convolution (DAC 128 -> 256)"),
     ("nc_conv_k16.o", r"conv_mfma_kernelILi4ELi2ELi16ELi2ELi18ELb0ELi2ELi4ELi0ELb0ELi0ELb0E", "k = 16 stride-8 down-convolution (SNAC 44 kHz, long rows)"),
     ("nc_conv_k16.o", r"conv_mfma_kernelILi2ELi2ELi16ELi2ELi18ELb0ELi2ELi4ELi0ELb0ELi0ELb0E", "k = 16 stride-8, 64 x 256 tiles"),
+    ("nc_resa.o", r"res_a_kernelILi1ELb1E", "Encodec residual block, fused first pass, C = 32"),
+    ("nc_resa.o", r"res_a_kernelILi2ELb1E", "Encodec residual block, fused first pass, C = 64"),
 ]
+
+
+def compiler_version():
+    """First line of `hipcc --version`'s clang line: the record is only comparable under the compiler that produced it."""
+    try:
+        out = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True).stdout
+        for l in out.splitlines():
+            if "clang version" in l:
+                return l.strip()
+        return out.splitlines()[0].strip() if out else "unknown"
+    except OSError:
+        return "unknown"
 
 
 def hot_table(build_dir):
@@ -134,7 +165,8 @@ def hot_table(build_dir):
         if not os.path.exists(path):
             continue
         for k, v in audit_object(path, rx, 48).items():
-            tab[k] = {"object": obj, "what": what, "loops": v["loops"], "max_in_loop_v_readlane": max(lp["v_readlane"] for lp in v["loops"])}
+            tab[k] = {"object": obj, "what": what, "loops": v["loops"], "max_in_loop_v_readlane": max(lp["v_readlane"] for lp in v["loops"]),
+                      "scratch_bytes": v["scratch_bytes"], "vgpr": v["vgpr"], "vgpr_spill": v["vgpr_spill"], "sgpr": v["sgpr"], "sgpr_spill": v["sgpr_spill"]}
     return tab
 
 
@@ -143,11 +175,13 @@ def main():
         import json
         tab = hot_table(os.path.join(ROOT, "neuralcodecs_amd", "csrc", "build"))
         for k, v in tab.items():
-            print("%-3d %s  (%s)" % (v["max_in_loop_v_readlane"], k, v["what"]))
+            print("readlane %-3d scratch %-4s vgpr %-3s (+%s spilled) sgpr %-3s (+%s spilled)  %s  (%s)" % (
+                v["max_in_loop_v_readlane"], v["scratch_bytes"], v["vgpr"], v["vgpr_spill"], v["sgpr"], v["sgpr_spill"], k, v["what"]))
         if len(sys.argv) >= 3:
-            json.dump({"_about": "tools/isa_audit.py --table: in-loop instruction counts of the hot matrix-core instances, from the built objects "
-                                 "(static over all paths of a loop); tests/test_isa_audit_cpu.py holds the build to max_in_loop_v_readlane",
-                       "kernels": tab}, open(sys.argv[2], "w"), indent=1)
+            json.dump({"_about": "tools/isa_audit.py --table: in-loop instruction counts of the hot matrix-core instances and their register / spill / "
+                                 "scratch figures, from the built objects (static over all paths of a loop); tests/test_isa_audit_cpu.py holds the "
+                                 "build to max_in_loop_v_readlane, the vector-instruction counts, scratch_bytes and vgpr_spill",
+                       "compiler": compiler_version(), "kernels": tab}, open(sys.argv[2], "w"), indent=1)
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("source", help="a .hip source (compiled to assembly here) or a built .o (disassembled: fast)")
