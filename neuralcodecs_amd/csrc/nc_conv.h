@@ -230,6 +230,21 @@ struct Down2Args {
     double* gn_part; int gn_nrb, gn_ncb; unsigned* gn_count; float* gn_stats; double gn_n;
 };
 bool launch_down2(const Down2Args& a, int TM, bool aligned, hipStream_t s);
+bool launch_down4(const Down2Args& a, int TM, hipStream_t s);   // nc_down4.hip: k = 8, stride 4, 128 output rows, 16-byte aligned rows
+
+// arguments of the streaming two-input k = 4, stride-2 up-convolution of the Encodec decoder (nc_up2.hip up2_kernel)
+struct Up2Args {
+    const float* xa; const float* xb;   // the two pending operands [B][Cin][L] (same strides)
+    int64_t x_bstride, x_cstride;
+    int Cin, L, elu;
+    const float* stats_a; const float* gamma_a; const float* beta_a;   // nullable together with the b set
+    const float* stats_b; const float* gamma_b; const float* beta_b;
+    const float* w; const float* bias;  // sub-pixel image of the layer (rows co*2 + phase, two taps, CB = 16, one row tile); bias [Cout]
+    float* y; int64_t y_bstride, y_cstride; int Cout;   // UNTRIMMED output [B][Cout][S L + S]
+    int B, n_t_tiles, n_cb, n_co_tiles;
+    double* gn_part; int gn_nrb, gn_ncb; unsigned* gn_count; float* gn_stats; double gn_n;
+};
+bool launch_up2(const Up2Args& a, int TM, int S, bool aligned, hipStream_t s);   // S = stride: 2 (k = 4, TM = 2) or 4 (k = 8, TM = 4, two row tiles)
 
 // short-row strided convolution on v_mfma_f32_16x16x4_f32 (nc_conv_small.hip): plain input, bias-only epilogue
 bool conv_small_eligible(int Cin, int Cout, int K, int stride, int dil, bool transposed);

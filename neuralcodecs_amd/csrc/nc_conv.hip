@@ -546,7 +546,10 @@ static int conv_small_choice(const ConvLayer& L, const ConvIO& io, int B) {
     static const int64_t wide_below = env_int("NC_SMALL_WIDE_BELOW", 512);
     const int64_t Tout = L.out_len(io.Tin);
     if (L.K == 1) {   // wide pointwise GEMMs over few columns (the chunked LSTM input projections): 32-column form only
-        static const int64_t k1_cols = env_int("NC_SMALL_K1_COLS", 4096);
+        // (round 6: up to 1024 columns, was 4096 -- every 64-row x 32-column workgroup streams its 128 KB weight panel out of L2, so the 44-step
+        //  chunks of C3 (1408 columns: 1408 workgroups, 180 MB of panels, 54 us) run faster on the pointwise kernel's 256-column tiles:
+        //  C3 8.47 -> 8.38 ms, C2 53.80 -> 53.67 ms, C5 / C1 unchanged; tools/probe/r6_k1cols2.sh)
+        static const int64_t k1_cols = env_int("NC_SMALL_K1_COLS", 1024);
         return (!io.gn_part && (int64_t)B * Tout <= k1_cols) ? 2 : 0;
     }
     const int64_t grid16 = (int64_t)B * ((Tout + 15) / 16) * ((L.Cout + 63) / 64);

@@ -1166,13 +1166,19 @@ static void second_input(ConvIO& io, const EncodecModel::Act& b2) {
 EncodecModel::Act EncodecModel::sconv(SConv& L, const Act& a, const Act* b2, bool elu, int N) {
     const Plan pl = plan_sconv(a.L, L.K, L.stride, 1);
     static const bool no_fuse = env_flag("NC_ENCODEC_NO_FUSE");
-    {   // the stride-2 down-convolution behind the first residual block: streaming two-input kernel (nc_down2.hip)
+    {   // the stride-2 / stride-4 down-convolutions behind the first two residual blocks: streaming two-input kernels (nc_down2.hip, nc_down4.hip)
         static const bool no_down2 = env_flag("NC_NO_DOWN2");
+        static const bool no_down4 = env_flag("NC_NO_DOWN4");
         const int64_t T = a.L;
-        if (!no_down2 && !no_fuse && b2 && elu && !cfg.causal && !L.transposed && L.K == 4 && L.stride == 2 && L.conv.cfg.TM == 2 && L.conv.cfg.CB == 8 &&
-            L.Cout == 64 && !(L.Cin & 1) && L.Cin <= 128 && b2->C == a.C && b2->L == a.L && b2->rs == a.rs && (a.stats != nullptr) == (b2->stats != nullptr) &&
-            T >= 4 && !(T & 1) && pl.left == 1 && pl.right == 1 && pl.Lz == T && pl.Lout == T / 2 && (int64_t)(a.C + 1) * a.rs + T < ((int64_t)1 << 32) &&
-            (!cfg.time_group_norm || (N <= GN_MAX_SAMPLES && !env_flag("NC_NO_GN_FINISH")))) {
+        const bool common = !no_fuse && b2 && elu && !cfg.causal && !L.transposed && !(L.Cin & 1) && L.Cin <= 128 && b2->C == a.C && b2->L == a.L &&
+                            b2->rs == a.rs && (a.stats != nullptr) == (b2->stats != nullptr) && pl.Lz == T && (int64_t)(a.C + 1) * a.rs + T < ((int64_t)1 << 32) &&
+                            (!cfg.time_group_norm || (N <= GN_MAX_SAMPLES && !env_flag("NC_NO_GN_FINISH")));
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        const bool s2 = common && !no_down2 && L.K == 4 && L.stride == 2 && L.conv.cfg.TM == 2 && L.conv.cfg.CB == 8 && L.Cout == 64 && T >= 4 && !(T & 1) &&
+                        pl.left == 1 && pl.right == 1 && pl.Lout == T / 2;
+        const bool s4 = common && !no_down4 && L.K == 8 && L.stride == 4 && L.conv.cfg.TM == 4 && L.conv.cfg.CB == 4 && L.Cout == 128 && L.Cin % 8 == 0 && T >= 8 &&
+                        !(T & 3) && pl.left == 2 && pl.right == 2 && pl.Lout == T / 4 && !(a.rs & 3) && al16(a.p + a.off) && al16(b2->p + b2->off);
+        if (s2 || s4) {
             Down2Args d{};
             d.xa = a.p + a.off; d.xb = b2->p + b2->off; d.x_bstride = (int64_t)a.C * a.rs; d.x_cstride = a.rs;
             d.Cin = a.C; d.T = (int)T; d.Tout = (int)pl.Lout;
@@ -1181,7 +1187,7 @@ EncodecModel::Act EncodecModel::sconv(SConv& L, const Act& a, const Act* b2, boo
             d.w = L.conv.w.as<float>(); d.bias = L.conv.has_bias ? L.conv.bias.as<float>() : nullptr;
             float* y = alloc((size_t)N * L.Cout * pl.Lout);
             d.y = y; d.y_bstride = (int64_t)L.Cout * pl.Lout; d.y_cstride = pl.Lout; d.Cout = L.Cout;
-            d.B = N; d.n_t_tiles = (int)((pl.Lout + 127) / 128); d.n_cb = (L.Cin + 7) / 8;
+            d.B = N; d.n_t_tiles = (int)((pl.Lout + 127) / 128); d.n_cb = (L.Cin + 7) / 8;   // (both kernels walk 8 input channels per barrier; the stride-4 one = two blocks of its CB = 4 image)
             float* st = nullptr;
             if (cfg.time_group_norm) {
                 d.gn_nrb = L.Cout / 32; d.gn_ncb = (int)((pl.Lout + 31) / 32);
@@ -1195,7 +1201,7 @@ EncodecModel::Act EncodecModel::sconv(SConv& L, const Act& a, const Act* b2, boo
             const bool aligned = al8(d.xa) && al8(d.xb) && !(d.x_cstride & 1) && !(d.x_bstride & 1);
             {
                 ProfScope ps(&prof, stream, L.conv.kclass, L.conv.flops(N, pl.Lp), 4.0 * N * (2.0 * a.C * (double)T + (double)L.Cout * pl.Lout));
-                if (!launch_down2(d, 2, aligned, stream)) fail(NC_ESTATE, "internal: no streaming down-convolution instance");
+                if (!(s4 ? launch_down4(d, 4, stream) : launch_down2(d, 2, aligned, stream))) fail(NC_ESTATE, "internal: no streaming down-convolution instance");
             }
             Act o;
             o.p = y; o.C = L.Cout; o.L = pl.Lout; o.rs = pl.Lout; o.off = 0;
@@ -1232,6 +1238,49 @@ EncodecModel::Act EncodecModel::sconv(SConv& L, const Act& a, const Act* b2, boo
 EncodecModel::Act EncodecModel::sconvT(SConv& L, const Act& a, const Act* b2, bool elu, int N) {
     static const bool no_fuse = env_flag("NC_ENCODEC_NO_FUSE");
     const int64_t Lfull = (a.L - 1) * L.stride + L.K;
+    {   // the stride-2 / stride-4 up-convolutions in front of the last two residual blocks: streaming two-input kernel (nc_up2.hip)
+        static const bool no_up2 = env_flag("NC_NO_UP2");
+        static const bool no_up4 = env_flag("NC_NO_UP4");
+        const int64_t T = a.L;
+        const int S = L.stride;
+        const bool common = !no_fuse && b2 && !cfg.causal && L.transposed && L.K == 2 * S && L.conv.sub_stride == S && L.conv.n_phase == 1 && L.conv.cfg.CB == 16 &&
+                            !(L.Cin & 1) && L.Cin <= 128 && b2->C == a.C && b2->L == a.L && b2->rs == a.rs && (a.stats != nullptr) == (b2->stats != nullptr) &&
+                            T >= 4 && !(T & 1) && (int64_t)(a.C + 1) * a.rs + T < ((int64_t)1 << 32) && (int64_t)L.Cout * Lfull < ((int64_t)1 << 31) &&
+                            (!cfg.time_group_norm || (N <= GN_MAX_SAMPLES && !env_flag("NC_NO_GN_FINISH")));
+        const bool u2 = common && !no_up2 && S == 2 && L.conv.cfg.TM == 2 && L.Cout == 32;
+        const bool u4 = common && !no_up4 && S == 4 && L.conv.cfg.TM == 4 && L.Cout == 64;
+        if (u2 || u4) {
+            Up2Args d{};
+            d.xa = a.p + a.off; d.xb = b2->p + b2->off; d.x_bstride = (int64_t)a.C * a.rs; d.x_cstride = a.rs;
+            d.Cin = a.C; d.L = (int)T; d.elu = elu ? 1 : 0;
+            d.stats_a = a.stats; d.gamma_a = a.stats ? a.gamma : nullptr; d.beta_a = a.stats ? a.beta : nullptr;
+            d.stats_b = b2->stats; d.gamma_b = b2->stats ? b2->gamma : nullptr; d.beta_b = b2->stats ? b2->beta : nullptr;
+            d.w = L.conv.w.as<float>(); d.bias = L.conv.has_bias ? L.conv.bias.as<float>() : nullptr;
+            float* y = alloc((size_t)N * L.Cout * Lfull);
+            d.y = y; d.y_bstride = (int64_t)L.Cout * Lfull; d.y_cstride = Lfull; d.Cout = L.Cout;
+            d.B = N; d.n_t_tiles = (int)((T + 1 + 255) / 256); d.n_cb = (L.Cin + 15) / 16; d.n_co_tiles = S * L.Cout / (32 * L.conv.cfg.TM);
+            float* st = nullptr;
+            if (cfg.time_group_norm) {
+                d.gn_nrb = S * L.Cout / 32; d.gn_ncb = (int)(((Lfull + S - 1) / S + 31) / 32);
+                d.gn_part = reinterpret_cast<double*>(alloc((size_t)N * d.gn_nrb * d.gn_ncb * 4));
+                st = alloc((size_t)N * 2);
+                d.gn_stats = st;
+                d.gn_count = gn_counters.as<unsigned>() + (size_t)cur_group * 2 * GN_MAX_SAMPLES;
+                d.gn_n = gn_count_arg((double)L.Cout * (double)Lfull);
+            }
+            auto al8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; };
+            const bool aligned = al8(d.xa) && al8(d.xb) && !(d.x_cstride & 1) && !(d.x_bstride & 1);
+            {
+                ProfScope ps(&prof, stream, L.conv.kclass, L.conv.flops(N, T), 4.0 * N * (2.0 * a.C * (double)T + (double)L.Cout * Lfull));
+                if (!launch_up2(d, L.conv.cfg.TM, S, aligned, stream)) fail(NC_ESTATE, "internal: no streaming up-convolution instance");
+            }
+            const int64_t pt = L.K - L.stride, right = pt / 2, left = pt - right;           // non-causal trim (SConvTranspose1d.cs:159-171)
+            Act o;
+            o.p = y; o.C = L.Cout; o.L = Lfull - left - right; o.rs = Lfull; o.off = left;
+            o.stats = st; o.gamma = st ? L.gamma.as<float>() : nullptr; o.beta = st ? L.beta.as<float>() : nullptr;
+            return o;
+        }
+    }
     ConvIO io{};
     const bool two_in = b2 && !no_fuse && conv_in2_available(L.conv) && b2->C == a.C && b2->L == a.L && b2->rs == a.rs &&
                         (a.stats != nullptr) == (b2->stats != nullptr);

@@ -9,7 +9,7 @@ Every dispatch is assigned a kernel class: by kernel name (dwconv_kernel -> dwco
 implicit-GEMM template that serves several classes under one name, by zipping the engine's launch log (NC_LAUNCH_LOG, one line
 per template launch in launch order) with the template's counter rows in dispatch order (thread counts must agree).
 FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH is doubled (gfx950 tallies 128-B read requests as 64 B,
-MI355X_MICROARCH.md "HBM").  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES): SQ_BUSY_CU_CYCLES sums, over
+MI355X_MICROARCH.md "HBM").  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES); valu_busy = SQ_ACTIVE_INST_VALU (quad-cycles) / SQ_BUSY_CU_CYCLES; pipe_busy = their sum: SQ_BUSY_CU_CYCLES sums, over
 the CUs, the cycles a CU had a wave resident; the MFMA counter sums busy cycles over the SIMDs.
 """
 import argparse
@@ -21,11 +21,11 @@ import sys
 from collections import OrderedDict, defaultdict
 
 KC = ("conv_k7", "conv_k1", "conv_down", "conv_up", "conv_misc", "rvq", "elem", "dwconv", "norm", "attn", "lstm", "stem", "head")
-BY_NAME = [(r"conv1x1_kernel|conv1x1_stream_kernel|skinny_proj|snac_unit_kernel", "conv_k1"), (r"conv3_stream_kernel", "conv_misc"), (r"conv_small", "conv_down"),   # (the short-row kernel also serves two k=7 layers of the conv_misc class)
+BY_NAME = [(r"conv1x1_kernel|conv1x1_stream_kernel|skinny_proj|snac_unit_kernel|res_a_kernel", "conv_k1"), (r"conv3_stream_kernel", "conv_misc"), (r"conv_small|down2_kernel|down4_kernel", "conv_down"), (r"up2_kernel", "conv_up"),   # (the short-row kernel also serves two k=7 layers of the conv_misc class)
            (r"dwconv_kernel|dwconv_vec_kernel", "dwconv"), (r"layernorm_ct|layernorm_tile|gn_block|gn_final|gn_", "norm"),
            (r"local_attn", "attn"), (r"lstm_|lstm2_", "lstm"), (r"stem_", "stem"), (r"conv_thin(_inm)?_kernel", "head"),
            (r"vq_argmin|vq_gather|euclid_vq|euclid_rvq|dac_rvq|emb_sum", "rvq"),
-           (r"avg_pool|rvq_update|pad_act|scale_kernel|overlap_add|rms_|randn", "elem")]
+           (r"avg_pool|rvq_update|pad_act|scale_kernel|overlap_add|rms_|randn", "elem")]   # (rms_ covers rms_scale_kernel)
 
 
 def load(path_csv, path_log):
@@ -97,6 +97,14 @@ def main():
             e["mfma_busy"] = round(mb / (4.0 * bc), 4)
             e["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] = mb / cnt[cls]["SQ_VALU_MFMA_BUSY_CYCLES"]
             e["SQ_BUSY_CU_CYCLES_per_launch"] = bc / cnt[cls]["SQ_BUSY_CU_CYCLES"]
+        va = acc[cls].get("SQ_ACTIVE_INST_VALU")
+        if va is not None and bc:
+            # round 6: on gfx950 the f32 matrix-core instructions and the vector ALU share one pipe per SIMD (profiles/r06_pipe_counters_encodec.txt):
+            # SQ_ACTIVE_INST_VALU counts quad-cycles of vector instructions, so valu_busy = 4 * it / (4 SIMDs * busy CU cycles), and
+            # pipe_busy = mfma_busy + valu_busy is the fraction of the SHARED pipe's cycles the class keeps occupied
+            e["valu_busy"] = round(va / bc, 4)
+            if "mfma_busy" in e:
+                e["pipe_busy"] = round(e["mfma_busy"] + e["valu_busy"], 4)
         res[cls] = e
     res["_method"] = ("rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES, kernel trace only) of the bench "
                       "command; classes by kernel name + engine launch log (tools/pmc_classes.py); FETCH doubled per MI355X_MICROARCH.md")

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (via gpurun): the profiles a round commits under profiles/.
 #   1. rocprofv3 kernel trace (+ --stats) of the headline bench command            -> <tag>_dac_b32.kernel_stats.txt
 #   2. kernel traces of the other BASELINE configs (tools/codecbench.py)           -> <tag>_{encodec48,snac44,snac24}.kernel_stats.txt
-#   3. PMC passes (kernel trace only, one counter set per pass: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES)
+#   3. PMC passes (kernel trace only, one counter set per pass: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU)
 #      of the bench command and of the C3 / C5-share commands, each with the engine's launch log (NC_LAUNCH_LOG) so that
 #      tools/pmc_classes.py can attribute counters to exactly the launches a kernel class counts       -> traffic.json
 # Outputs land under gpurun_out/prof_<tag>/; copy the summaries to profiles/ afterwards.
@@ -28,7 +28,7 @@ for wl in dac encodec48 snac44; do
     if [ $wl = dac ]; then CMD="$BENCH --steps 2 --warmup 1"; else CMD="python3 $R/tools/codecbench.py --only $wl --steps 2 --warmup 1"; fi
     pmc_pass ${wl}_fetch "FETCH_SIZE" $CMD
     pmc_pass ${wl}_write "WRITE_SIZE" $CMD
-    pmc_pass ${wl}_sq "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" $CMD
+    pmc_pass ${wl}_sq "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU" $CMD
 done
 rm -rf $OUT/trace_*/*/*.db.tmp
 find $OUT -name '*.csv' | head -40
