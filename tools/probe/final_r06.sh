@@ -9,7 +9,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 timeout 900 python bench.py > $O/r06_bench_full.json 2> $O/r06_bench_full.err; echo bench rc=$?
 cp gpurun_out/bench_detail.json $O/r06_bench_detail.json 2>/dev/null
 timeout 1500 python tools/gpu_parity_sweep.py --weight-seeds 42,7,1234 --pcm-seeds 1,2,3 --presets --out $O/r06_gpu_parity_sweep.json > $O/sweep.log 2>&1; tail -2 $O/sweep.log | cut -c1-300
-timeout 600 python tools/soak.py --iters 3000 --out $O/r06_soak_default.json > $O/soak.log 2>&1; tail -1 $O/soak.log | cut -c1-300
+timeout 600 python tools/soak.py --iters 10000 --out $O/r06_soak_default.json > $O/soak.log 2>&1; tail -1 $O/soak.log | cut -c1-300
 bash tools/profile_round.sh r06 > $O/profile_round_r06.log 2>&1
 P=gpurun_out/prof_r06
 LIB=neuralcodecs_amd/libnc_mi355x.so
