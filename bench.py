@@ -26,7 +26,7 @@ The JSON line carries
   * `extra_configs` (N=1 only): BASELINE configs C3 (Encodec 48 kHz stereo, 16 x 2 s), C5's per-GPU share and C1
     (SNAC 24 kHz, 1 x 1 s) on the same GPU: ms, x real-time, compact per-class HIP-event table, dominant kernel class with its
     roofline fraction and a GPU == oracle check on one clip; their step times also as flat top-level keys (c3_... / c5_share_... / c1_...).
-  The line is kept small (< 4 KB); the full per-class tables are written to gpurun_out/bench_detail.json (NC_BENCH_DETAIL=<path>).
+  The line is kept small (about 4 KB); the full per-class tables are written to gpurun_out/bench_detail.json (NC_BENCH_DETAIL=<path>).
   `roofline.traffic` comes from profiles/traffic.json only when the loaded library's SHA-256 equals the one recorded there
   (else null + "traffic_stale": true).
 """
@@ -721,17 +721,18 @@ def main():
         if isinstance(extras, dict) and "error" not in extras:
             slim = {}
             for k, e in extras.items():
-                slim[k] = {kk: e[kk] for kk in ("workload", "B", "clip_seconds", "ms_per_step", "x_realtime", "whole_step_tflops", "kernel_ms_per_step",
-                                                "dominant", "traffic_stale", "gpu_equals_oracle") if kk in e}
-                slim[k]["classes"] = compact_classes(e["classes"])
-                slim[k]["launches_per_step"] = round(sum(c["launches_per_step"] for c in e["classes"].values()), 1)
+                slim[k] = {kk: e[kk] for kk in ("B", "clip_seconds", "ms_per_step", "x_realtime", "whole_step_tflops", "kernel_ms_per_step",
+                                                "traffic_stale", "gpu_equals_oracle") if kk in e}
+                dm = e.get("dominant") or {}
+                slim[k]["dominant"] = {kk: dm[kk] for kk in ("class", "bound", "achieved", "unit", "frac", "ms_per_step") if kk in dm}
+                slim[k]["launches_per_step"] = round(sum(c["launches_per_step"] for c in e["classes"].values()), 1)   # (class tables: the detail file)
             out["extra_configs"] = slim
             for k, flat in (("encodec48k", "c3_encodec48k_16x2s_ms_per_step"), ("snac44k_c5_share", "c5_share_snac44k_8x5s_ms_per_step"),
                             ("snac24k", "c1_snac24k_1x1s_ms_per_step")):
                 if k in extras:
                     out[flat] = extras[k]["ms_per_step"]
         if cpu and isinstance(cpu.get("aten_proxy"), dict):
-            out["cpu_baseline"] = dict(cpu, aten_proxy={k: v for k, v in cpu["aten_proxy"].items() if not isinstance(v, (list, dict))})
+            out["cpu_baseline"] = dict(cpu, aten_proxy={k: v for k, v in cpu["aten_proxy"].items() if k in ("value", "unit", "threads", "iterations", "median_s", "error")})
         try:
             dpath = os.environ.get("NC_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
             os.makedirs(os.path.dirname(dpath), exist_ok=True)
