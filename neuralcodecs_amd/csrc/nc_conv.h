@@ -227,10 +227,12 @@ struct Down2Args {
     const float* w; const float* bias;  // packed image of the layer (K = 4, CB = 8, one row tile)
     float* y; int64_t y_bstride, y_cstride; int Cout;
     int B, n_t_tiles, n_cb;
+    int n_co_tiles; int64_t w_co_stride;   // down5_kernel: row tiles of 128 and the float offset between their weight images (1 / 0 elsewhere)
     double* gn_part; int gn_nrb, gn_ncb; unsigned* gn_count; float* gn_stats; double gn_n;
 };
 bool launch_down2(const Down2Args& a, int TM, bool aligned, hipStream_t s);
 bool launch_down4(const Down2Args& a, int TM, hipStream_t s);   // nc_down4.hip: k = 8, stride 4, 128 output rows, 16-byte aligned rows
+bool launch_down5(const Down2Args& a, int TM, hipStream_t s);   // nc_down5.hip: k = 10, stride 5, 256 output rows as two row tiles
 
 // arguments of the streaming two-input k = 4, stride-2 up-convolution of the Encodec decoder (nc_up2.hip up2_kernel)
 struct Up2Args {

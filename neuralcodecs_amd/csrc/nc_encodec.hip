@@ -1178,7 +1178,10 @@ EncodecModel::Act EncodecModel::sconv(SConv& L, const Act& a, const Act* b2, boo
                         pl.left == 1 && pl.right == 1 && pl.Lout == T / 2;
         const bool s4 = common && !no_down4 && L.K == 8 && L.stride == 4 && L.conv.cfg.TM == 4 && L.conv.cfg.CB == 4 && L.Cout == 128 && L.Cin % 8 == 0 && T >= 8 &&
                         !(T & 3) && pl.left == 2 && pl.right == 2 && pl.Lout == T / 4 && !(a.rs & 3) && al16(a.p + a.off) && al16(b2->p + b2->off);
-        if (s2 || s4) {
+        static const bool no_down5 = env_flag("NC_NO_DOWN5");
+        const bool s5 = common && !no_down5 && L.K == 10 && L.stride == 5 && L.conv.cfg.TM == 4 && L.conv.cfg.CB == 3 && L.Cout == 256 && L.Cin % 4 == 0 && T >= 10 &&
+                        T % 5 == 0 && pl.left == 3 && pl.right == 2 && pl.Lout == T / 5;
+        if (s2 || s4 || s5) {
             Down2Args d{};
             d.xa = a.p + a.off; d.xb = b2->p + b2->off; d.x_bstride = (int64_t)a.C * a.rs; d.x_cstride = a.rs;
             d.Cin = a.C; d.T = (int)T; d.Tout = (int)pl.Lout;
@@ -1188,6 +1191,11 @@ EncodecModel::Act EncodecModel::sconv(SConv& L, const Act& a, const Act* b2, boo
             float* y = alloc((size_t)N * L.Cout * pl.Lout);
             d.y = y; d.y_bstride = (int64_t)L.Cout * pl.Lout; d.y_cstride = pl.Lout; d.Cout = L.Cout;
             d.B = N; d.n_t_tiles = (int)((pl.Lout + 127) / 128); d.n_cb = (L.Cin + 7) / 8;   // (both kernels walk 8 input channels per barrier; the stride-4 one = two blocks of its CB = 4 image)
+            d.n_co_tiles = 1; d.w_co_stride = 0;
+            if (s5) {   // four channels per barrier; two row tiles of 128 whose images lie n_cb * KB * BM floats apart
+                d.n_cb = L.Cin / 4; d.n_co_tiles = L.Cout / 128;
+                d.w_co_stride = (int64_t)((L.Cin + 2) / 3) * 30 * 128;
+            }
             float* st = nullptr;
             if (cfg.time_group_norm) {
                 d.gn_nrb = L.Cout / 32; d.gn_ncb = (int)((pl.Lout + 31) / 32);
@@ -1201,7 +1209,8 @@ EncodecModel::Act EncodecModel::sconv(SConv& L, const Act& a, const Act* b2, boo
             const bool aligned = al8(d.xa) && al8(d.xb) && !(d.x_cstride & 1) && !(d.x_bstride & 1);
             {
                 ProfScope ps(&prof, stream, L.conv.kclass, L.conv.flops(N, pl.Lp), 4.0 * N * (2.0 * a.C * (double)T + (double)L.Cout * pl.Lout));
-                if (!(s4 ? launch_down4(d, 4, stream) : launch_down2(d, 2, aligned, stream))) fail(NC_ESTATE, "internal: no streaming down-convolution instance");
+                if (!(s5 ? launch_down5(d, 4, stream) : s4 ? launch_down4(d, 4, stream) : launch_down2(d, 2, aligned, stream)))
+                    fail(NC_ESTATE, "internal: no streaming down-convolution instance");
             }
             Act o;
             o.p = y; o.C = L.Cout; o.L = pl.Lout; o.rs = pl.Lout; o.off = 0;

@@ -67,6 +67,7 @@ const EnvRow kEnv[] = {
     {"NC_DAC_PITCH", 'b', "DAC activation rows at pitch L rounded up to 16 samples (64-byte aligned rows: the 696-step layers take the XV-only instances; measured slower)"},
     {"NC_NO_DOWN2", 'b', "Encodec 48 kHz encoder: the windowed two-input instance for the stride-2 down-convolution instead of the streaming kernel"},
     {"NC_NO_DOWN4", 'b', "Encodec 48 kHz encoder: summed copy + windowed instance for the stride-4 down-convolution instead of the streaming kernel"},
+    {"NC_NO_DOWN5", 'b', "Encodec 48 kHz encoder: summed copy + windowed instance for the stride-5 down-convolution instead of the streaming kernel"},
     {"NC_NO_UP4", 'b', "Encodec 48 kHz decoder: summed copy + windowed instance for the stride-4 up-convolution instead of the streaming kernel"},
     {"NC_NO_UP2", 'b', "Encodec 48 kHz decoder: the windowed two-input instance for the stride-2 up-convolution instead of the streaming kernel"},
     {"NC_RMS_TWO_PASS", 'b', "Encodec RMS scale as two launches (chunk sums, final) instead of the one-launch form"},

@@ -21,7 +21,7 @@ import sys
 from collections import OrderedDict, defaultdict
 
 KC = ("conv_k7", "conv_k1", "conv_down", "conv_up", "conv_misc", "rvq", "elem", "dwconv", "norm", "attn", "lstm", "stem", "head")
-BY_NAME = [(r"conv1x1_kernel|conv1x1_stream_kernel|skinny_proj|snac_unit_kernel|res_a_kernel", "conv_k1"), (r"conv3_stream_kernel", "conv_misc"), (r"conv_small|down2_kernel|down4_kernel", "conv_down"), (r"up2_kernel", "conv_up"),   # (the short-row kernel also serves two k=7 layers of the conv_misc class)
+BY_NAME = [(r"conv1x1_kernel|conv1x1_stream_kernel|skinny_proj|snac_unit_kernel|res_a_kernel", "conv_k1"), (r"conv3_stream_kernel", "conv_misc"), (r"conv_small|down2_kernel|down4_kernel|down5_kernel", "conv_down"), (r"up2_kernel", "conv_up"),   # (the short-row kernel also serves two k=7 layers of the conv_misc class)
            (r"dwconv_kernel|dwconv_vec_kernel", "dwconv"), (r"layernorm_ct|layernorm_tile|gn_block|gn_final|gn_", "norm"),
            (r"local_attn", "attn"), (r"lstm_|lstm2_", "lstm"), (r"stem_", "stem"), (r"conv_thin(_inm)?_kernel", "head"),
            (r"vq_argmin|vq_gather|euclid_vq|euclid_rvq|dac_rvq|emb_sum", "rvq"),
