@@ -78,6 +78,13 @@ Rccl& rccl() {
         if (r__ != ncclSuccess) fail(NC_EDEVICE, "%s failed: %s", #expr, rccl().GetErrorString(r__));      \
     } while (0)
 
+// The local-mode entry points walk the members' devices with hipSetDevice: the caller's current device is put back on the way out
+struct DeviceRestore {
+    int dev = -1;
+    DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+
 template <class F>
 nc_status guard(F&& f) {
     try {
@@ -289,6 +296,7 @@ void rank_encode_allgather(nc_group* g, int kind, const float* pcm, int B, int64
 // batches gather with one collective and the padding rows are dropped on the way back to the host.  One host thread per device stages
 // its block through pinned memory, uploads, and queues the encode; the grouped all-gather is issued by the calling thread.
 void local_encode_allgather(nc_group* g, int kind, const float* pcm, int B_total, int64_t T, int sample_rate, int n_q, int64_t* codes, float* z) {
+    DeviceRestore restore_device;
     if (!g || g->rank >= 0) fail(NC_EINVAL, "group was not created with nc_group_create_local");
     if (!pcm || !codes || B_total <= 0 || T <= 0) fail(NC_EINVAL, "bad arguments");
     const int W = g->world;
@@ -393,6 +401,7 @@ void local_encode_allgather(nc_group* g, int kind, const float* pcm, int B_total
 // caller queues next on a codec's stream (the local decode) overlaps it.  Nothing here waits on the host.
 void local_encode_allgather_dev(nc_group* g, int kind, const float* const* pcm, const int32_t* B_local, int64_t T, int sample_rate, int n_q,
                                 int64_t* const* codes_all, float* const* z, float* const* lat) {
+    DeviceRestore restore_device;
     if (!g || g->rank >= 0) fail(NC_EINVAL, "group was not created with nc_group_create_local");
     if (!pcm || !B_local || !codes_all || T <= 0) fail(NC_EINVAL, "bad arguments");
     const int W = g->world;
@@ -478,6 +487,7 @@ void rank_encodec_allgather(nc_group* g, const float* pcm, int B, int64_t T, int
 
 void local_encodec_allgather_dev(nc_group* g, const float* const* pcm, const int32_t* B_local, int64_t T, int64_t* const* codes_all,
                                  float* const* scales_all) {
+    DeviceRestore restore_device;
     if (!g || g->rank >= 0) fail(NC_EINVAL, "group was not created with nc_group_create_local");
     if (!pcm || !B_local || !codes_all || T <= 0) fail(NC_EINVAL, "bad arguments");
     const int W = g->world;
@@ -562,6 +572,7 @@ void create_local(int32_t ndev, nc_codec* const* handles, uint32_t flags, nc_gro
     *out = nullptr;
     if (ndev <= 0 || ndev > 64) fail(NC_EINVAL, "bad device count %d", ndev);
     if (flags & ~(uint32_t)NC_GROUP_PEER_COPY) fail(NC_EINVAL, "unknown group flags 0x%x", flags);
+    DeviceRestore restore_device;
     std::unique_ptr<nc_group> g(new nc_group());
     g->world = ndev; g->rank = -1;
     g->peer_copy = (flags & NC_GROUP_PEER_COPY) != 0;
@@ -637,6 +648,7 @@ nc_status nc_group_snac_encode_allgather_dev(nc_group* g, const float* pcm, int3
 nc_status nc_group_wait(nc_group* g) {
     return guard([&] {
         if (!g || g->m.empty()) fail(NC_EINVAL, "null group");
+        DeviceRestore restore_device;
         for (auto& x : g->m) {
             (void)hipSetDevice(x.device);
             NC_HIP(hipStreamWaitEvent(x.h->impl->stream, x.ev_gather, 0));
