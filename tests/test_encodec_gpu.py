@@ -147,3 +147,18 @@ def test_encodec_tied_codebooks_first_index_full_width(preset, bw):
         frames, _, _ = _check_vs_oracle(m, c_oracle.RefEncodec(cfg, blob), pcm)
     for f in frames:
         assert f.codes.max() < cfg.codebook_size // 2 and not np.any(f.codes % 7 == 0), "a tie was not resolved to the first index"
+
+
+@pytest.mark.parametrize("tail", [482, 500, 966, 1000, 4444, 12346, 20002])
+def test_encodec48k_streaming_kernels_on_odd_segment_lengths(tail):
+    """Round 6: the streaming kernels of the 48 kHz model's outer stages (fused first pass of the residual blocks, stride-2 / 4 / 5 down- and
+    stride-2 / 4 up-convolutions: nc_resa / nc_down2 / nc_down4 / nc_down5 / nc_up2) take a layer only when its row length suits their lane
+    layout (even, a multiple of 4 / 5, 16-byte aligned rows ...); everything else keeps the windowed launches.  One clip whose SECOND
+    segment is `tail` samples long walks the stack at lengths where some layers qualify and others do not (482 -> 241 -> ...; 1000 -> 500 ->
+    125 -> 25; 12346 -> 6173 ...), with the reflect fixes and halo clamps of short rows: engine == C oracle bit for bit at full width."""
+    g, cfg, m, ref = _setup("encodec48k_b1")
+    T = 47520 + tail                                             # segment stride 47520 (Encodec.cs:278-282): segments of 48000 and `tail` samples
+    pcm = synthetic_pcm(2, cfg.channels, T, cfg.sampling_rate, seed=100 + tail)
+    frames, _, _ = _check_vs_oracle(m, ref, pcm)
+    assert len(frames) == 2
+    m.dispose()
