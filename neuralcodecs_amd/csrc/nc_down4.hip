@@ -49,8 +49,8 @@ __device__ __forceinline__ void d4_step_operands(float even, float odd, float& b
 
 template <int TM>
 __global__ __launch_bounds__(256, 2) void down4_kernel(const Down2Args p) {
-    // (CB = 8 input channels per barrier = TWO reduction blocks of the packed image, which lays the blocks of a row tile end to end: at one
-    //  block per barrier -- two channel pairs, ~6 k cycles -- the barrier and the weight staging showed: 315 -> R us)
+    // (CB = 8 input channels per barrier = TWO reduction blocks of the packed image, which lays the blocks of a row tile end to end; one block
+    //  per barrier -- two channel pairs -- measured the same: 315 vs 310 us, the barrier is not what this kernel waits for)
     constexpr int CB = 8, K = 8, BM = 32 * TM;
     constexpr int A_FLOATS = CB * K * BM, A_VEC = A_FLOATS / 4, NA = (A_VEC + 255) / 256;
     constexpr int PF = 4;                          // channel pairs in flight
