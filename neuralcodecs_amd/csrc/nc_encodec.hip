@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void pad_act_kernel(ActView a, ActView b2, int
 // t % sub, columns = t / sub) view of x [B][C][T]; lane (h, c) adds its 16 rows of column c, then the butterfly.
 constexpr int GN_CBW = 4;   // column blocks per wavefront: their 64 row reads are all in flight before the first sum (memory-level parallelism)
 __global__ __launch_bounds__(256) void gn_block_kernel(const float* __restrict__ x, double* __restrict__ part, int64_t B, int C, int64_t T, int sub,
-                                                       int nrb, int ncb) {
+                                                       int nrb, int ncb, int64_t rs /* row pitch (elements) */) {
     const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
     const int ncg = (ncb + GN_CBW - 1) / GN_CBW;                      // groups of column blocks per row block
     const int64_t total = B * nrb * ncg;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void gn_block_kernel(const float* __restrict__
     if (gi >= total) return;
     const int64_t b = gi / ((int64_t)nrb * ncg), rem = gi - b * nrb * ncg;
     const int rb = (int)(rem / ncg), cg = (int)(rem - (int64_t)rb * ncg);
-    const float* xb = x + b * C * T;
+    const float* xb = x + b * C * rs;
     float v[GN_CBW][16];
     unsigned okm[GN_CBW];
 #pragma unroll
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void gn_block_kernel(const float* __restrict__
             const int co = sub == 1 ? R : R / sub;
             const int64_t t = sub == 1 ? q : q * sub + (R - co * sub);
             const bool ok = co < C && t < T;
-            v[u][r] = xb[(int64_t)min(co, C - 1) * T + min(t, T - 1)];   // branch-free: clamped address, value masked in the sum
+            v[u][r] = xb[(int64_t)min(co, C - 1) * rs + min(t, T - 1)];   // branch-free: clamped address, value masked in the sum
             if (ok) okm[u] |= 1u << r;
         }
     }
@@ -1128,14 +1128,15 @@ EncodecModel::GnJob EncodecModel::gn_begin(const ConvLayer& conv, ConvIO& io, in
     }
     return j;
 }
-const float* EncodecModel::gn_end(const GnJob& j, const float* raw, int N, int C, int64_t L) {
+const float* EncodecModel::gn_end(const GnJob& j, const float* raw, int N, int C, int64_t L, int64_t rs) {
+    if (rs <= 0) rs = L;
     if (!j.on) return nullptr;
     if (j.finished) return j.stats;
     const int64_t n = (int64_t)j.nrb * j.ncb;
     ProfScope ps(&prof, stream, NC_KC_NORM, 3.0 * N * C * (double)L, j.fused ? 16.0 * N * (double)n : 4.0 * N * C * (double)L);
     if (!j.fused)
         hipLaunchKernelGGL(gn_block_kernel, dim3((unsigned)(((int64_t)N * j.nrb * ((j.ncb + GN_CBW - 1) / GN_CBW) + 3) / 4)), dim3(256), 0, stream, raw, j.part,
-                           (int64_t)N, C, L, j.sub, j.nrb, j.ncb);
+                           (int64_t)N, C, L, j.sub, j.nrb, j.ncb, rs);
     hipLaunchKernelGGL(gn_final_kernel, dim3((unsigned)N), dim3(64), 0, stream, j.part, j.stats, n, (double)C * (double)L);
     NC_HIP(hipGetLastError());
     return j.stats;
@@ -1301,18 +1302,25 @@ EncodecModel::Act EncodecModel::sconvT(SConv& L, const Act& a, const Act* b2, bo
         const float* xin = pad_act(a, b2, elu, N, pl);
         io.x = xin; io.x_bstride = (int64_t)L.Cin * a.L; io.x_cstride = a.L; io.x_len = (int32_t)a.L; io.Tin = a.L;
     }
-    float* y = alloc((size_t)N * L.Cout * Lfull);
-    io.y = y; io.y_bstride = (int64_t)L.Cout * Lfull; io.y_cstride = Lfull;
-    // (the block view of the statistics follows the layer geometry, not the kernel form: the same sums under NC_NO_SUBPIXEL)
-    const GnJob gj = gn_begin(L.conv, io, N, L.Cout, Lfull, conv_gn_sub(L.K, L.stride, L.Cout, true));
-    launch_conv(L.conv, io, N, stream, &prof);
     const int64_t pt = L.K - L.stride;
     int64_t right, left;
     if (cfg.causal) { right = pt; left = 0; }                                               // trimRightRatio = 1
     else { right = pt / 2; left = pt - right; }
+    // The consumers read the TRIMMED view (rows start `left` samples in).  Where that start is not 8-byte aligned -- the stride-5 layer: left = 3,
+    // odd row length 6005 -- the residual block behind it lost its aligned kernels (the C = 128 shortcut ran on the windowed template: 181 us
+    // against 71 us for the same layer in the encoder).  Rows are therefore laid out at a pitch of whole 16 bytes and the buffer starts
+    // `shift` samples in, so that every row of the trimmed view begins on a 16-byte boundary (NC_NO_UP_PITCH=1: dense rows, no shift).
+    static const bool no_pitch = env_flag("NC_NO_UP_PITCH");
+    const int64_t P = no_pitch ? Lfull : ((Lfull + 3) & ~(int64_t)3);
+    const int64_t shift = no_pitch ? 0 : (4 - left % 4) % 4;
+    float* y = alloc((size_t)N * L.Cout * P + 4) + shift;
+    io.y = y; io.y_bstride = (int64_t)L.Cout * P; io.y_cstride = P;
+    // (the block view of the statistics follows the layer geometry, not the kernel form: the same sums under NC_NO_SUBPIXEL)
+    const GnJob gj = gn_begin(L.conv, io, N, L.Cout, Lfull, conv_gn_sub(L.K, L.stride, L.Cout, true));
+    launch_conv(L.conv, io, N, stream, &prof);
     Act o;
-    o.p = y; o.C = L.Cout; o.L = Lfull - left - right; o.rs = Lfull; o.off = left;
-    o.stats = gn_end(gj, y, N, L.Cout, Lfull);
+    o.p = y; o.C = L.Cout; o.L = Lfull - left - right; o.rs = P; o.off = left;
+    o.stats = gn_end(gj, y, N, L.Cout, Lfull, P);
     o.gamma = o.stats ? L.gamma.as<float>() : nullptr;
     o.beta = o.stats ? L.beta.as<float>() : nullptr;
     return o;
@@ -1501,10 +1509,12 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
         // are then one contiguous column range of a 2-D matrix, so the chunk's GEMM is a one-"clip" pointwise convolution over
         // chunk*N columns with full 128-column tiles (cut out of [N,C,T], a chunk would fill a fifth of every tile: measured, the
         // per-chunk GEMMs then cost as much as the full one and 6 chunks made C3 2.2 ms slower).
-        static const int want_chunks = [] { const int v = (int)env_int("NC_LSTM_CHUNKS", 4); return v < 1 ? 1 : v; }();
+        // (round 6: 6 chunks, was 4 -- re-swept after the projection GEMMs moved to the pointwise kernel: C3 8.26 -> 8.21 ms, Encodec 24 kHz x 16 clips
+        //  5.51 -> 5.26 ms; 8 chunks: back to the 4-chunk times.  tools/probe/r6_chunks24.sh)
+        static const int want_chunks = [] { const int v = (int)env_int("NC_LSTM_CHUNKS", 6); return v < 1 ? 1 : v; }();
         // chunk boundaries (even: chunk starts stay 8-byte aligned for the 1x1 path).  The layer above trails the layer below by its
         // LAST chunk (+ that chunk's input-projection GEMM), so the last chunk is short (T/8) and the others share the rest: with 4
-        // chunks of 150 steps 44 / 44 / 44 / 18 instead of 38 / 38 / 38 / 36 -- the tail after layer 0 has finished shrinks from 36
+        // chunks of 150 steps 44 / 44 / 44 / 18 instead of 38 / 38 / 38 / 36 (6 chunks: 28 / 28 / 28 / 28 / 20 / 18) -- the tail after layer 0 has finished shrinks from 36
         // steps to 18 without a single extra cross-stream event.
         std::vector<int64_t> cstart{0};
         if (nl >= 2 && want_chunks > 1 && T >= 32 && !on_side_group && (int64_t)4 * C * T * N < ((int64_t)1 << 31)) {

@@ -280,7 +280,7 @@ struct EncodecModel : Codec {
                                                   // branch output of the fused first pass of a residual block, two outputs finishing in one launch)
     int cur_group = 0;
     GnJob gn_begin(const ConvLayer& conv, ConvIO& io, int N, int C, int64_t L, int sub);
-    const float* gn_end(const GnJob& j, const float* raw, int N, int C, int64_t L);
+    const float* gn_end(const GnJob& j, const float* raw, int N, int C, int64_t L, int64_t rs = 0);   // rs: row pitch of `raw` (0 = dense rows of L)
     Act sconv(SConv& L, const Act& a, const Act* b2, bool elu, int N);
     Act sconvT(SConv& L, const Act& a, const Act* b2, bool elu, int N);
     void resblock(ResBlock& r, const Act& x, int N, Act& s, Act& y);

@@ -68,6 +68,7 @@ const EnvRow kEnv[] = {
     {"NC_NO_DOWN2", 'b', "Encodec 48 kHz encoder: the windowed two-input instance for the stride-2 down-convolution instead of the streaming kernel"},
     {"NC_NO_DOWN4", 'b', "Encodec 48 kHz encoder: summed copy + windowed instance for the stride-4 down-convolution instead of the streaming kernel"},
     {"NC_NO_DOWN5", 'b', "Encodec 48 kHz encoder: summed copy + windowed instance for the stride-5 down-convolution instead of the streaming kernel"},
+    {"NC_NO_UP_PITCH", 'b', "Encodec transposed convolutions write dense rows (the trimmed view of the stride-5 layer then starts on an odd sample)"},
     {"NC_NO_UP4", 'b', "Encodec 48 kHz decoder: summed copy + windowed instance for the stride-4 up-convolution instead of the streaming kernel"},
     {"NC_NO_UP2", 'b', "Encodec 48 kHz decoder: the windowed two-input instance for the stride-2 up-convolution instead of the streaming kernel"},
     {"NC_RMS_TWO_PASS", 'b', "Encodec RMS scale as two launches (chunk sums, final) instead of the one-launch form"},
@@ -75,7 +76,7 @@ const EnvRow kEnv[] = {
     {"NC_SYNC_ACQUIRE", 'b', "agent-scope acquire fence behind the persistent LSTM's flag poll and in front of the in-launch GroupNorm finish"},
     {"NC_LSTM_SPLIT", 'b', "EXPERIMENTS=1 builds: per-layer persistent LSTM with load-only / store-only wave roles and value-validated exchange regions (lstm1_kernel; measured slower)"},
     {"NC_LSTM_STEPWISE", 'b', "one LSTM launch per step"},
-    {"NC_LSTM_CHUNKS", 'i', "layer-pipeline chunks of the per-layer persistent LSTM (4; 1 = layers in sequence)"},
+    {"NC_LSTM_CHUNKS", 'i', "layer-pipeline chunks of the per-layer persistent LSTM (6; 1 = layers in sequence)"},
     {"NC_LSTM_EVEN_CHUNKS", 'b', "equal LSTM chunks"},
     {"NC_LSTM_UB", 'i', "hidden-unit blocks per LSTM workgroup (2 | 4)"},
     {"NC_LSTM_NO_ELU", 'b', "the consumer applies the ELU behind an SLSTM"},
