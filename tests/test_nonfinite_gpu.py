@@ -97,3 +97,31 @@ def test_encodec_nonfinite_clips(name):
             assert close_nonfinite(f.scale, g[f"scale{i}"], 1e-6) and same(f.scale, r[1])
     assert close_nonfinite(audio[..., :g["audio"].shape[-1]], g["audio"], PCM_TOL)
     assert same(audio, ref.decode(rfr))
+
+
+def test_encodec48k_full_width_nonfinite_segments():
+    """The full-width 48 kHz model (the round-6 streaming kernels: fused first pass, strided two-input down / up convolutions, one-launch RMS
+    scale) on clips whose non-finite sample poisons ONE segment: that segment's GroupNorm statistics, scale and every value behind them turn
+    NaN / inf exactly as in the C oracle (bit for bit, NaN == NaN), its codes are ATen's all-NaN-row answer 0, and the other segments of the
+    same clip stay finite and exact."""
+    from neuralcodecs_amd.weights import synthetic_pcm
+    g = load_golden("encodec48k_b1")
+    cfg = encodec_cfg_from_meta(g["meta"])
+    blob = save_blob(encodec_synthetic_state_dict(cfg, seed=42))
+    ref = c_oracle.RefEncodec(cfg, blob)
+    T = 96000
+    pcm = synthetic_pcm(2, cfg.channels, T, cfg.sampling_rate, seed=31)
+    pcm[0, 0, 1000] = np.inf                      # segment 0 of clip 0 only (segments start at 0, 47520, 95040)
+    pcm[1, 1, 60000] = np.nan                     # segment 1 of clip 1 only
+    with Encodec(cfg) as m:
+        m.load_blob(blob)
+        frames = m.encode(pcm)
+        audio = m.decode(frames, T)
+    rfr = ref.encode(pcm)
+    assert len(frames) == len(rfr) == 3
+    for f, r in zip(frames, rfr):
+        assert np.array_equal(f.codes, r[0]) and same(f.scale, r[1])
+    assert same(audio, ref.decode(rfr))
+    assert np.all(frames[0].codes[0] == 0) and np.all(frames[1].codes[1] == 0)            # poisoned segments: every row NaN -> index 0
+    assert frames[0].codes[1].max() > 0 and frames[1].codes[0].max() > 0 and frames[2].codes.max() > 0   # the others are ordinary
+    assert np.isinf(frames[0].scale[0]).all() and np.isnan(frames[1].scale[1]).all() and np.isfinite(frames[2].scale).all()
