@@ -97,11 +97,11 @@ __global__ __launch_bounds__(256, TMS == 1 ? 4 : 3) void res_a_kernel(const ResA
     constexpr int BMS = 32 * TMS, BMB = 32;
     constexpr int AB_FLOATS = CB * 3 * BMB, AB_VEC = AB_FLOATS / 4, NAB = (AB_VEC + 255) / 256;   // 384 vectors: 2 passes
     constexpr int AS_FLOATS = CB * BMS, AS_VEC = AS_FLOATS / 4;                                    // 128 / 256 vectors: 1 pass
-#ifdef RA_PF
-    constexpr int PF = RA_PF;
-#else
+    // (PF: channel pairs in flight; 8 measured the same as 4)
+
+
     constexpr int PF = 4;
-#endif
+
 
     __shared__ __attribute__((aligned(16))) float Asb[2][AB_FLOATS];
     __shared__ __attribute__((aligned(16))) float Ass[2][AS_FLOATS];
@@ -212,13 +212,13 @@ __global__ __launch_bounds__(256, TMS == 1 ? 4 : 3) void res_a_kernel(const ResA
                 }
             }
             // branch: ELU, then the three taps (conv3_stream_kernel's step layout)
-#ifdef RA_NO_ELU
-            const float a = na, bb = nb, hv = nh;
-#elif defined(RA_NO_HALO)
-            const float a = nc_eluf(na), bb = nc_eluf(nb), hv = nh;
-#else
+
+
+
+
+
             const float a = nc_eluf(na), bb = nc_eluf(nb), hv = nc_eluf(nh);
-#endif
+
             float aL = ra_from_left(bb), bR = ra_from_right(a);
             aL = lane_first ? hv : aL;
             bR = lane_last ? hv : bR;
@@ -251,14 +251,14 @@ __global__ __launch_bounds__(256, TMS == 1 ? 4 : 3) void res_a_kernel(const ResA
     }
 
     const bool colok = col < T;
-#ifndef RA_NO_GNOUT
+
     if (p.gn_part_s != nullptr) {
         ra_gn_out<TMS>(accs, Eps, p.Cs, colok, col0, l31, hi, lane, p.gn_part_s + (int64_t)b * p.gn_nrb_s * p.gn_ncb * 2, p.gn_nrb_s, p.gn_ncb,
                        p.gn_count_s ? p.gn_count_s + b : nullptr, p.gn_stats_s + 2 * b, (unsigned)p.n_t_tiles, p.gn_n_s);
         ra_gn_out<1>(accb, Epb, p.Cb, colok, col0, l31, hi, lane, p.gn_part_b + (int64_t)b * p.gn_nrb_b * p.gn_ncb * 2, p.gn_nrb_b, p.gn_ncb,
                      p.gn_count_b ? p.gn_count_b + b : nullptr, p.gn_stats_b + 2 * b, (unsigned)p.n_t_tiles, p.gn_n_b);
     }
-#endif
+
     if (!colok) return;
     ra_store<TMS>(accs, Eps, p.Cs, p.ys + (int64_t)b * p.ys_bstride + (unsigned)(4 * hi) * (unsigned)p.ys_cstride + (unsigned)col, (unsigned)p.ys_cstride, hi);
     ra_store<1>(accb, Epb, p.Cb, p.yb + (int64_t)b * p.yb_bstride + (unsigned)(4 * hi) * (unsigned)p.yb_cstride + (unsigned)col, (unsigned)p.yb_cstride, hi);
