@@ -155,13 +155,19 @@ def extra_configs(dev, steps, warmup, check):
         timed(fn, steps, 0, torch.cuda.synchronize)               # the class table: HIP events around every launch
         prof = m.profile_read()
         m.profile_enable(False)
-        classes = class_table(prof, steps, load_traffic(algo_key))
+        tr = load_traffic(algo_key)
+        classes = class_table(prof, steps, tr)
         fl, by = ALGO[algo_key]
         e = {"workload": name, "B": B, "clip_seconds": secs, "ms_per_step": round(dt * 1e3, 3), "x_realtime": round(B * secs / dt, 1),
              "whole_step_tflops": round(fl * B * secs / dt / 1e12, 3), "whole_step_algo_GBps": round(by * B * secs / dt / 1e9, 1),
              "kernel_ms_per_step": round(sum(c["ms_per_step"] for c in classes.values()), 3),
              "dominant": dominant(classes), "classes": classes,
              "pmc_traffic_ref": "profiles/traffic.json#" + algo_key, "traffic_stale": traffic_stale(algo_key)}
+        if tr and e["dominant"]:      # matrix-core / vector busy of the dominant class on the pipe they share (profiles/traffic.json)
+            t = tr.get(e["dominant"]["class"], {})
+            for kk in ("mfma_busy", "valu_busy", "pipe_busy"):
+                if kk in t:
+                    e["dominant"][kk] = t[kk]
         if check:
             deferred.append((e, oracle_check))
         out[algo_key if algo_key != "snac44k" else "snac44k_c5_share"] = e
@@ -724,7 +730,7 @@ def main():
                 slim[k] = {kk: e[kk] for kk in ("B", "clip_seconds", "ms_per_step", "x_realtime", "whole_step_tflops", "kernel_ms_per_step",
                                                 "traffic_stale", "gpu_equals_oracle") if kk in e}
                 dm = e.get("dominant") or {}
-                slim[k]["dominant"] = {kk: dm[kk] for kk in ("class", "bound", "achieved", "unit", "frac", "ms_per_step") if kk in dm}
+                slim[k]["dominant"] = {kk: dm[kk] for kk in ("class", "bound", "achieved", "unit", "frac", "ms_per_step", "mfma_busy", "valu_busy", "pipe_busy") if kk in dm}
                 slim[k]["launches_per_step"] = round(sum(c["launches_per_step"] for c in e["classes"].values()), 1)   # (class tables: the detail file)
             out["extra_configs"] = slim
             for k, flat in (("encodec48k", "c3_encodec48k_16x2s_ms_per_step"), ("snac44k_c5_share", "c5_share_snac44k_8x5s_ms_per_step"),
