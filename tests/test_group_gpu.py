@@ -172,3 +172,40 @@ def test_encodec_group_rank_and_local_modes_single_device():
         assert lens2 == lens and nq2 == nq and torch.equal(lcall[0], call) and (lsall is None or torch.equal(lsall[0], sall))
         loc.dispose()
     m.dispose()
+
+
+def test_encodec_four_member_peer_copy_group_on_one_device():
+    """Round 6: the peer-copy transport (NC_GROUP_PEER_COPY) with FOUR Encodec handles on the one device -- codes (int64 and 10-bit packed) and
+    the per-segment scales of every member's block reach every member's copy of the gathered tensors; block d == a plain encode of its clips."""
+    import torch
+    from conftest import encodec_cfg_from_meta
+    from neuralcodecs_amd import Encodec
+    from neuralcodecs_amd.weights import encodec_synthetic_state_dict
+    g = load_golden("encodec_small48")
+    cfg = encodec_cfg_from_meta(g["meta"])
+    blob = save_blob(encodec_synthetic_state_dict(cfg, seed=g["meta"]["weight_seed"]))
+    ms = [Encodec(cfg) for _ in range(4)]
+    for m in ms:
+        m.load_blob(blob)
+    B, T = 2, 8100
+    pcm = synthetic_pcm(4 * B, cfg.channels, T, cfg.sampling_rate, seed=17)
+    want = [ms[0].encode(pcm[d * B:(d + 1) * B]) for d in range(4)]
+    blocks = [torch.from_numpy(pcm[d * B:(d + 1) * B]).cuda() for d in range(4)]
+    grp = parallel.Group.local(ms, peer_copy=True)
+    for bits in (0, 10):
+        grp.set_code_bits(bits)
+        call, sall, lens, nq = grp.encodec_encode_allgather_local(blocks)
+        grp.wait()
+        torch.cuda.synchronize()
+        for member in range(4):
+            for d in range(4):
+                frames = parallel.Group.encodec_frames(call[member][d], None if sall is None else sall[member][d], B, nq, lens)
+                assert len(frames) == len(want[d])
+                for (c, s), w in zip(frames, want[d]):
+                    assert np.array_equal(c.cpu().numpy(), w.codes), (bits, member, d)
+                    assert s is None or np.array_equal(s.cpu().numpy().reshape(-1), np.asarray(w.scale).reshape(-1))
+    with pytest.raises(ValueError):
+        parallel.Group.local([ms[0], ms[0]], peer_copy=True)      # the same handle twice: one codec (stream, workspace) per member
+    grp.dispose()
+    for m in ms:
+        m.dispose()
