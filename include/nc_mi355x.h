@@ -431,7 +431,7 @@ NC_API nc_status nc_op_vq_argmin(int device_index, const float* z_e, int32_t B, 
                                  int32_t N, int64_t* idx, float* st);
 /* the Encodec Euclidean RVQ (Modules/Encodec/ResidualVectorQuantizer.cs:133-157 over EuclideanCodebook.cs:155-182) on residual [B,D,T]
  * with codebooks [n_q,N,D] -> codes [B,n_q,T], residual_out [B,D,T] (nullable; the residual after the last stage in form 0, the input in form 1, whose residual never
- * leaves LDS).  form 0: one launch per stage; form 1: the all-stages matrix-core kernel (D == 128 and N % 512 == 0, else NC_EUNSUPPORTED). */
+ * leaves LDS).  form 0: one launch per stage; form 1: the all-stages matrix-core kernel (D == 128 and N = 512 or 1024, else NC_EUNSUPPORTED). */
 NC_API nc_status nc_op_euclid_rvq(int device_index, const float* residual, int32_t B, int32_t D, int64_t T, const float* codebooks,
                                   int32_t n_q, int32_t N, int32_t form, int64_t* codes, float* residual_out);
 /* weight-norm fold w = v/(||v||+1e-7)*g over dim-0 slices (host-side, what load_weights does) */

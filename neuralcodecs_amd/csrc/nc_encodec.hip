@@ -597,8 +597,10 @@ __global__ __launch_bounds__(64 * NWV) void euclid_rvq_mfma_kernel(const float* 
                                                               int n_q, int N, int B, int64_t T, int64_t* __restrict__ codes,
                                                               int64_t codes_bstride) {
     constexpr int D = DD;
-    __shared__ float es[EM_MAXD][EM_F];   // residual block [d][frame]: lane (frame, k half) of a B fragment reads es[2kp + half][frame]
+    __shared__ float es[EM_MAXD][EM_F + 1];   // residual block [d][frame]: lane (frame, k half) of a B fragment reads es[2kp + half][frame]; rows padded by one
+                                              // word -- the residual update walks d across the lanes (unpadded: every lane of a wave on ONE bank)
     __shared__ float e2s[EM_F];
+    __shared__ __attribute__((aligned(16))) float c2s[1024];   // |c_n|^2 of the stage (N <= 1024: the launcher routes larger codebooks to euclid_vq_kernel)
     __shared__ float bd[NWV][EM_F];
     __shared__ int bi[NWV][EM_F];
     __shared__ int win[EM_F];
@@ -613,63 +615,102 @@ __global__ __launch_bounds__(64 * NWV) void euclid_rvq_mfma_kernel(const float* 
         es[d][f] = v;
     }
     const int npw = N / NWV;                 // codes per wave (a multiple of 128)
+    const int npass = npw / 128;
+    // (the stage's pointers come out of a pointer table: say that they are global memory, or the reads are issued as flat loads, which
+    // count against the LDS counter too and serialise with the B-fragment reads)
+    typedef __attribute__((address_space(1))) const em_f32x4* em_gp4;
+    typedef __attribute__((address_space(1))) const float* em_gp1;
+    // 128 codes per pass as four row tiles; row l of tile i is code n0 + 4 l + i, so the four A values a lane needs for one k are four
+    // consecutive codes of the transposed codebook: ONE 16-byte load, 512 contiguous bytes per lane half.  The reads run two groups of
+    // G matrix-core steps ahead through a ring of FOUR register sets (a pass is 8 groups: every pass starts on set 0, so the ring runs
+    // on across the passes AND the stages -- the first two groups of the next pass / the next stage's first pass are in flight under the
+    // last two groups of this one, the argmin, the hand-off and the residual update; filled per pass, every pass and every stage began
+    // with an exposed L2 round trip: 288 -> 251 us on C3's 150-workgroup grid together with the two changes below)
+    constexpr int G = 8, NG = DD / 2 / G;    // matrix-core steps per group, groups per pass
+    static_assert(NG % 4 == 0, "the four-set ring must start every pass on set 0");
+    const int64_t kstride = (int64_t)2 * N / 4;                            // float4 words per MFMA step (two codebook rows)
+    auto pass_ptr = [&](int q, int pass) __attribute__((always_inline)) -> em_gp4 {
+        return (em_gp4)(cbT_ptrs[q] + (int64_t)hi * N + wave * npw + pass * 128 + 4 * l31);   // k = hi at kp = 0
+    };
+    em_f32x4 av[4][G];
+    em_gp4 ap = pass_ptr(0, 0);
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int u = 0; u < G; ++u) av[g][u] = ap[(int64_t)(g * G + u) * kstride];
+    // |c_n|^2 of a stage: in registers one stage ahead, in LDS for the stage's scans (the argmin read them from global memory per pass)
+    constexpr int C2R = 1024 / (64 * NWV);
+    float c2r[C2R];
+#pragma unroll
+    for (int i = 0; i < C2R; ++i) c2r[i] = ((em_gp1)c2_ptrs[0])[min(tid + i * 64 * NWV, N - 1)];
     for (int q = 0; q < n_q; ++q) {
-        const float* __restrict__ cbT = cbT_ptrs[q];
         const float* __restrict__ cb = cb_ptrs[q];
-        const float* __restrict__ c2 = c2_ptrs[q];
         __syncthreads();                     // es holds the residual entering this stage
+#pragma unroll
+        for (int i = 0; i < C2R; ++i)
+            if (tid + i * 64 * NWV < N) c2s[tid + i * 64 * NWV] = c2r[i];
+        if (q + 1 < n_q) {
+#pragma unroll
+            for (int i = 0; i < C2R; ++i) c2r[i] = ((em_gp1)c2_ptrs[q + 1])[min(tid + i * 64 * NWV, N - 1)];
+        }
         if (tid < EM_F) {
             float a = 0.0f;
-            for (int d = 0; d < D; ++d) a = nc_fma(es[d][tid], es[d][tid], a);
+            // |e|^2: ONE fma chain over d ascending (the canonical order), the LDS reads 16 at a time ahead of their 16 dependent fmas
+            // (rolled, every fma waited for its own read: 2.0 us of a 27 us stage)
+#pragma unroll 1
+            for (int d0 = 0; d0 < D; d0 += 16) {
+                float ev[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) ev[u] = es[d0 + u][tid];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a = nc_fma(ev[u], ev[u], a);
+            }
             e2s[tid] = a;
         }
         __syncthreads();
         const float e2 = e2s[l31];
         float best = __builtin_inff();
         int besti = 0x7fffffff;
-        for (int n0 = wave * npw; n0 < (wave + 1) * npw; n0 += 128) {
-            // 128 codes per pass as four row tiles; row l of tile i is code n0 + 4 l + i, so the four A values a lane needs for one k
-            // are four consecutive codes of the transposed codebook: ONE 16-byte load, 512 contiguous bytes per lane half
+        for (int pass = 0; pass < npass; ++pass) {
+            const int n0 = wave * npw + pass * 128;
+            const bool last_pass = pass + 1 == npass;
+            const bool has_next = !last_pass || q + 1 < n_q;
+            const em_gp4 ap_next = last_pass ? pass_ptr(min(q + 1, n_q - 1), 0) : ap + 32;   // (+ 128 codes)
             em_f32x16 acc[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-            // (the stage's pointers come out of a pointer table: say that they are global memory, or the reads are issued as flat
-            // loads, which count against the LDS counter too and serialise with the B-fragment reads)
-            typedef __attribute__((address_space(1))) const em_f32x4* em_gp4;
-            const em_gp4 ap = (em_gp4)(cbT + (int64_t)hi * N + n0 + 4 * l31);   // k = hi at kp = 0
-            const int64_t kstride = (int64_t)2 * N / 4;                    // float4 words per MFMA step (two codebook rows)
-            constexpr int G = 8, NG = DD / 2 / G;                          // MFMA steps per group, groups per pass
-            em_f32x4 av[3][G];                                             // ring: the reads run two groups ahead of the matrix cores
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int u = 0; u < G; ++u) av[g][u] = ap[(int64_t)(g * G + u) * kstride];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 if (g + 2 < NG) {
 #pragma unroll
-                    for (int u = 0; u < G; ++u) av[(g + 2) % 3][u] = ap[(int64_t)((g + 2) * G + u) * kstride];
+                    for (int u = 0; u < G; ++u) av[(g + 2) % 4][u] = ap[(int64_t)((g + 2) * G + u) * kstride];
+                } else if (has_next) {
+#pragma unroll
+                    for (int u = 0; u < G; ++u) av[(g + 2) % 4][u] = ap_next[(int64_t)((g + 2 - NG) * G + u) * kstride];
                 }
                 __builtin_amdgcn_sched_barrier(0);   // the reads of group g+2 stay ahead of the matrix-core steps of group g
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
                     const float bv = es[2 * (g * G + u) + hi][l31];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g % 3][u][i], bv, acc[i], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g % 4][u][i], bv, acc[i], 0, 0, 0);
                 }
             }
-            // D[row = (r & 3) + 8 (r >> 2) + 4 hi][column = l31]; lowest index on ties (codes are not visited in ascending order)
+            ap = ap_next;
+            // D[row = (r & 3) + 8 (r >> 2) + 4 hi][column = l31].  A lane meets its codes in ASCENDING order (code = n0 + 4 row + i: rows ascend with r,
+            // i is the inner loop, n0 ascends over the passes), so the ascending-scan form of ATen's order applies: an equal distance never
+            // replaces the incumbent, a NaN takes over once.  (The lane halves and the waves are merged with the any-order form below.)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int nb = n0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * hi);
-                const em_f32x4 cc = *(em_gp4)(c2 + nb);
+                const em_f32x4 cc = *reinterpret_cast<const em_f32x4*>(c2s + nb);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float dist = (e2 + cc[i]) - 2.0f * acc[i][r];
-                    if (nc_argmin_before(dist, nb + i, best, besti)) { best = dist; besti = nb + i; }
+                    if (nc_argmin_scan(dist, best)) { best = dist; besti = nb + i; }
                 }
             }
         }
@@ -691,9 +732,16 @@ __global__ __launch_bounds__(64 * NWV) void euclid_rvq_mfma_kernel(const float* 
             if (fr < total) { const int64_t b = fr / T, t = fr - b * T; codes[b * codes_bstride + (int64_t)q * T + t] = (int64_t)i0; }
         }
         __syncthreads();
-        for (int i = tid; i < EM_F * D; i += 64 * NWV) {  // residual -= embed[idx]: 8 threads per frame walk its code vector
-            const int f = i / D, d = i - f * D;
-            es[d][f] = es[d][f] - ((__attribute__((address_space(1))) const float*)cb)[(int64_t)win[f] * D + d];
+        {   // residual -= embed[idx]: thread (d = tid % D, frames f = tid / D + (64 NWV / D) u) -- a frame's code vector is one coalesced 512-byte
+            // read; all of a thread's reads are issued before the first is used (one L2 round trip per stage instead of one per element)
+            constexpr int FS = 64 * NWV / D, NU = EM_F / FS;
+            static_assert((64 * NWV) % D == 0 && EM_F % FS == 0, "update map");
+            const int d = tid % D, fb = tid / D;
+            float cv[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) cv[u] = ((em_gp1)cb)[(int64_t)win[fb + FS * u] * D + d];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) es[d][fb + FS * u] = es[d][fb + FS * u] - cv[u];
         }
     }
 }
@@ -1756,7 +1804,7 @@ void EncodecModel::encode_batch(const float* x, int N, int64_t L, int64_t Tz, in
     if (prof.on) prof.begin(stream, NC_KC_RVQ, 2.0 * D * cfg.codebook_size * (double)total * n_q, 0.0);   // the distance GEMM
     static const bool no_mfma_vq = env_present("NC_EUCLID_NO_MFMA");
     const int Nc = cfg.codebook_size;
-    if (!no_mfma_vq && Nc % 512 == 0 && D == 128) {
+    if (!no_mfma_vq && Nc % 512 == 0 && Nc <= 1024 && D == 128) {
         // all stages in one launch, cross terms on the matrix cores (the residual block stays in LDS between the stages)
         // (NC_RVQ_8WAVES=1: 8 wavefronts per workgroup, 128 codes each -- measured the same 236 us on C3's 150-workgroup grid as the
         // 4-wave form: the stage is bound by its serial phases and the codebook stream, not by the matrix-core chain)
@@ -1995,7 +2043,7 @@ void op_euclid_rvq(const float* residual_in, int B, int D, int64_t T, const floa
     NC_HIP(hipMemcpy(d2.p, p2.data(), p2.size() * sizeof(float*), hipMemcpyHostToDevice));
     const int64_t total = (int64_t)B * T;
     if (form == 1) {
-        if (D != 128 || N % 512 != 0) fail(NC_EUNSUPPORTED, "the matrix-core Euclidean RVQ takes D == 128 and N %% 512 == 0");
+        if (D != 128 || N % 512 != 0 || N > 1024) fail(NC_EUNSUPPORTED, "the matrix-core Euclidean RVQ takes D == 128 and N = 512 or 1024");
         hipLaunchKernelGGL(euclid_rvq_mfma_kernel<128>, dim3((unsigned)((total + EM_F - 1) / EM_F)), dim3(256), 0, nullptr, res.as<float>(),
                            dT.as<const float*>(), dR.as<const float*>(), d2.as<const float*>(), n_q, N, B, T, codes.as<int64_t>(), (int64_t)n_q * T);
     } else {

@@ -133,14 +133,13 @@ __global__ __launch_bounds__(256, TMS == 1 ? 4 : 3) void res_a_kernel(const ResA
     const int col0 = t_tile * BN + wave * BNW;
     const int col = col0 + 2 * l31;
     const int colc = min(col, T - 2);
-    const int hcol = min(max(l31 < 16 ? col0 - 1 : col0 + BNW, 0), T - 1);
     const float* const xb = p.x + (int64_t)b * p.x_bstride;
     const unsigned x_lane_off = (unsigned)hi * x_cstride + (unsigned)colc;
-    const unsigned h_lane_off = (unsigned)hi * x_cstride + (unsigned)hcol;
     const ra_f32x4* const wb_base = reinterpret_cast<const ra_f32x4*>(p.w_b);
     const ra_f32x4* const ws_base = reinterpret_cast<const ra_f32x4*>(p.w_s);
     const bool first_col = col == 0, last_col = col + 2 == T;
     const bool lane_first = l31 == 0, lane_last = l31 == 31;
+    const int hsel_addr = 4 * (32 * hi + (lane_last ? 2 : 0));   // ds_bpermute byte address of this lane's halo value for pair 0
 
     ra_f32x16 accs[TMS][2], accb[1][2];
 #pragma unroll
@@ -153,9 +152,8 @@ __global__ __launch_bounds__(256, TMS == 1 ? 4 : 3) void res_a_kernel(const ResA
         }
 
     ra_f32x2 bq[PF];
-    float hq[PF];
     const int last_pair = Cin / 2 - 1;
-    auto load_pair = [&](int g, ra_f32x2& v, float& h) __attribute__((always_inline)) {
+    auto load_pair = [&](int g, ra_f32x2& v) __attribute__((always_inline)) {
         const float* row = xb + (size_t)(2 * min(g, last_pair)) * x_cstride;
         if constexpr (XV2) {
             v = *reinterpret_cast<const ra_f32x2*>(row + x_lane_off);
@@ -163,10 +161,20 @@ __global__ __launch_bounds__(256, TMS == 1 ? 4 : 3) void res_a_kernel(const ResA
             v[0] = row[x_lane_off];
             v[1] = row[x_lane_off + 1];
         }
-        h = row[h_lane_off];
     };
 #pragma unroll
-    for (int u = 0; u < PF; ++u) load_pair(u, bq[u], hq[u]);
+    for (int u = 0; u < PF; ++u) load_pair(u, bq[u]);
+    // Halo values of a WHOLE reduction block in one go: the two columns next to the span (col0 - 1, col0 + 64) x 8 channel pairs x 2 channels
+    // = 32 values, one per lane group -- lane (hi, l31) fetches channel 2 (8 cb + (l31 >> 2)) + hi at the left (bit 1 of l31 clear) / right
+    // column -- so ONE GroupNorm apply + ELU per block serves all eight pairs (it was one per pair, for two useful lanes each); pair pr picks
+    // its four values with v_readlane / v_writelane.
+    const int hb_pair = l31 >> 2;
+    const int hb_col = min(max((l31 & 2) ? col0 + BNW : col0 - 1, 0), T - 1);
+    auto load_halo_block = [&](int cbi) __attribute__((always_inline)) -> float {
+        const int g = min(cbi * (CB / 2) + hb_pair, last_pair);
+        return xb[(size_t)(2 * g + hi) * x_cstride + (unsigned)hb_col];
+    };
+    float hb_next = load_halo_block(0);
 
     ra_f32x4 rab[NAB], ras;
 #pragma unroll
@@ -188,18 +196,23 @@ __global__ __launch_bounds__(256, TMS == 1 ? 4 : 3) void res_a_kernel(const ResA
         }
         const float* Acb = Asb[cur] + hi * BMB + nc_a_lane_off<1>(l31);
         const float* Acs = Ass[cur] + hi * BMS + nc_a_lane_off<TMS>(l31);
+        float hvb = hb_next;
+        hb_next = load_halo_block(cb + 1);                     // (clamped past the last block)
+        if (gn_in) {
+            const float2 gbh = Gt[2 * min(cb * (CB / 2) + hb_pair, last_pair) + hi];
+            hvb = ((hvb - in_mu) * in_rs) * gbh.x + gbh.y;
+        }
+        hvb = nc_eluf(hvb);
         ra_static_for<CB / 2>([&](auto pt) __attribute__((always_inline)) {
             constexpr int pr = decltype(pt)::value;
             const int g = cb * (CB / 2) + pr;
             const float2 gb = gn_in ? Gt[2 * g + hi] : make_float2(1.0f, 0.0f);
             const ra_f32x2 raw = bq[pr % PF];
-            const float hraw = hq[pr % PF];
-            load_pair(g + PF, bq[pr % PF], hq[pr % PF]);
-            float na = raw[0], nb = raw[1], nh = hraw;
+            load_pair(g + PF, bq[pr % PF]);
+            float na = raw[0], nb = raw[1];
             if (gn_in) {                                       // GroupNorm(1,C) apply (NormConv1d.cs:155)
                 na = ((na - in_mu) * in_rs) * gb.x + gb.y;
                 nb = ((nb - in_mu) * in_rs) * gb.x + gb.y;
-                nh = ((nh - in_mu) * in_rs) * gb.x + gb.y;
             }
             // shortcut: kk = ci, the un-activated value of this lane's own channel
             {
@@ -217,11 +230,12 @@ __global__ __launch_bounds__(256, TMS == 1 ? 4 : 3) void res_a_kernel(const ResA
 
 
 
-            const float a = nc_eluf(na), bb = nc_eluf(nb), hv = nc_eluf(nh);
-
+            const float a = nc_eluf(na), bb = nc_eluf(nb);
             float aL = ra_from_left(bb), bR = ra_from_right(a);
-            aL = lane_first ? hv : aL;
-            bR = lane_last ? hv : bR;
+            // the span's halo for the first / last lane of either half: lanes 4 pr (+32) hold the left values, 4 pr + 2 (+32) the right ones
+            const float hs = __int_as_float(__builtin_amdgcn_ds_bpermute(hsel_addr + 16 * pr, __float_as_int(hvb)));
+            aL = lane_first ? hs : aL;
+            bR = lane_last ? hs : bR;
             aL = first_col ? bb : aL;                          // reflect pad (SConv1d.cs:258-274): x[-1] = x[1]
             bR = last_col ? a : bR;                            //                                    x[T]  = x[T-2]
             const float ax = ra_other_half(a, hi), bx = ra_other_half(bb, hi);

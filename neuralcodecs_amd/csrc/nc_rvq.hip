@@ -190,6 +190,8 @@ void launch_vq_argmin(const Codebook& cb, const float* z_e, int64_t ze_bstride, 
 //   q[c]    = (fma chain over d ascending of W_out[c][d] * st[d], from +0) + b_out[c];   zq[c] = zq[c] + q[c];   r[c] = r[c] - q[c]
 // 36 launches (4 per stage) and the round trips of residual / zq through HBM between them become one launch.
 constexpr int RF = 16;     // frames per workgroup
+constexpr int RP = RF + 1; // row pitch of the residual block in LDS: the update phase walks the channels across the lanes -- at pitch 16 every
+                           // lane of a wave met one of TWO banks (32-way conflicts on its 128 reads and writes per thread and stage)
 constexpr int RD = 8;      // codebook dimension of this instantiation
 typedef float rvq_f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const float* rvq_gp;
@@ -206,8 +208,8 @@ struct RvqFusedArgs {
 __global__ __launch_bounds__(256) void dac_rvq_fused_kernel(const RvqFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int L = a.L, N = a.N;
-    float* rs = sm;                       // [L][RF] residual block
-    float* s_cb = rs + L * RF;            // [RD][N]
+    float* rs = sm;                       // [L][RP] residual block (RF frames + one pad word per channel row)
+    float* s_cb = rs + L * RP;            // [RD][N]
     float* s_c2 = s_cb + RD * N;          // [N]
     float* s_w = s_c2 + N;                // [L][RD] in_proj weight (transposed)
     float* s_ze = s_w + L * RD;           // [RF][RD]
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void dac_rvq_fused_kernel(const RvqFusedArgs a
     for (int i = tid; i < L * RF; i += 256) {
         const int c = i / RF, f = i - c * RF;
         const int b = s_bt[2 * f], t = s_bt[2 * f + 1];
-        rs[i] = b >= 0 ? a.residual[((int64_t)b * L + c) * T + t] : 0.0f;
+        rs[c * RP + f] = b >= 0 ? a.residual[((int64_t)b * L + c) * T + t] : 0.0f;
     }
     const int NJ = L / 256;               // channels per thread in the out_proj / update phase (host: L % 256 == 0, NJ <= 4)
     float zqr[4][RF];
@@ -238,12 +240,25 @@ __global__ __launch_bounds__(256) void dac_rvq_fused_kernel(const RvqFusedArgs a
         __syncthreads();                  // the previous stage has finished with the codebook / weight images and updated rs
         {
             const rvq_gp4 c4 = (rvq_gp4)sg.cbT, w4 = (rvq_gp4)sg.w_inT, n4 = (rvq_gp4)sg.c2;
+            // every read of the stage's images (68 KB) is issued before the first LDS store: three copy loops in sequence were three L2 round
+            // trips.  (One stage AHEAD in registers -- read under the previous stage, stored behind its last barrier -- measured slower: 198 -> 240 us.)
+            constexpr int NCW = RD * 1024 / 4 / 256, NWW = 1024 * RD / 4 / 256;   // words per thread at the largest N / L the launcher admits
+            rvq_f32x4 cw[NCW], ww[NWW], nw;
+            const int ncb = RD * N / 4, nww = L * RD / 4;
+#pragma unroll
+            for (int u = 0; u < NCW; ++u) cw[u] = c4[min(tid + 256 * u, ncb - 1)];
+#pragma unroll
+            for (int u = 0; u < NWW; ++u) ww[u] = w4[min(tid + 256 * u, nww - 1)];
+            nw = n4[min(tid, N / 4 - 1)];
             rvq_f32x4* d4 = reinterpret_cast<rvq_f32x4*>(s_cb);
-            for (int i = tid; i < RD * N / 4; i += 256) d4[i] = c4[i];
-            d4 = reinterpret_cast<rvq_f32x4*>(s_c2);
-            for (int i = tid; i < N / 4; i += 256) d4[i] = n4[i];
+#pragma unroll
+            for (int u = 0; u < NCW; ++u)
+                if (tid + 256 * u < ncb) d4[tid + 256 * u] = cw[u];
             d4 = reinterpret_cast<rvq_f32x4*>(s_w);
-            for (int i = tid; i < L * RD / 4; i += 256) d4[i] = w4[i];
+#pragma unroll
+            for (int u = 0; u < NWW; ++u)
+                if (tid + 256 * u < nww) d4[tid + 256 * u] = ww[u];
+            if (tid < N / 4) reinterpret_cast<rvq_f32x4*>(s_c2)[tid] = nw;
         }
         // out_proj rows of this thread's channels: read now, used after the search (their latency hides under the in_proj chains)
         rvq_f32x4 wo[4][2];
@@ -258,45 +273,82 @@ __global__ __launch_bounds__(256) void dac_rvq_fused_kernel(const RvqFusedArgs a
         __syncthreads();
         if (tid < RF * RD) {              // in_proj: thread = (frame, d), one chain over the latent channels
             const int f = tid / RD, d = tid - f * RD;
+            const float b_in = ((rvq_gp)sg.b_in)[d];
             float acc = 0.0f;
-#pragma unroll 16
-            for (int c = 0; c < L; ++c) acc = nc_fma(s_w[c * RD + d], rs[c * RF + f], acc);
-            const float ze = acc + ((rvq_gp)sg.b_in)[d];
+            // ONE chain over c ascending (the canonical order); the LDS operands of 16 steps are read ahead of their 16 dependent fmas, the
+            // next 16 while those issue (left to `#pragma unroll 16` every fma waited for its own pair of reads)
+            float wv[2][16], rv[2][16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { wv[0][u] = s_w[u * RD + d]; rv[0][u] = rs[u * RP + f]; }
+#pragma unroll 1
+            for (int c0 = 0; c0 < L; c0 += 32) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { wv[1][u] = s_w[(c0 + 16 + u) * RD + d]; rv[1][u] = rs[(c0 + 16 + u) * RP + f]; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc = nc_fma(wv[0][u], rv[0][u], acc);
+                const int cn = min(c0 + 32, L - 16);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { wv[0][u] = s_w[(cn + u) * RD + d]; rv[0][u] = rs[(cn + u) * RP + f]; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc = nc_fma(wv[1][u], rv[1][u], acc);
+            }
+            const float ze = acc + b_in;
             s_ze[tid] = ze;
             const int b = s_bt[2 * f], t = s_bt[2 * f + 1];
             if (b >= 0) a.latents[((int64_t)b * a.n_q * RD + (int64_t)q * RD + d) * T + t] = ze;
         }
         __syncthreads();
-        for (int fi = 0; fi < RF / 4; ++fi) {   // nearest code: wave = 4 frames, lane scans N/64 codes (vq_argmin_kernel)
-            const int f = wave * (RF / 4) + fi;
-            float e[RD];
+        {   // nearest code: wave = 4 frames, lane scans N/64 codes (vq_argmin_kernel's arithmetic).  The four frames of a wave go through
+            // ONE pass over the codebook (a code's 8 LDS words feed four chains; frame after frame the loop was four dependent scans)
+            constexpr int FW = RF / 4;
+            float e[FW][RD], e2[FW], best[FW];
+            int bi[FW];
 #pragma unroll
-            for (int d = 0; d < RD; ++d) e[d] = s_ze[f * RD + d];
-            float e2 = 0.0f;
+            for (int fi = 0; fi < FW; ++fi) {
+                const int f = wave * FW + fi;
 #pragma unroll
-            for (int d = 0; d < RD; ++d) e2 = nc_fma(e[d], e[d], e2);
-            float best = __builtin_inff();
-            int bi = 0x7fffffff;
+                for (int d = 0; d < RD; ++d) e[fi][d] = s_ze[f * RD + d];
+                e2[fi] = 0.0f;
+#pragma unroll
+                for (int d = 0; d < RD; ++d) e2[fi] = nc_fma(e[fi][d], e[fi][d], e2[fi]);
+                best[fi] = __builtin_inff();
+                bi[fi] = 0x7fffffff;
+            }
             for (int n = lane; n < N; n += 64) {
-                float cr = 0.0f;
+                float cv[RD];
 #pragma unroll
-                for (int d = 0; d < RD; ++d) cr = nc_fma(e[d], s_cb[d * N + n], cr);
-                const float dist = (e2 + s_c2[n]) - 2.0f * cr;
-                if (nc_argmin_scan(dist, best)) { best = dist; bi = n; }
+                for (int d = 0; d < RD; ++d) cv[d] = s_cb[d * N + n];
+                const float cn = s_c2[n];
+#pragma unroll
+                for (int fi = 0; fi < FW; ++fi) {
+                    float cr = 0.0f;
+#pragma unroll
+                    for (int d = 0; d < RD; ++d) cr = nc_fma(e[fi][d], cv[d], cr);
+                    const float dist = (e2[fi] + cn) - 2.0f * cr;
+                    if (nc_argmin_scan(dist, best[fi])) { best[fi] = dist; bi[fi] = n; }
+                }
             }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) {
-                const float od = __shfl_xor(best, off, 64);
-                const int oi = __shfl_xor(bi, off, 64);
-                if (nc_argmin_before(od, oi, best, bi)) { best = od; bi = oi; }
+#pragma unroll
+                for (int fi = 0; fi < FW; ++fi) {
+                    const float od = __shfl_xor(best[fi], off, 64);
+                    const int oi = __shfl_xor(bi[fi], off, 64);
+                    if (nc_argmin_before(od, oi, best[fi], bi[fi])) { best[fi] = od; bi[fi] = oi; }
+                }
             }
-            if (bi == 0x7fffffff) bi = 0;
-            const int b = s_bt[2 * f], t = s_bt[2 * f + 1];
-            if (lane == 0 && b >= 0) a.codes[((int64_t)b * a.n_q + q) * T + t] = (int64_t)bi;
-            if (lane < RD) {
-                const float qv = ((rvq_gp)sg.cb)[(int64_t)bi * RD + lane];
-                const float ev = s_ze[f * RD + lane];
-                s_st[f * RD + lane] = ev + (qv - ev);
+#pragma unroll
+            for (int fi = 0; fi < FW; ++fi) {
+                const int f = wave * FW + fi;
+                if (bi[fi] == 0x7fffffff) bi[fi] = 0;
+                const int b = s_bt[2 * f], t = s_bt[2 * f + 1];
+                if (lane == 0 && b >= 0) a.codes[((int64_t)b * a.n_q + q) * T + t] = (int64_t)bi[fi];
+                if (lane < RD) {
+                    const float qv = s_cb[lane * N + bi[fi]];   // (the stage's codebook is in LDS, transposed: the same words as sg.cb[bi][lane]
+                                                                //  without an L2 round trip per frame)
+                    const float ev = s_ze[f * RD + lane];
+                    s_st[f * RD + lane] = ev + (qv - ev);
+                }
             }
         }
         __syncthreads();
@@ -312,7 +364,7 @@ __global__ __launch_bounds__(256) void dac_rvq_fused_kernel(const RvqFusedArgs a
                     for (int d = 0; d < RD; ++d) acc = nc_fma(wv[d], s_st[f * RD + d], acc);
                     const float y = acc + bo4[j];
                     zqr[j][f] = zqr[j][f] + y;
-                    rs[c * RF + f] = rs[c * RF + f] - y;
+                    rs[c * RP + f] = rs[c * RP + f] - y;
                 }
             }
         }
@@ -333,8 +385,8 @@ __global__ __launch_bounds__(256) void dac_rvq_fused_kernel(const RvqFusedArgs a
 bool launch_dac_rvq_fused(const RvqStage* stages_dev, int n_q, int L, int D, int N, const float* residual, int B, int64_t T, int64_t* codes,
                           float* zq, float* latents, hipStream_t s, Profiler* prof) {
     static const bool off = env_present("NC_DAC_RVQ_STAGEWISE");
-    if (off || D != RD || L % 256 != 0 || L > 1024 || N % 64 != 0 || n_q <= 0) return false;
-    const size_t lds = sizeof(float) * ((size_t)L * RF + (size_t)RD * N + N + (size_t)L * RD + 2 * RF * RD + 2 * RF);
+    if (off || D != RD || L % 256 != 0 || L > 1024 || N % 64 != 0 || N > 1024 || n_q <= 0) return false;
+    const size_t lds = sizeof(float) * ((size_t)L * RP + (size_t)RD * N + N + (size_t)L * RD + 2 * RF * RD + 2 * RF);
     if (lds > 160 * 1024) return false;
     ensure_dynamic_lds((const void*)dac_rvq_fused_kernel, 160 * 1024);
     const int64_t total = (int64_t)B * T;
