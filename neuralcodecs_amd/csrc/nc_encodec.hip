@@ -353,10 +353,17 @@ struct LstmSeqArgs {
 typedef __attribute__((address_space(1))) unsigned lstm_gu32;
 // UB = unit blocks (of 4 hidden units) per workgroup: 4 (16 wavefronts, C/16 workgroups per column tile) or 2 (8 wavefronts, C/8
 // workgroups per tile: two chains per SIMD instead of four -- the matrix-core part of a step halves, twice the CUs take part)
-template <int KS, int UB = 4>
+// HT (round 6, the default; NC_LSTM_NO_HTILE=1 selects the form above): the h tile goes through LDS and the weights live in REGISTERS.
+//   The four unit-block waves of a quarter need the same 8 KB of h_{t-1}; each fetched it for itself -- 128 KB of agent-scope reads per
+//   workgroup and step, a good part of the step's ~1.5 us operand fetch at the CU's fabric port.  Now the 16 waves fetch the 32 KB tile
+//   ONCE (8 coalesced dword reads per lane, the same agent-scope loads), park it in LDS, and every wave takes its 32 B fragments from
+//   there; W_hh (a wave's share is QS x 64 words = 32 registers) stays in registers for the whole sequence instead of being re-read from
+//   LDS every step.  One more workgroup barrier per step; same operands, same chains: bit-identical.
+template <int KS, int UB = 4, bool HT = true>
 __global__ __launch_bounds__(256 * UB, 1) void lstm_seq_kernel(const LstmSeqArgs a) {
     constexpr int QS = KS / 4;                                          // k-steps per quarter
-    extern __shared__ __attribute__((aligned(16))) float lstm_lds[];   // [4 UB waves][QS][64] weights | [3][UB][64] f32x4 partial tiles
+    constexpr int CC = 4 * KS;                                          // hidden units (= a.C)
+    extern __shared__ __attribute__((aligned(16))) float lstm_lds[];   // [4 UB waves][QS][64] weights (HT: [CC][16] h tile) | [3][UB][64] f32x4 partial tiles
     __shared__ int dead;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -367,11 +374,18 @@ __global__ __launch_bounds__(256 * UB, 1) void lstm_seq_kernel(const LstmSeqArgs
     const int ubw = blockIdx.x, tile = blockIdx.y;  // tile: local index within this launch
     const int ub = ubw * UB + ubl;                   // unit block of this wave: hidden units 4*ub .. 4*ub+3
     float* Aw = lstm_lds + wave * QS * 64;
-    f32x4v* const part = reinterpret_cast<f32x4v*>(lstm_lds + 4 * UB * QS * 64);
+    float* const Hs = lstm_lds;
+    f32x4v* const part = reinterpret_cast<f32x4v*>(lstm_lds + (HT ? CC * 16 : 4 * UB * QS * 64));
     const float* wsrc = a.whhp + ((int64_t)ub * KS + q * QS) * 64;
+    float aw[HT ? QS : 1];
+    if constexpr (HT) {
 #pragma unroll
-    for (int i = 0; i < QS / 4; ++i)
-        __builtin_amdgcn_global_load_lds((lstm_gptr)(wsrc + i * 256 + lane * 4), (lstm_lptr)(Aw + i * 256), 16, 0, 0);
+        for (int i = 0; i < QS; ++i) aw[i] = wsrc[i * 64 + lane];
+    } else {
+#pragma unroll
+        for (int i = 0; i < QS / 4; ++i)
+            __builtin_amdgcn_global_load_lds((lstm_gptr)(wsrc + i * 256 + lane * 4), (lstm_lptr)(Aw + i * 256), 16, 0, 0);
+    }
     if (threadIdx.x == 0) dead = 0;
     const int k4 = lane >> 4, cl = lane & 15;
     const int j = ub * 4 + k4;                      // this lane's hidden unit
@@ -423,24 +437,51 @@ __global__ __launch_bounds__(256 * UB, 1) void lstm_seq_kernel(const LstmSeqArgs
             }
             __syncthreads();
             if (dead) return;
-            const float* hp = ((t & 1) ? hx0 : hx1) + (int64_t)q * QS * 64 + lane;   // h_{t-1} sits in buffer (t-1)&1
             float hb[QS];
             // the h operands are read with agent-scope (sc1) loads: they observe the producers' write-through stores directly, so the
             // consumer needs no acquire fence (an agent-scope L1 invalidation costs ~1.7 us, more than the loads themselves)
+            if constexpr (HT) {
+                constexpr int NT = 256 * UB, NL = (CC * 16 + NT - 1) / NT;
+                const float* hsrc = (t & 1) ? hx0 : hx1;                 // h_{t-1} sits in buffer (t-1)&1: [unit][16 clips], CC * 16 words
+                float hv[NL];
 #pragma unroll
-            for (int i = 0; i < QS; ++i) {
+                for (int u = 0; u < NL; ++u) {
+                    const int idx = min(u * NT + (int)threadIdx.x, CC * 16 - 1);
 #ifdef NC_LSTM_FENCE
-                hb[i] = hp[i * 64];
+                    hv[u] = hsrc[idx];
 #else
-                hb[i] = __hip_atomic_load(hp + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hv[u] = __hip_atomic_load(hsrc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
-            }
-            if (q == 0) {
-                g0 = g[(int64_t)j * gc + tn * gt]; g1 = g[(int64_t)(C + j) * gc + tn * gt]; g2 = g[(int64_t)(2 * C + j) * gc + tn * gt]; g3 = g[(int64_t)(3 * C + j) * gc + tn * gt];
-                if (a.skip) sk = a.skip[orow + tn];
-            }
+                }
+                if (q == 0) {
+                    g0 = g[(int64_t)j * gc + tn * gt]; g1 = g[(int64_t)(C + j) * gc + tn * gt]; g2 = g[(int64_t)(2 * C + j) * gc + tn * gt]; g3 = g[(int64_t)(3 * C + j) * gc + tn * gt];
+                    if (a.skip) sk = a.skip[orow + tn];
+                }
 #pragma unroll
-            for (int i = 0; i < QS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[i * 64 + lane], hb[i], acc, 0, 0, 0);
+                for (int u = 0; u < NL; ++u)
+                    if (u * NT + (int)threadIdx.x < CC * 16) Hs[u * NT + threadIdx.x] = hv[u];
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < QS; ++i) hb[i] = Hs[(q * QS + i) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < QS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[i], hb[i], acc, 0, 0, 0);
+            } else {
+                const float* hp = ((t & 1) ? hx0 : hx1) + (int64_t)q * QS * 64 + lane;   // h_{t-1} sits in buffer (t-1)&1
+#pragma unroll
+                for (int i = 0; i < QS; ++i) {
+#ifdef NC_LSTM_FENCE
+                    hb[i] = hp[i * 64];
+#else
+                    hb[i] = __hip_atomic_load(hp + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+                }
+                if (q == 0) {
+                    g0 = g[(int64_t)j * gc + tn * gt]; g1 = g[(int64_t)(C + j) * gc + tn * gt]; g2 = g[(int64_t)(2 * C + j) * gc + tn * gt]; g3 = g[(int64_t)(3 * C + j) * gc + tn * gt];
+                    if (a.skip) sk = a.skip[orow + tn];
+                }
+#pragma unroll
+                for (int i = 0; i < QS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[i * 64 + lane], hb[i], acc, 0, 0, 0);
+            }
             if (q > 0) part[((q - 1) * UB + ubl) * 64 + lane] = acc;
             __syncthreads();
             if (q == 0) {
@@ -1673,9 +1714,16 @@ float* EncodecModel::run_lstm(Lstm& l, const float* x, int N, int64_t T, bool el
                     ensure_dynamic_lds((const void*)kern, lds);
                     hipLaunchKernelGGL(kern, dim3((unsigned)nprod, (unsigned)nt), dim3(256 * UBW), lds, s, a);
                 };
-                if (KS == 128 && UBW == 2) launch(lstm_seq_kernel<128, 2>);
-                else if (KS == 128) launch(lstm_seq_kernel<128, 4>);
-                else launch(lstm_seq_kernel<16, 4>);
+                static const bool no_htile = env_flag("NC_LSTM_NO_HTILE");   // every wave fetches its own h operands, W_hh in LDS (the round-2..5 form)
+                if (no_htile) {
+                    if (KS == 128 && UBW == 2) launch(lstm_seq_kernel<128, 2, false>);
+                    else if (KS == 128) launch(lstm_seq_kernel<128, 4, false>);
+                    else launch(lstm_seq_kernel<16, 4, false>);
+                } else {
+                    if (KS == 128 && UBW == 2) launch(lstm_seq_kernel<128, 2, true>);
+                    else if (KS == 128) launch(lstm_seq_kernel<128, 4, true>);
+                    else launch(lstm_seq_kernel<16, 4, true>);
+                }
             }
             NC_HIP(hipGetLastError());
             if (prof.on) prof.end(s);

@@ -79,6 +79,7 @@ const EnvRow kEnv[] = {
     {"NC_LSTM_CHUNKS", 'i', "layer-pipeline chunks of the per-layer persistent LSTM (6; 1 = layers in sequence)"},
     {"NC_LSTM_EVEN_CHUNKS", 'b', "equal LSTM chunks"},
     {"NC_LSTM_UB", 'i', "hidden-unit blocks per LSTM workgroup (2 | 4)"},
+    {"NC_LSTM_NO_HTILE", 'b', "persistent LSTM: every wavefront fetches its own h operands, W_hh in LDS (the form before the LDS h tile)"},
     {"NC_LSTM_NO_ELU", 'b', "the consumer applies the ELU behind an SLSTM"},
     {"NC_LSTM_FUSED", 'b', "EXPERIMENTS=1 builds: fused two-layer persistent LSTM (nc_lstm.hip; measured slower)"},
     {"NC_LSTM2_TRACE", 's', "EXPERIMENTS=1 builds: file for the in-kernel stamps of the fused LSTM (tools/probe/lstm2_trace.py)"},

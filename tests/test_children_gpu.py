@@ -110,7 +110,7 @@ FALLBACK_ROWS = [
     {"NC_NO_XV": "1"},                                                                 # legacy instances for the two-tap up-convolutions (item-form staging)
     {"NC_NO_XV_K7": "1"},                                                              # legacy instances for the k = 7 convolutions on the long rows
     {"NC_DUO": "1"},                                                                   # EXPERIMENTS=1 library: two tiles per 8-wavefront workgroup (k = 7)
-    {"NC_NO_RES_A": "1", "NC_NO_DOWN2": "1", "NC_NO_DOWN4": "1", "NC_NO_DOWN5": "1", "NC_NO_UP2": "1", "NC_NO_UP4": "1", "NC_NO_UP_PITCH": "1", "NC_RMS_TWO_PASS": "1"},                                                              # round-5 launches: two-launch first pass of the residual blocks, windowed stride-2 down-conv, two-pass RMS scale
+    {"NC_NO_RES_A": "1", "NC_NO_DOWN2": "1", "NC_NO_DOWN4": "1", "NC_NO_DOWN5": "1", "NC_NO_UP2": "1", "NC_NO_UP4": "1", "NC_NO_UP_PITCH": "1", "NC_RMS_TWO_PASS": "1", "NC_LSTM_NO_HTILE": "1"},                                                              # round-5 launches: two-launch first pass of the residual blocks, windowed stride-2 down-conv, two-pass RMS scale
 ]
 
 

@@ -46,6 +46,7 @@ run NC_NO_XV_K7=1
 # round 6: the streaming Encodec kernels and their layouts back on the paths they replaced; the DAC row pitch (opt-in, measured slower)
 run NC_NO_RES_A=1 NC_NO_DOWN2=1 NC_NO_DOWN4=1 NC_NO_DOWN5=1 NC_NO_UP2=1 NC_NO_UP4=1
 run NC_NO_UP_PITCH=1 NC_RMS_TWO_PASS=1 NC_LSTM_CHUNKS=3
+run NC_LSTM_NO_HTILE=1
 run NC_DAC_PITCH=1
 # round 5: the experiments library (measured-and-rejected kernels)
 expl NC_LSTM_FUSED=1 NC_RVQ_8WAVES=1
