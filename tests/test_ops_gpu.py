@@ -383,3 +383,36 @@ def test_conv1d_pointwise_short_row_form_bit_exact(cin, cout, T, B):
     got = ops.conv1d(x, w, b, 1, 0, 1)
     assert got.shape == want.shape
     assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+
+
+# ---- Encodec Euclidean RVQ: the all-stages matrix-core launch against the per-stage kernels and the C oracle (round 6: its codebook ring runs
+#      on across passes AND stages; N = 512 is one pass per wave, N = 1024 two; frame counts that leave the last workgroup ragged) ----
+@pytest.mark.parametrize("N,n_q,B,T", [(1024, 8, 3, 150), (512, 5, 2, 77), (1024, 3, 1, 31), (512, 1, 1, 4), (1024, 2, 5, 32)])
+def test_euclid_rvq_matrix_core_form_equals_stagewise_and_oracle(N, n_q, B, T):
+    rng = np.random.default_rng(1000 * N + T)
+    ze = rng.standard_normal((B, 128, T)).astype(np.float32)
+    books = rng.standard_normal((n_q, N, 128)).astype(np.float32)
+    c1, _ = ops.euclid_rvq(ze, books, form=1)
+    c0, r0 = ops.euclid_rvq(ze, books, form=0)
+    assert np.array_equal(c0, c1)
+    r = ze.copy()
+    for q in range(n_q):                                       # ResidualVectorQuantizer.cs:139-156 over EuclideanCodebook.cs:155-182
+        idx = c_oracle.vq_argmin(r, books[q])[0]
+        assert np.array_equal(c0[:, q, :], idx), f"stage {q}"
+        r = r - books[q][idx].transpose(0, 2, 1)
+    assert np.array_equal(r0, r)
+
+
+def test_euclid_rvq_matrix_core_form_refuses_large_codebooks():
+    """The all-stages launch keeps |c|^2 of a stage in 4 KB of LDS: codebooks above 1024 entries take the per-stage kernels (form 0 still serves them)."""
+    rng = np.random.default_rng(5)
+    ze = rng.standard_normal((1, 128, 9)).astype(np.float32)
+    books = rng.standard_normal((2, 2048, 128)).astype(np.float32)
+    with pytest.raises(Exception, match="512 or 1024"):
+        ops.euclid_rvq(ze, books, form=1)
+    c0, _ = ops.euclid_rvq(ze, books, form=0)
+    r = ze.copy()
+    for q in range(2):
+        idx = c_oracle.vq_argmin(r, books[q])[0]
+        assert np.array_equal(c0[:, q, :], idx)
+        r = r - books[q][idx].transpose(0, 2, 1)
