@@ -626,7 +626,7 @@ def main():
             tk7 = (tr or {}).get("conv_k7", {})
             algo_b = k7["bytes"] / max(k7["launches"], 1)
             roofline = {
-                "kernel": "conv_mfma_kernel<K=7> (dilated k=7 residual-unit conv, fp32 MFMA implicit GEMM; fused units include their 1x1)",
+                "kernel": "conv_mfma_kernel<K=7> (dilated k=7 residual-unit conv, fp32 MFMA implicit GEMM; fused units incl. their 1x1)",
                 "bound": "mfma", "achieved": round(ach_tflops, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": round(tk7["hbm_bytes_per_launch"]) if tk7 else None,
@@ -639,7 +639,7 @@ def main():
                 "pipe_busy": tk7.get("pipe_busy"),       # mfma_busy + valu_busy = the fraction of that shared pipe the class occupies
                 "algorithmic_bytes_per_launch": round(algo_b),
                 "launches_per_step": k7["launches"] / max(args.steps, 1),
-                "avg_launch_ms": k7["ms"] / max(k7["launches"], 1),
+                "avg_launch_ms": round(k7["ms"] / max(k7["launches"], 1), 5),
                 "flops_per_launch": k7["flops"] / max(k7["launches"], 1),
                 "share_of_kernel_time": round(k7["ms"] / total_kernel_ms, 4) if total_kernel_ms else None,
                 "all_classes": classes,
