@@ -1,5 +1,8 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: kernel time of the Euclidean RVQ launch in the C3 step under ablation builds of the library (build_abl/lib_rvq_*.so)
+# Runs ON THE GPU BOX: kernel time of the Euclidean RVQ launch in the C3 step under ablation builds of the library (build_abl/lib_rvq_*.so).
+# The builds came from tools/probe/mk_abl.sh rvq_<V> nc_encodec.hip -DRVQ_ABL_<V> with TEMPORARY #ifdef RVQ_ABL_NOMFMA / NOEPI / NOUPD / NOE2 blocks in
+# euclid_rvq_mfma_kernel (skip the matrix-core instructions / the dist + argmin / the residual update / the |e|^2 chain); the blocks were removed again
+# before the commit -- results of such builds are meaningless, only their timing was used (profiles/r06_ab_quantizers.txt).
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for v in "" NOMFMA NOEPI NOUPD NOE2; do
